@@ -1,0 +1,173 @@
+// attention.hip — multi-head self/cross attention of SuperGlue's GNN, flash style, on the fp32
+// matrix cores.  Replaces attention()/MultiHeadedAttention.forward's einsum-softmax-einsum
+// (superglue_test.py:85-89, :102-106); the N x M probability matrix is never materialised.
+//
+// Layout: qkv rows = keypoints ([side0: B*N0p][side1: B*N1p]), ld = 3d, columns [q | k | v], each
+// re-ordered head-major (head*HD + dim) when the projection weights are loaded (the reference's
+// view(b, dim, heads, n) is dim-major/head-minor, :104).  Output rows likewise, ld = d.
+//
+// Workgroup = 4 waves; a wave owns 32 queries and walks all keys in tiles of 32 (K/V tile staged
+// in LDS, double buffered, one barrier per tile).  Per tile and wave:
+//   S^T = K.Q^T      HD/2 x v_mfma_f32_32x32x2_f32: lane (q = lane&31) ends up holding 16 keys'
+//                    scores of ITS query (the other 16 live in lane^32) -> the softmax row
+//                    reductions are in-lane plus one cross-half shuffle;
+//   online softmax   running max m, denominator l, rescale factor all lane-local per query;
+//   O^T += V^T.P^T   16 MFMAs per 32 output dims: the MFMA k-index is only a summation index, so
+//                    step s pairs key (s&3)+8(s>>2) (lanes 0-31) with that key +4 (lanes 32-63):
+//                    exactly the keys whose probabilities sit in accumulator register s — P is fed
+//                    to the matrix core straight from the S accumulators, no transposes, no LDS.
+#include "imx_kernels.h"
+#include <math.h>
+
+namespace imx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+template <int HD>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale) {
+  constexpr int KS = HD + 1;          // K tile row stride (odd: conflict-free column reads)
+  constexpr int OB = HD / 32;         // output blocks of 32 dims
+  __shared__ __attribute__((aligned(16))) float Kt[2][32 * KS];
+  __shared__ __attribute__((aligned(16))) float Vt[2][32 * HD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y;
+  const int side = blockIdx.z / p.B, b = blockIdx.z % p.B;
+  const int kside = p.cross ? 1 - side : side;
+  const int Nqp = side ? p.N1p : p.N0p, Nkp = kside ? p.N1p : p.N0p;
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= Nqp) return;
+  const int nq = side ? (p.n1 ? p.n1[b] : p.N1) : (p.n0 ? p.n0[b] : p.N0);
+  const int nk = kside ? (p.n1 ? p.n1[b] : p.N1) : (p.n0 ? p.n0[b] : p.N0);
+  const size_t qbase = (side ? (size_t)p.B * p.N0p : 0) + (size_t)b * Nqp;
+  const size_t kbase = (kside ? (size_t)p.B * p.N0p : 0) + (size_t)b * Nkp;
+  const int ld = 3 * p.d;
+  const int qrow = q0 + 32 * wave + l31;
+  const bool wave_active = (q0 + 32 * wave) < Nqp;   // whole wave inside the padded row range
+
+  // Q fragment: lane holds Q[q][16*hi*(HD/32) ...]: dims [hi*HD/2, hi*HD/2 + HD/2)
+  float q[HD / 2];
+  if (wave_active) {
+    const float* qp = p.qkv + (qbase + qrow) * ld + head * HD + hi * (HD / 2);
+#pragma unroll
+    for (int t = 0; t < HD / 2; t += 4) {
+      float4 v = *reinterpret_cast<const float4*>(qp + t);
+      q[t] = v.x; q[t + 1] = v.y; q[t + 2] = v.z; q[t + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < HD / 2; ++t) q[t] = 0.f;
+  }
+
+  f32x16 O[OB];
+#pragma unroll
+  for (int o = 0; o < OB; ++o)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[o][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  const int nt = (nk + 31) / 32;
+  // staging map: 32 keys x HD dims, float4 per thread-iteration
+  constexpr int V4 = HD / 4;                 // float4 per row
+  constexpr int ITER = (32 * V4) / 256;      // 1 (HD=32) or 2 (HD=64)
+  float4 kreg[ITER], vreg[ITER];
+#define IMX_GLOAD(kt_)                                                                         \
+  _Pragma("unroll") for (int it = 0; it < ITER; ++it) {                                        \
+    const int e = tid + it * 256, key = e / V4, v4 = e % V4;                                   \
+    const float* base = p.qkv + (kbase + (size_t)(kt_) * 32 + key) * ld + head * HD + 4 * v4;  \
+    kreg[it] = *reinterpret_cast<const float4*>(base + p.d);                                   \
+    vreg[it] = *reinterpret_cast<const float4*>(base + 2 * p.d);                               \
+  }
+#define IMX_LSTORE(buf_)                                                                       \
+  _Pragma("unroll") for (int it = 0; it < ITER; ++it) {                                        \
+    const int e = tid + it * 256, key = e / V4, v4 = e % V4;                                   \
+    float* kd = &Kt[buf_][key * KS + 4 * v4];                                                  \
+    kd[0] = kreg[it].x; kd[1] = kreg[it].y; kd[2] = kreg[it].z; kd[3] = kreg[it].w;            \
+    *reinterpret_cast<float4*>(&Vt[buf_][key * HD + 4 * v4]) = vreg[it];                       \
+  }
+
+  if (nt > 0) { IMX_GLOAD(0) IMX_LSTORE(0) }
+  __syncthreads();
+
+  for (int kt = 0; kt < nt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nt) { IMX_GLOAD(kt + 1) }
+    if (wave_active) {
+      // ---- S^T = K . Q^T
+      f32x16 S;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = 0.f;
+      const float* kp = &Kt[buf][l31 * KS + hi * (HD / 2)];
+#pragma unroll
+      for (int t = 0; t < HD / 2; ++t) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[t], q[t], S, 0, 0, 0);
+      // ---- online softmax over this tile's 32 keys (16 here, 16 in lane^32)
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float s = S[r] * scale;
+        s = key < nk ? s : -INFINITY;
+        S[r] = s;
+        mx = fmaxf(mx, s);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mn = fmaxf(m, mx);
+      const float alpha = expf(m - mn);      // m = -inf on the first tile -> 0
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pr = expf(S[r] - mn);
+        S[r] = pr;
+        rs += pr;
+      }
+      rs += __shfl_xor(rs, 32);
+      l = l * alpha + rs;
+      m = mn;
+      // ---- O^T = O^T * alpha + V^T . P^T
+      const float* vp = &Vt[buf][(4 * hi) * HD + l31];
+#pragma unroll
+      for (int o = 0; o < OB; ++o) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[o][r] *= alpha;
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+          const int key_lo = (st & 3) + 8 * (st >> 2);
+          O[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[key_lo * HD + o * 32], S[st], O[o], 0, 0, 0);
+        }
+      }
+    }
+    if (kt + 1 < nt) { IMX_LSTORE(buf ^ 1) }
+    __syncthreads();
+  }
+
+  if (wave_active) {
+    const float inv = (l > 0.f && qrow < nq) ? 1.0f / l : 0.f;   // rows past the valid count: zeros
+    float* op = p.out + (qbase + qrow) * p.d + head * HD;
+#pragma unroll
+    for (int o = 0; o < OB; ++o)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(O[o][4 * g] * inv, O[o][4 * g + 1] * inv, O[o][4 * g + 2] * inv, O[o][4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(op + o * 32 + 8 * g + 4 * hi) = v;
+      }
+  }
+}
+
+#undef IMX_GLOAD
+#undef IMX_LSTORE
+}  // namespace
+
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+  const int hd = a.d / a.heads;
+  const int nmax = a.N0p > a.N1p ? a.N0p : a.N1p;
+  dim3 grid((unsigned)((nmax + 127) / 128), (unsigned)a.heads, (unsigned)(2 * a.B));
+  const float scale = (float)(1.0 / sqrt((double)hd));
+  if (hd == 32) hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(256), 0, s, a, scale);
+  else if (hd == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, s, a, scale);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace imx

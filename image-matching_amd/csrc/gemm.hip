@@ -1,0 +1,158 @@
+// gemm.hip — row-major fp32 GEMMs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// launch_gemm        out = act([a0|a1] . W + bias) (+ res): every 1x1 Conv2d / Conv1d(k=1) of the
+//                    path — convPb/convDb (superpoint_test.py:78,83), the MLPs, projections and
+//                    merges of superglue_test.py:49-60,92-119,214-216 — with BatchNorm folded into
+//                    W/bias and the torch.cat([x, message]) of :119 expressed as a K split.
+// launch_score_gemm  scores = mdesc0^T mdesc1 / sqrt(d)  (superglue_test.py:259-260).
+//
+// Workgroup = 256 threads -> 128 rows x NT columns; wave w owns rows [32w, 32w+32) x NT/32 N-blocks.
+// K in chunks of 32: A tile [128][33] (odd stride: conflict-free 32-lane column reads),
+// W tile [32][NT] (row reads, conflict free).
+#include "imx_kernels.h"
+
+namespace imx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+constexpr int BM = 128, CK = 32, SA = CK + 1;
+
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
+  constexpr int NB = NT / 32;
+  __shared__ __attribute__((aligned(16))) float smem[BM * SA + CK * NT];
+  float* a_tile = smem;
+  float* w_tile = smem + BM * SA;   // BM*SA = 4224 floats, 16-B aligned
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * BM, n0 = blockIdx.y * NT;
+  const int K = p.K0 + p.K1;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+  for (int c0 = 0; c0 < K; c0 += CK) {
+    const float* src; int lda, cc;
+    if (c0 < p.K0) { src = p.a0; lda = p.lda0; cc = c0; } else { src = p.a1; lda = p.lda1; cc = c0 - p.K0; }
+    __syncthreads();
+    for (int e = tid; e < BM * (CK / 4); e += 256) {
+      int row = e / (CK / 4), v4 = e % (CK / 4);
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + row < p.M) val = *reinterpret_cast<const float4*>(src + (size_t)(r0 + row) * lda + cc + 4 * v4);
+      float* d = a_tile + row * SA + 4 * v4;
+      d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+    }
+    for (int e = tid; e < CK * NT / 4; e += 256) {
+      int idx = e * 4, k = idx / NT, col = idx % NT;
+      *reinterpret_cast<float4*>(w_tile + idx) =
+          *reinterpret_cast<const float4*>(p.w + (size_t)(c0 + k) * p.Npad + n0 + col);
+    }
+    __syncthreads();
+    const float* ap = a_tile + (32 * wave + (lane & 31)) * SA + (lane >> 5);
+    const float* bp = w_tile + (lane >> 5) * NT + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < CK / 2; ++kk) {
+      float a = ap[2 * kk];
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[2 * kk * NT + n * 32], acc[n], 0, 0, 0);
+    }
+  }
+
+  const int hi = lane >> 5;
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const int col = n0 + n * 32 + (lane & 31);
+    if (col >= p.N) continue;
+    const float bs = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = r0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (row >= p.M) continue;
+      float v = acc[n][r] + bs;
+      if (p.relu) v = fmaxf(v, 0.f);
+      if (p.res) v = p.res[(size_t)row * p.ldr + col] + v;
+      p.out[(size_t)row * p.ldo + col] = v;
+    }
+  }
+}
+
+// "NT" GEMM: both operands row-major [row][k]; tile 128 (i) x 64 (j).
+__global__ __launch_bounds__(256) void score_mfma(ScoreArgs p) {
+  constexpr int NT = 64, NB = 2;
+  __shared__ __attribute__((aligned(16))) float smem[(BM + NT) * SA];
+  float* a_tile = smem;
+  float* b_tile = smem + BM * SA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.x * BM, j0 = blockIdx.y * NT, b = blockIdx.z;
+  const float* m0 = p.m0 + (size_t)b * p.N0p * p.d;
+  const float* m1 = p.m1 + (size_t)b * p.N1p * p.d;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+  for (int c0 = 0; c0 < p.d; c0 += CK) {
+    __syncthreads();
+    for (int e = tid; e < (BM + NT) * (CK / 4); e += 256) {
+      int row = e / (CK / 4), v4 = e % (CK / 4);
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < BM) {
+        if (i0 + row < p.N0p) val = *reinterpret_cast<const float4*>(m0 + (size_t)(i0 + row) * p.d + c0 + 4 * v4);
+      } else {
+        if (j0 + row - BM < p.N1p) val = *reinterpret_cast<const float4*>(m1 + (size_t)(j0 + row - BM) * p.d + c0 + 4 * v4);
+      }
+      float* d = smem + row * SA + 4 * v4;
+      d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
+    }
+    __syncthreads();
+    const float* ap = a_tile + (32 * wave + (lane & 31)) * SA + (lane >> 5);
+    const float* bp = b_tile + (lane & 31) * SA + (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < CK / 2; ++kk) {
+      float a = ap[2 * kk];
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[n * 32 * SA + 2 * kk], acc[n], 0, 0, 0);
+    }
+  }
+  const int hi = lane >> 5;
+  float* out = p.out + (size_t)b * p.N0p * p.N1p;
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const int j = j0 + n * 32 + (lane & 31);
+    if (j >= p.N1p) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (i < p.N0p) out[(size_t)i * p.N1p + j] = acc[n][r] * p.scale;
+    }
+  }
+}
+}  // namespace
+
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+  if (a.K0 % CK || a.K1 % CK || a.Npad % 64 || a.M <= 0) return hipErrorInvalidValue;
+  const unsigned gm = (unsigned)((a.M + BM - 1) / BM);
+  if (a.Npad % 128 == 0) {
+    hipLaunchKernelGGL(gemm_mfma<128>, dim3(gm, a.Npad / 128), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(gemm_mfma<64>, dim3(gm, a.Npad / 64), dim3(256), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_score_gemm(const ScoreArgs& a, hipStream_t s) {
+  if (a.d % CK) return hipErrorInvalidValue;
+  dim3 grid((unsigned)((a.N0p + BM - 1) / BM), (unsigned)((a.N1p + 63) / 64), (unsigned)a.B);
+  hipLaunchKernelGGL(score_mfma, grid, dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace imx

@@ -1,0 +1,810 @@
+// imx_api.cpp — C ABI of libimx.so (include/imx.h): handle, weight loading with BatchNorm
+// folding and layout transforms, workspace, and the launch sequences of the SuperPoint /
+// SuperGlue / Matching forwards.  All arithmetic of the path runs in the kernels declared in
+// imx_kernels.h; this file only moves weights once and enqueues kernels on the caller's stream.
+#include "../../include/imx.h"
+#include "imx_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace imx;
+
+namespace {
+
+constexpr double BN_EPS = 1e-5;   // nn.BatchNorm default (unet_parts.py:16; superglue_test.py:58)
+constexpr int HEADS = 4;          // AttentionalPropagation(feature_dim, 4), superglue_test.py:126
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+struct ConvW {
+  float* w = nullptr;
+  float* b = nullptr;
+  int cin = 0, cout = 0;
+};
+struct GemmW {
+  float* w = nullptr;
+  float* b = nullptr;
+  int K = 0, N = 0, Npad = 0;
+};
+struct GnnLayer {
+  GemmW qkv, merge, mlp1, mlp2;
+};
+struct Tap {
+  const void* p;
+  std::vector<int64_t> shape;
+};
+struct TimedEvent {
+  std::string name;
+  hipEvent_t e0, e1;
+};
+struct TimingRow {
+  std::string name;
+  int64_t launches;
+  double ms;
+};
+
+std::string g_create_error;
+
+}  // namespace
+
+struct imx_handle_s {
+  int device = 0;
+  imx_config_t cfg{};
+  std::string err;
+  std::map<std::string, std::vector<int64_t>> expected[2];
+  std::map<std::string, HostTensor> raw[2];
+  bool finalized[2] = {false, false};
+  std::vector<void*> weight_allocs;
+  // SuperPoint
+  float *w1 = nullptr, *b1 = nullptr;
+  ConvW conv[8];   // conv1b, 2a, 2b, 3a, 3b, 4a, 4b, heads (convPa | convDa)
+  GemmW pb, db;
+  // SuperGlue
+  float *kenc0_w = nullptr, *kenc0_b = nullptr;
+  int kenc_c1 = 0;
+  std::vector<GemmW> kenc;
+  std::vector<GnnLayer> layers;
+  GemmW final_proj;
+  float bin_score = 1.f;
+  // workspace
+  std::map<std::string, DevBuf> bufs;
+  // state of the last detect
+  int det_B = 0, det_H = 0, det_W = 0, det_Hc = 0, det_Wc = 0, det_Ksel = 0;
+  // debug / timing
+  bool debug = false, timing = false;
+  std::map<std::string, Tap> taps;
+  std::vector<TimedEvent> events;
+  std::vector<TimingRow> report;
+};
+
+namespace {
+
+int fail(imx_handle_t h, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf; else g_create_error = buf;
+  return -1;
+}
+
+#define HIP_OK(h, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) return fail(h, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+float* ws(imx_handle_t h, const std::string& name, size_t bytes) {
+  DevBuf& b = h->bufs[name];
+  if (b.bytes >= bytes && b.p) return static_cast<float*>(b.p);
+  if (b.p) {
+    (void)hipDeviceSynchronize();
+    (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  if (hipMalloc(&b.p, want) != hipSuccess) {
+    b.p = nullptr;
+    h->err = "hipMalloc failed for workspace '" + name + "' (" + std::to_string(want) + " bytes)";
+    return nullptr;
+  }
+  b.bytes = want;
+  return static_cast<float*>(b.p);
+}
+#define WS(var, type, name, bytes)                         \
+  type* var = reinterpret_cast<type*>(ws(h, name, bytes)); \
+  if (!var) return -1;
+
+template <class F>
+int run(imx_handle_t h, const char* name, hipStream_t s, F&& f) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->timing) {
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(h, "hipEventCreate failed");
+    (void)hipEventRecord(e0, s);
+  }
+  hipError_t e = f();
+  if (h->timing) {
+    (void)hipEventRecord(e1, s);
+    h->events.push_back({name, e0, e1});
+  }
+  if (e != hipSuccess) return fail(h, "kernel '%s' launch failed: %s", name, hipGetErrorString(e));
+  return 0;
+}
+#define RUN(name, expr)                                              \
+  do {                                                               \
+    if (run(h, name, s, [&]() -> hipError_t { return (expr); })) return -1; \
+  } while (0)
+
+void tap(imx_handle_t h, const char* name, const void* p, std::vector<int64_t> shape) { h->taps[name] = Tap{p, std::move(shape)}; }
+
+// ----------------------------------------------------------------------------- expected keys
+void add_conv_keys(std::map<std::string, std::vector<int64_t>>& m, const std::string& conv, int cout, int cin, int k,
+                   const std::string& bn) {
+  if (k > 0) m[conv + ".weight"] = {cout, cin, k, k}; else m[conv + ".weight"] = {cout, cin, 1};
+  m[conv + ".bias"] = {cout};
+  if (!bn.empty())
+    for (const char* leaf : {"weight", "bias", "running_mean", "running_var"}) m[bn + "." + leaf] = {cout};
+}
+
+void build_expected(imx_handle_t h) {
+  const imx_config_t& c = h->cfg;
+  auto& sp = h->expected[IMX_NET_SUPERPOINT];
+  const int c1 = 64, c2 = 64, c3 = 128, c4 = 128, c5 = 256, d = c.descriptor_dim;
+  if (c.sp_variant == IMX_SP_VARIANT_BN) {
+    const char* blocks[4] = {"inc.conv.conv", "down1.mpconv.1.conv", "down2.mpconv.1.conv", "down3.mpconv.1.conv"};
+    const int cin[4] = {1, c1, c2, c3}, cout[4] = {c1, c2, c3, c4};
+    for (int i = 0; i < 4; ++i) {
+      std::string p = blocks[i];
+      add_conv_keys(sp, p + ".0", cout[i], cin[i], 3, p + ".1");
+      add_conv_keys(sp, p + ".3", cout[i], cout[i], 3, p + ".4");
+    }
+    add_conv_keys(sp, "convPa", c5, c4, 3, "bnPa");
+    add_conv_keys(sp, "convPb", 65, c5, 1, "bnPb");
+    add_conv_keys(sp, "convDa", c5, c4, 3, "bnDa");
+    add_conv_keys(sp, "convDb", d, c5, 1, "bnDb");
+  } else {
+    const char* names[8] = {"conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b"};
+    const int cin[8] = {1, c1, c1, c2, c2, c3, c3, c4}, cout[8] = {c1, c1, c2, c2, c3, c3, c4, c4};
+    for (int i = 0; i < 8; ++i) add_conv_keys(sp, names[i], cout[i], cin[i], 3, "");
+    add_conv_keys(sp, "convPa", c5, c4, 3, "");
+    add_conv_keys(sp, "convPb", 65, c5, 1, "");
+    add_conv_keys(sp, "convDa", c5, c4, 3, "");
+    add_conv_keys(sp, "convDb", d, c5, 1, "");
+  }
+  auto& sg = h->expected[IMX_NET_SUPERGLUE];
+  sg["bin_score"] = {};
+  std::vector<int> ch = {3};
+  for (int i = 0; i < c.kenc_n; ++i) ch.push_back(c.kenc_channels[i]);
+  ch.push_back(d);
+  for (size_t i = 1; i < ch.size(); ++i) {
+    int j = 3 * (int)(i - 1);
+    std::string p = "kenc.encoder." + std::to_string(j);
+    add_conv_keys(sg, p, ch[i], ch[i - 1], 0, i + 1 < ch.size() ? "kenc.encoder." + std::to_string(j + 1) : "");
+  }
+  for (int l = 0; l < c.num_gnn_layers; ++l) {
+    std::string p = "gnn.layers." + std::to_string(l);
+    add_conv_keys(sg, p + ".attn.merge", d, d, 0, "");
+    for (int k = 0; k < 3; ++k) add_conv_keys(sg, p + ".attn.proj." + std::to_string(k), d, d, 0, "");
+    add_conv_keys(sg, p + ".mlp.0", 2 * d, 2 * d, 0, p + ".mlp.1");
+    add_conv_keys(sg, p + ".mlp.3", d, 2 * d, 0, "");
+  }
+  add_conv_keys(sg, "final_proj", d, d, 0, "");
+}
+
+// ----------------------------------------------------------------------------- weight folding
+bool ends_with(const std::string& s, const std::string& suf) {
+  return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+float* upload(imx_handle_t h, const std::vector<float>& v) {
+  void* p = nullptr;
+  if (hipMalloc(&p, v.size() * sizeof(float) + 16) != hipSuccess) return nullptr;
+  if (hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(p);
+    return nullptr;
+  }
+  h->weight_allocs.push_back(p);
+  return static_cast<float*>(p);
+}
+
+// per-output-channel scale s and shift t such that BN(conv + b) = conv*s + t
+void fold_bn(const std::map<std::string, HostTensor>& raw, const std::string& conv, const std::string& bn, int cout,
+             std::vector<double>& s, std::vector<double>& t) {
+  const std::vector<float>& b = raw.at(conv + ".bias").data;
+  s.assign(cout, 1.0);
+  t.resize(cout);
+  if (bn.empty()) {
+    for (int c = 0; c < cout; ++c) t[c] = b[c];
+    return;
+  }
+  const auto& g = raw.at(bn + ".weight").data;
+  const auto& be = raw.at(bn + ".bias").data;
+  const auto& mu = raw.at(bn + ".running_mean").data;
+  const auto& var = raw.at(bn + ".running_var").data;
+  for (int c = 0; c < cout; ++c) {
+    s[c] = (double)g[c] / std::sqrt((double)var[c] + BN_EPS);
+    t[c] = ((double)b[c] - (double)mu[c]) * s[c] + (double)be[c];
+  }
+}
+
+// torch Conv2d (Cout,Cin,3,3) -> [tap = ky*3+kx][ci][co_off + co] of a [9][Cin][cout_total] buffer
+void put_conv3(const std::map<std::string, HostTensor>& raw, const std::string& conv, const std::string& bn, int cin,
+               int cout, int cout_total, int co_off, std::vector<float>& w, std::vector<float>& bias) {
+  std::vector<double> s, t;
+  fold_bn(raw, conv, bn, cout, s, t);
+  const std::vector<float>& src = raw.at(conv + ".weight").data;
+  for (int co = 0; co < cout; ++co) {
+    for (int ci = 0; ci < cin; ++ci)
+      for (int tp = 0; tp < 9; ++tp)
+        w[((size_t)tp * cin + ci) * cout_total + co_off + co] = (float)((double)src[((size_t)co * cin + ci) * 9 + tp] * s[co]);
+    bias[co_off + co] = (float)t[co];
+  }
+}
+
+int make_conv(imx_handle_t h, ConvW& out, const std::map<std::string, HostTensor>& raw, const std::string& conv,
+              const std::string& bn, int cin, int cout) {
+  std::vector<float> w((size_t)9 * cin * cout), b(cout);
+  put_conv3(raw, conv, bn, cin, cout, cout, 0, w, b);
+  out.w = upload(h, w);
+  out.b = upload(h, b);
+  out.cin = cin;
+  out.cout = cout;
+  return (out.w && out.b) ? 0 : fail(h, "weight upload failed (%s)", conv.c_str());
+}
+
+// linear weight (N,K[,1[,1]]) -> W[k_perm(k)][n_perm(n)] padded to Npad columns, folded BN
+int make_gemm(imx_handle_t h, GemmW& out, const std::map<std::string, HostTensor>& raw, const std::string& conv,
+              const std::string& bn, int K, int N, const std::vector<int>* kperm = nullptr) {
+  const int Npad = ((N + 63) / 64) * 64;
+  std::vector<double> s, t;
+  fold_bn(raw, conv, bn, N, s, t);
+  const std::vector<float>& src = raw.at(conv + ".weight").data;
+  std::vector<float> w((size_t)K * Npad, 0.f), b(Npad, 0.f);
+  for (int n = 0; n < N; ++n) {
+    for (int k = 0; k < K; ++k) {
+      const int kk = kperm ? (*kperm)[k] : k;   // kk = position of reference input channel k in OUR layout
+      w[(size_t)kk * Npad + n] = (float)((double)src[(size_t)n * K + k] * s[n]);
+    }
+    b[n] = (float)t[n];
+  }
+  out.w = upload(h, w);
+  out.b = upload(h, b);
+  out.K = K;
+  out.N = N;
+  out.Npad = Npad;
+  return (out.w && out.b) ? 0 : fail(h, "weight upload failed (%s)", conv.c_str());
+}
+
+int finalize_superpoint(imx_handle_t h) {
+  const auto& raw = h->raw[IMX_NET_SUPERPOINT];
+  const bool bn = h->cfg.sp_variant == IMX_SP_VARIANT_BN;
+  const int d = h->cfg.descriptor_dim;
+  std::string ck[8], bk[8];
+  if (bn) {
+    const char* blocks[4] = {"inc.conv.conv", "down1.mpconv.1.conv", "down2.mpconv.1.conv", "down3.mpconv.1.conv"};
+    for (int i = 0; i < 4; ++i) {
+      ck[2 * i] = std::string(blocks[i]) + ".0"; bk[2 * i] = std::string(blocks[i]) + ".1";
+      ck[2 * i + 1] = std::string(blocks[i]) + ".3"; bk[2 * i + 1] = std::string(blocks[i]) + ".4";
+    }
+  } else {
+    const char* names[8] = {"conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b"};
+    for (int i = 0; i < 8; ++i) ck[i] = names[i];
+  }
+  // conv1a: (64,1,3,3) -> [9][64]
+  {
+    std::vector<float> w(9 * 64), b(64);
+    put_conv3(raw, ck[0], bk[0], 1, 64, 64, 0, w, b);
+    h->w1 = upload(h, w);
+    h->b1 = upload(h, b);
+    if (!h->w1 || !h->b1) return fail(h, "weight upload failed (conv1a)");
+  }
+  const int cin[8] = {1, 64, 64, 64, 64, 128, 128, 128}, cout[8] = {64, 64, 64, 64, 128, 128, 128, 128};
+  for (int i = 1; i < 8; ++i)
+    if (make_conv(h, h->conv[i - 1], raw, ck[i], bk[i], cin[i], cout[i])) return -1;
+  // heads: convPa | convDa merged into one 128 -> 512 convolution
+  {
+    std::vector<float> w((size_t)9 * 128 * 512), b(512);
+    put_conv3(raw, "convPa", bn ? "bnPa" : "", 128, 256, 512, 0, w, b);
+    put_conv3(raw, "convDa", bn ? "bnDa" : "", 128, 256, 512, 256, w, b);
+    h->conv[7].w = upload(h, w);
+    h->conv[7].b = upload(h, b);
+    h->conv[7].cin = 128;
+    h->conv[7].cout = 512;
+    if (!h->conv[7].w || !h->conv[7].b) return fail(h, "weight upload failed (heads)");
+  }
+  if (make_gemm(h, h->pb, raw, "convPb", bn ? "bnPb" : "", 256, 65)) return -1;
+  if (make_gemm(h, h->db, raw, "convDb", bn ? "bnDb" : "", 256, d)) return -1;
+  return 0;
+}
+
+int finalize_superglue(imx_handle_t h) {
+  const auto& raw = h->raw[IMX_NET_SUPERGLUE];
+  const imx_config_t& c = h->cfg;
+  const int d = c.descriptor_dim;
+  if (d % (HEADS * 32) != 0 || (d / HEADS != 32 && d / HEADS != 64))
+    return fail(h, "SuperGlue needs descriptor_dim/4 in {32,64} (got descriptor_dim=%d)", d);
+  h->bin_score = raw.at("bin_score").data[0];
+  std::vector<int> ch = {3};
+  for (int i = 0; i < c.kenc_n; ++i) ch.push_back(c.kenc_channels[i]);
+  ch.push_back(d);
+  for (size_t i = 1; i < ch.size(); ++i)
+    if (ch[i] % 32) return fail(h, "keypoint_encoder widths must be multiples of 32 (got %d)", ch[i]);
+  // layer 0: (C1,3,1) + BN -> w[3][C1]
+  {
+    const int C1 = ch[1];
+    std::vector<double> s, t;
+    fold_bn(raw, "kenc.encoder.0", ch.size() > 2 ? "kenc.encoder.1" : "", C1, s, t);
+    const auto& src = raw.at("kenc.encoder.0.weight").data;
+    std::vector<float> w(3 * C1), b(C1);
+    for (int n = 0; n < C1; ++n) {
+      for (int k = 0; k < 3; ++k) w[k * C1 + n] = (float)((double)src[n * 3 + k] * s[n]);
+      b[n] = (float)t[n];
+    }
+    h->kenc0_w = upload(h, w);
+    h->kenc0_b = upload(h, b);
+    h->kenc_c1 = C1;
+    if (!h->kenc0_w || !h->kenc0_b) return fail(h, "weight upload failed (kenc0)");
+  }
+  h->kenc.clear();
+  for (size_t i = 2; i < ch.size(); ++i) {
+    int j = 3 * (int)(i - 1);
+    GemmW g;
+    if (make_gemm(h, g, raw, "kenc.encoder." + std::to_string(j),
+                  i + 1 < ch.size() ? "kenc.encoder." + std::to_string(j + 1) : "", ch[i - 1], ch[i]))
+      return -1;
+    h->kenc.push_back(g);
+  }
+  // channel permutation: reference channel c = dim*HEADS + head (view(b, dim, heads, n),
+  // superglue_test.py:104)  ->  ours = head*HD + dim
+  const int HD = d / HEADS;
+  std::vector<int> perm(d);
+  for (int cidx = 0; cidx < d; ++cidx) perm[cidx] = (cidx % HEADS) * HD + cidx / HEADS;
+  h->layers.clear();
+  for (int l = 0; l < c.num_gnn_layers; ++l) {
+    std::string p = "gnn.layers." + std::to_string(l);
+    GnnLayer L;
+    // fused q|k|v projection: W[k][which*d + perm(n)]
+    {
+      const int N = 3 * d;
+      std::vector<float> w((size_t)d * N, 0.f), b(N, 0.f);
+      for (int which = 0; which < 3; ++which) {
+        const auto& src = raw.at(p + ".attn.proj." + std::to_string(which) + ".weight").data;
+        const auto& bs = raw.at(p + ".attn.proj." + std::to_string(which) + ".bias").data;
+        for (int n = 0; n < d; ++n) {
+          for (int k = 0; k < d; ++k) w[(size_t)k * N + which * d + perm[n]] = src[(size_t)n * d + k];
+          b[which * d + perm[n]] = bs[n];
+        }
+      }
+      L.qkv.w = upload(h, w);
+      L.qkv.b = upload(h, b);
+      L.qkv.K = d;
+      L.qkv.N = N;
+      L.qkv.Npad = N;
+      if (!L.qkv.w || !L.qkv.b) return fail(h, "weight upload failed (%s qkv)", p.c_str());
+    }
+    if (make_gemm(h, L.merge, raw, p + ".attn.merge", "", d, d, &perm)) return -1;
+    if (make_gemm(h, L.mlp1, raw, p + ".mlp.0", p + ".mlp.1", 2 * d, 2 * d)) return -1;
+    if (make_gemm(h, L.mlp2, raw, p + ".mlp.3", "", 2 * d, d)) return -1;
+    h->layers.push_back(L);
+  }
+  if (make_gemm(h, h->final_proj, raw, "final_proj", "", d, d)) return -1;
+  return 0;
+}
+
+hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+int pad32(int n) { return ((n + 31) / 32) * 32; }
+
+int gemm(imx_handle_t h, hipStream_t s, const char* name, const GemmW& W, const float* a0, int lda0, int K0, const float* a1,
+         int lda1, int K1, const float* res, int ldr, float* out, int ldo, int M, bool relu) {
+  if (K0 + K1 != W.K) return fail(h, "internal: gemm '%s' K mismatch (%d+%d vs %d)", name, K0, K1, W.K);
+  GemmArgs g{a0, lda0, K0, a1, lda1, K1, W.w, W.b, res, ldr, out, ldo, M, W.N, W.Npad, relu ? 1 : 0};
+  RUN(name, launch_gemm(g, s));
+  return 0;
+}
+
+// ----------------------------------------------------------------------------- SuperPoint
+int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, int B, int H, int W, int32_t* counts_out,
+              hipStream_t s) {
+  if (!h->finalized[IMX_NET_SUPERPOINT]) return fail(h, "SuperPoint weights not finalized");
+  if (B <= 0 || H < 8 || W < 8) return fail(h, "bad image batch shape B=%d H=%d W=%d", B, H, W);
+  const imx_config_t& c = h->cfg;
+  const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, Hc = H4 / 2, Wc = W4 / 2, H8 = Hc * 8, W8 = Wc * 8;
+  const int d = c.descriptor_dim;
+  const size_t f = sizeof(float);
+  WS(a1, float, "sp.a1", (size_t)B * H2 * W2 * 64 * f);
+  WS(a2a, float, "sp.a2a", (size_t)B * H2 * W2 * 64 * f);
+  WS(a2, float, "sp.a2", (size_t)B * H4 * W4 * 64 * f);
+  WS(a3a, float, "sp.a3a", (size_t)B * H4 * W4 * 128 * f);
+  WS(a3, float, "sp.a3", (size_t)B * Hc * Wc * 128 * f);
+  WS(a4a, float, "sp.a4a", (size_t)B * Hc * Wc * 128 * f);
+  WS(x4, float, "sp.x4", (size_t)B * Hc * Wc * 128 * f);
+  WS(hd, float, "sp.heads", (size_t)B * Hc * Wc * 512 * f);
+  WS(semi, float, "sp.semi", (size_t)B * Hc * Wc * 65 * f);
+  WS(dense, float, "sp.dense", (size_t)B * Hc * Wc * d * f);
+  WS(smap, float, "sp.score_map", (size_t)B * H8 * W8 * f);
+  WS(nms, float, "sp.nms", (size_t)B * H8 * W8 * f);
+
+  auto conv = [&](const char* name, const ConvW& w, const float* in, float* out, int hh, int ww, bool pool, bool first) -> int {
+    ConvArgs a{};
+    a.in = in; a.in2 = first ? img1 : nullptr; a.split = first ? split : 0;
+    a.w = w.w; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
+    a.B = B; a.H = hh; a.W = ww; a.Cin = w.cin; a.Cout = w.cout; a.relu = 1; a.pool = pool ? 1 : 0; a.first = first ? 1 : 0;
+    RUN(name, launch_conv3x3(a, s));
+    return 0;
+  };
+  if (conv("conv1ab_pool", h->conv[0], img0, a1, H, W, true, true)) return -1;
+  if (conv("conv2a", h->conv[1], a1, a2a, H2, W2, false, false)) return -1;
+  if (conv("conv2b_pool", h->conv[2], a2a, a2, H2, W2, true, false)) return -1;
+  if (conv("conv3a", h->conv[3], a2, a3a, H4, W4, false, false)) return -1;
+  if (conv("conv3b_pool", h->conv[4], a3a, a3, H4, W4, true, false)) return -1;
+  if (conv("conv4a", h->conv[5], a3, a4a, Hc, Wc, false, false)) return -1;
+  if (conv("conv4b", h->conv[6], a4a, x4, Hc, Wc, false, false)) return -1;
+  if (conv("convPaDa", h->conv[7], x4, hd, Hc, Wc, false, false)) return -1;
+  const int rows = B * Hc * Wc;
+  if (gemm(h, s, "convPb", h->pb, hd, 512, 256, nullptr, 0, 0, nullptr, 0, semi, 65, rows, false)) return -1;
+  if (gemm(h, s, "convDb", h->db, hd + 256, 512, 256, nullptr, 0, 0, nullptr, 0, dense, d, rows, false)) return -1;
+  RUN("softmax_shuffle", launch_softmax_shuffle(semi, 65, smap, B, Hc, Wc, s));
+  RUN("nms", launch_nms(smap, nms, B, H8, W8, c.nms_radius, s));
+
+  const int Ksel = c.max_keypoints >= 0 ? (c.max_keypoints > 0 ? c.max_keypoints : 1) : H8 * W8;
+  if (c.max_keypoints > 16384) return fail(h, "max_keypoints > 16384 is not supported (got %d)", c.max_keypoints);
+  KeypointArgs k{};
+  k.nms = nms; k.B = B; k.H = H8; k.W = W8; k.threshold = c.keypoint_threshold; k.border = c.remove_borders;
+  k.max_keypoints = c.max_keypoints; k.Ksel = Ksel;
+  WS(row_count, int, "kp.row_count", (size_t)B * H8 * 4);
+  WS(row_off, int, "kp.row_off", (size_t)B * H8 * 4);
+  WS(cand_count, int, "kp.cand_count", (size_t)B * 4);
+  WS(cand_idx, int, "kp.cand_idx", (size_t)B * H8 * W8 * 4);
+  WS(cand_score, float, "kp.cand_score", (size_t)B * H8 * W8 * 4);
+  WS(sel_count, int, "kp.sel_count", (size_t)B * 4);
+  WS(sel_idx, int, "kp.sel_idx", (size_t)B * Ksel * 4);
+  WS(sel_score, float, "kp.sel_score", (size_t)B * Ksel * 4);
+  k.row_count = row_count; k.row_off = row_off; k.cand_count = cand_count; k.cand_idx = cand_idx; k.cand_score = cand_score;
+  k.sel_count = sel_count; k.sel_idx = sel_idx; k.sel_score = sel_score;
+  RUN("keypoints", launch_keypoints(k, s));
+  if (counts_out) HIP_OK(h, hipMemcpyAsync(counts_out, sel_count, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+
+  h->det_B = B; h->det_H = H; h->det_W = W; h->det_Hc = Hc; h->det_Wc = Wc; h->det_Ksel = Ksel;
+  tap(h, "a1", a1, {B, H2, W2, 64});
+  tap(h, "a2", a2, {B, H4, W4, 64});
+  tap(h, "a3", a3, {B, Hc, Wc, 128});
+  tap(h, "x4", x4, {B, Hc, Wc, 128});
+  tap(h, "semi", semi, {B, Hc, Wc, 65});
+  tap(h, "desc_raw", dense, {B, Hc, Wc, d});
+  tap(h, "score_map", smap, {B, H8, W8});
+  tap(h, "nms", nms, {B, H8, W8});
+  return 0;
+}
+
+int sp_describe(imx_handle_t h, int b0, int B, int Kcap, float* kpts, float* scores, float* desc, hipStream_t s) {
+  if (h->det_B <= 0 || b0 + B > h->det_B) return fail(h, "describe: no matching imx_superpoint_detect (B=%d, detect B=%d)", B, h->det_B);
+  DescribeArgs a{};
+  a.dense = static_cast<const float*>(h->bufs["sp.dense"].p);
+  a.ld = h->cfg.descriptor_dim; a.d = h->cfg.descriptor_dim; a.Hc = h->det_Hc; a.Wc = h->det_Wc; a.W8 = h->det_Wc * 8;
+  a.sel_count = static_cast<const int*>(h->bufs["kp.sel_count"].p);
+  a.sel_idx = static_cast<const int*>(h->bufs["kp.sel_idx"].p);
+  a.sel_score = static_cast<const float*>(h->bufs["kp.sel_score"].p);
+  a.Ksel = h->det_Ksel; a.b0 = b0; a.B = B; a.Kcap = Kcap; a.kpts = kpts; a.scores = scores; a.desc = desc;
+  a.align_corners = h->cfg.align_corners; a.dense_eps = h->cfg.sp_variant == IMX_SP_VARIANT_OFFICIAL ? 1 : 0;
+  RUN("describe", launch_describe(a, s));
+  return 0;
+}
+
+// ----------------------------------------------------------------------------- SuperGlue
+struct SgSide {
+  const float* kpts; const float* scores; const float* desc;
+  int64_t sb, sc, sn;
+  const int32_t* n; int N, H, W;
+};
+
+int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* m1, float* ms0, float* ms1, hipStream_t s) {
+  if (!h->finalized[IMX_NET_SUPERGLUE]) return fail(h, "SuperGlue weights not finalized");
+  const imx_config_t& c = h->cfg;
+  const int d = c.descriptor_dim;
+  const int N0 = sd[0].N, N1 = sd[1].N;
+  if (B <= 0 || N0 < 0 || N1 < 0) return fail(h, "bad SuperGlue shapes B=%d N0=%d N1=%d", B, N0, N1);
+  const size_t f = sizeof(float);
+  if (N0 == 0 || N1 == 0) {   // superglue_test.py:235-242 (dtype handling is the Python side's)
+    if (N0) { HIP_OK(h, hipMemsetAsync(m0, 0xFF, (size_t)B * N0 * 8, s)); HIP_OK(h, hipMemsetAsync(ms0, 0, (size_t)B * N0 * f, s)); }
+    if (N1) { HIP_OK(h, hipMemsetAsync(m1, 0xFF, (size_t)B * N1 * 8, s)); HIP_OK(h, hipMemsetAsync(ms1, 0, (size_t)B * N1 * f, s)); }
+    return 0;
+  }
+  const int N0p = pad32(N0), N1p = pad32(N1);
+  const int R = B * (N0p + N1p);
+  const size_t off1 = (size_t)B * N0p;   // first row of side 1
+  int maxw = d;
+  for (int i = 0; i < c.kenc_n; ++i) maxw = std::max(maxw, c.kenc_channels[i]);
+  WS(x, float, "sg.x", (size_t)R * d * f);
+  WS(ta, float, "sg.ta", (size_t)R * maxw * f);
+  WS(tb, float, "sg.tb", (size_t)R * maxw * f);
+  WS(qkv, float, "sg.qkv", (size_t)R * 3 * d * f);
+  WS(att, float, "sg.att", (size_t)R * d * f);
+  WS(msg, float, "sg.msg", (size_t)R * d * f);
+  WS(hid, float, "sg.hid", (size_t)R * 2 * d * f);
+  WS(mdesc, float, "sg.mdesc", (size_t)R * d * f);
+  WS(S, float, "sg.S", (size_t)B * N0p * N1p * f);
+  WS(u, float, "sg.u", (size_t)B * (N0p + 1) * f);
+  WS(v, float, "sg.v", (size_t)B * (N1p + 1) * f);
+  WS(max0, float, "sg.max0", (size_t)B * N0p * f);
+  WS(max1, float, "sg.max1", (size_t)B * N1p * f);
+  WS(idx0, int, "sg.idx0", (size_t)B * N0p * 4);
+  WS(idx1, int, "sg.idx1", (size_t)B * N1p * 4);
+
+  // descriptors -> rows; keypoint encoder (superglue_test.py:245-250)
+  for (int sidx = 0; sidx < 2; ++sidx) {
+    const SgSide& q = sd[sidx];
+    const int Np = sidx ? N1p : N0p;
+    float* xr = x + (sidx ? off1 : 0) * d;
+    RUN("gather_desc", launch_gather_desc(q.desc, q.sb, q.sc, q.sn, B, q.N, Np, d, xr, s));
+    Kenc0Args k{};
+    k.kpts = q.kpts; k.scores = q.scores; k.B = B; k.N = q.N; k.Np = Np;
+    k.cx = (float)q.W / 2.0f; k.cy = (float)q.H / 2.0f;
+    k.scaling = (float)std::max(q.W, q.H) * 0.7f;
+    k.w = h->kenc0_w; k.bias = h->kenc0_b; k.C1 = h->kenc_c1;
+    k.out = ta + (sidx ? off1 : 0) * h->kenc_c1;
+    RUN("kenc0", launch_kenc0(k, s));
+  }
+  {
+    float* cur = ta;
+    float* nxt = tb;
+    int curw = h->kenc_c1;
+    for (size_t i = 0; i < h->kenc.size(); ++i) {
+      const GemmW& g = h->kenc[i];
+      const bool last = i + 1 == h->kenc.size();
+      if (last) {
+        if (gemm(h, s, "kenc", g, cur, curw, g.K, nullptr, 0, 0, x, d, x, d, R, false)) return -1;   // desc + kenc(...)
+      } else {
+        if (gemm(h, s, "kenc", g, cur, curw, g.K, nullptr, 0, 0, nullptr, 0, nxt, g.N, R, true)) return -1;
+        std::swap(cur, nxt);
+        curw = g.N;
+      }
+    }
+  }
+  if (h->debug) {
+    WS(tk, float, "tap.kenc", (size_t)R * d * f);
+    HIP_OK(h, hipMemcpyAsync(tk, x, (size_t)R * d * f, hipMemcpyDeviceToDevice, s));
+    tap(h, "kenc", tk, {R, d});
+  }
+  // attentional GNN (superglue_test.py:122-138)
+  for (size_t l = 0; l < h->layers.size(); ++l) {
+    const GnnLayer& L = h->layers[l];
+    if (gemm(h, s, "qkv_proj", L.qkv, x, d, d, nullptr, 0, 0, nullptr, 0, qkv, 3 * d, R, false)) return -1;
+    AttnArgs a{};
+    a.qkv = qkv; a.out = att; a.B = B; a.N0p = N0p; a.N1p = N1p; a.d = d; a.heads = HEADS;
+    a.n0 = sd[0].n; a.n1 = sd[1].n; a.N0 = N0; a.N1 = N1; a.cross = c.gnn_layer_is_cross[l];
+    RUN("attention", launch_attention(a, s));
+    if (gemm(h, s, "attn_merge", L.merge, att, d, d, nullptr, 0, 0, nullptr, 0, msg, d, R, false)) return -1;
+    if (gemm(h, s, "gnn_mlp1", L.mlp1, x, d, d, msg, d, d, nullptr, 0, hid, 2 * d, R, true)) return -1;
+    if (gemm(h, s, "gnn_mlp2", L.mlp2, hid, 2 * d, 2 * d, nullptr, 0, 0, x, d, x, d, R, false)) return -1;
+    if (h->debug) {
+      std::string nm = "gnn" + std::to_string(l);
+      WS(tg, float, "tap." + nm, (size_t)R * d * f);
+      HIP_OK(h, hipMemcpyAsync(tg, x, (size_t)R * d * f, hipMemcpyDeviceToDevice, s));
+      tap(h, nm.c_str(), tg, {R, d});
+    }
+  }
+  if (gemm(h, s, "final_proj", h->final_proj, x, d, d, nullptr, 0, 0, nullptr, 0, mdesc, d, R, false)) return -1;
+  ScoreArgs sc{mdesc, mdesc + off1 * d, S, B, N0p, N1p, d, (float)(1.0 / std::sqrt((double)d))};
+  RUN("score_gemm", launch_score_gemm(sc, s));
+  SinkhornArgs sk{S, u, v, B, N0p, N1p, sd[0].n, sd[1].n, N0, N1, h->bin_score, c.sinkhorn_iterations};
+  RUN("sinkhorn", launch_sinkhorn(sk, s));
+  MatchArgs ma{S, u, v, B, N0p, N1p, sd[0].n, sd[1].n, N0, N1, h->bin_score, c.match_threshold,
+               max0, idx0, max1, idx1, m0, m1, ms0, ms1};
+  RUN("matches", launch_matches(ma, s));
+  tap(h, "x", x, {R, d});
+  tap(h, "mdesc", mdesc, {R, d});
+  tap(h, "scores_in", S, {B, N0p, N1p});
+  tap(h, "u", u, {B, N0p + 1});
+  tap(h, "v", v, {B, N1p + 1});
+  tap(h, "max0", max0, {B, N0p});
+  tap(h, "max1", max1, {B, N1p});
+  return 0;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+const char* imx_version(void) { return "imx 0.1 gfx950 hip-7.2 fp32-mfma"; }
+
+int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
+  if (!cfg || !out) return fail(nullptr, "imx_create: null argument");
+  if (cfg->num_gnn_layers < 0 || cfg->num_gnn_layers > IMX_MAX_GNN_LAYERS) return fail(nullptr, "imx_create: bad num_gnn_layers %d", cfg->num_gnn_layers);
+  if (cfg->kenc_n < 1 || cfg->kenc_n > IMX_MAX_KENC) return fail(nullptr, "imx_create: bad keypoint_encoder length %d", cfg->kenc_n);
+  if (cfg->descriptor_dim <= 0 || cfg->descriptor_dim % 32) return fail(nullptr, "imx_create: descriptor_dim must be a positive multiple of 32 (got %d)", cfg->descriptor_dim);
+  if (cfg->nms_radius < 0 || cfg->nms_radius > 8) return fail(nullptr, "imx_create: nms_radius must be in [0,8] (got %d)", cfg->nms_radius);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "imx_create: no HIP device available (this library has no CPU path)");
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, "imx_create: device %d out of range (%d devices)", device_id, ndev);
+  if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, "imx_create: hipSetDevice(%d) failed", device_id);
+  imx_handle_s* h = new imx_handle_s();
+  h->device = device_id;
+  h->cfg = *cfg;
+  build_expected(h);
+  *out = h;
+  return 0;
+}
+
+int imx_destroy(imx_handle_t h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : h->weight_allocs) (void)hipFree(p);
+  for (auto& kv : h->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
+  for (auto& e : h->events) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+  delete h;
+  return 0;
+}
+
+const char* imx_last_error(imx_handle_t h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int imx_load_weight(imx_handle_t h, int net, const char* name, const float* host, int ndim, const int64_t* shape) {
+  if (!h) return -1;
+  if (net != IMX_NET_SUPERPOINT && net != IMX_NET_SUPERGLUE) return fail(h, "imx_load_weight: bad net id %d", net);
+  if (!name || !host) return fail(h, "imx_load_weight: null argument");
+  std::string key = name;
+  if (ends_with(key, "num_batches_tracked")) return 0;
+  auto it = h->expected[net].find(key);
+  if (it == h->expected[net].end()) return fail(h, "imx_load_weight: unexpected key '%s' for %s", name, net ? "SuperGlue" : "SuperPoint");
+  int64_t want = 1, got = 1;
+  for (int64_t v : it->second) want *= v;
+  for (int i = 0; i < ndim; ++i) got *= shape[i];
+  bool same = (size_t)ndim == it->second.size();
+  for (int i = 0; same && i < ndim; ++i) same = shape[i] == it->second[i];
+  if (!same && !(want == got && want == 1)) {
+    std::string ws_, gs_;
+    for (int64_t v : it->second) ws_ += std::to_string(v) + ",";
+    for (int i = 0; i < ndim; ++i) gs_ += std::to_string(shape[i]) + ",";
+    return fail(h, "imx_load_weight: size mismatch for %s: expected (%s) got (%s)", name, ws_.c_str(), gs_.c_str());
+  }
+  HostTensor t;
+  t.data.assign(host, host + got);
+  t.shape.assign(shape, shape + ndim);
+  h->raw[net][key] = std::move(t);
+  h->finalized[net] = false;
+  return 0;
+}
+
+int imx_finalize_weights(imx_handle_t h, int net) {
+  if (!h) return -1;
+  if (net != IMX_NET_SUPERPOINT && net != IMX_NET_SUPERGLUE) return fail(h, "imx_finalize_weights: bad net id %d", net);
+  HIP_OK(h, hipSetDevice(h->device));
+  for (auto& kv : h->expected[net])
+    if (!h->raw[net].count(kv.first)) return fail(h, "Missing key in state_dict: \"%s\"", kv.first.c_str());
+  int rc = net == IMX_NET_SUPERPOINT ? finalize_superpoint(h) : finalize_superglue(h);
+  if (rc) return rc;
+  h->finalized[net] = true;
+  return 0;
+}
+
+int imx_superpoint_detect(imx_handle_t h, const float* img_dev, int B, int H, int W, int32_t* counts_dev, void* stream) {
+  if (!h) return -1;
+  HIP_OK(h, hipSetDevice(h->device));
+  return sp_detect(h, img_dev, nullptr, B, B, H, W, counts_dev, as_stream(stream));
+}
+
+int imx_superpoint_describe(imx_handle_t h, int B, int Kcap, float* kpts_dev, float* scores_dev, float* desc_dev, void* stream) {
+  if (!h) return -1;
+  HIP_OK(h, hipSetDevice(h->device));
+  if (Kcap <= 0) return 0;
+  return sp_describe(h, 0, B, Kcap, kpts_dev, scores_dev, desc_dev, as_stream(stream));
+}
+
+int imx_superglue_forward(imx_handle_t h, int B, const float* kpts0_dev, const float* scores0_dev, const float* desc0_dev,
+                          int64_t desc0_stride_b, int64_t desc0_stride_c, int64_t desc0_stride_n, const int32_t* n0_dev,
+                          int N0, int H0, int W0, const float* kpts1_dev, const float* scores1_dev, const float* desc1_dev,
+                          int64_t desc1_stride_b, int64_t desc1_stride_c, int64_t desc1_stride_n, const int32_t* n1_dev,
+                          int N1, int H1, int W1, int64_t* matches0_dev, int64_t* matches1_dev, float* mscores0_dev,
+                          float* mscores1_dev, void* stream) {
+  if (!h) return -1;
+  HIP_OK(h, hipSetDevice(h->device));
+  SgSide sd[2] = {{kpts0_dev, scores0_dev, desc0_dev, desc0_stride_b, desc0_stride_c, desc0_stride_n, n0_dev, N0, H0, W0},
+                  {kpts1_dev, scores1_dev, desc1_dev, desc1_stride_b, desc1_stride_c, desc1_stride_n, n1_dev, N1, H1, W1}};
+  return sg_forward(h, B, sd, matches0_dev, matches1_dev, mscores0_dev, mscores1_dev, as_stream(stream));
+}
+
+int imx_match_pairs(imx_handle_t h, const float* img0_dev, const float* img1_dev, int B, int H, int W, float* kpts0_dev,
+                    float* kpts1_dev, float* scores0_dev, float* scores1_dev, int32_t* counts0_dev, int32_t* counts1_dev,
+                    float* desc0_dev, float* desc1_dev, int64_t* matches0_dev, int64_t* matches1_dev, float* mscores0_dev,
+                    float* mscores1_dev, void* stream) {
+  if (!h) return -1;
+  HIP_OK(h, hipSetDevice(h->device));
+  hipStream_t s = as_stream(stream);
+  const int K = h->cfg.max_keypoints, d = h->cfg.descriptor_dim;
+  if (K <= 0) return fail(h, "imx_match_pairs needs max_keypoints > 0 (fixed-size outputs); got %d", K);
+  WS(counts, int32_t, "mp.counts", (size_t)2 * B * 4);
+  if (sp_detect(h, img0_dev, img1_dev, B, 2 * B, H, W, counts, s)) return -1;
+  if (!desc0_dev) { WS(t0, float, "mp.desc0", (size_t)B * K * d * 4); desc0_dev = t0; }
+  if (!desc1_dev) { WS(t1, float, "mp.desc1", (size_t)B * K * d * 4); desc1_dev = t1; }
+  if (sp_describe(h, 0, B, K, kpts0_dev, scores0_dev, desc0_dev, s)) return -1;
+  if (sp_describe(h, B, B, K, kpts1_dev, scores1_dev, desc1_dev, s)) return -1;
+  if (counts0_dev) HIP_OK(h, hipMemcpyAsync(counts0_dev, counts, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  if (counts1_dev) HIP_OK(h, hipMemcpyAsync(counts1_dev, counts + B, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  const int H8 = h->det_Hc * 8, W8 = h->det_Wc * 8;
+  (void)H8; (void)W8;
+  SgSide sd[2] = {{kpts0_dev, scores0_dev, desc0_dev, (int64_t)K * d, 1, d, counts, K, H, W},
+                  {kpts1_dev, scores1_dev, desc1_dev, (int64_t)K * d, 1, d, counts + B, K, H, W}};
+  return sg_forward(h, B, sd, matches0_dev, matches1_dev, mscores0_dev, mscores1_dev, s);
+}
+
+int imx_set_debug(imx_handle_t h, int enable) {
+  if (!h) return -1;
+  h->debug = enable != 0;
+  return 0;
+}
+
+int imx_debug_fetch(imx_handle_t h, const char* name, float* host_out, int64_t capacity, int64_t* shape_out, int* ndim_out) {
+  if (!h) return -1;
+  auto it = h->taps.find(name ? name : "");
+  if (it == h->taps.end()) return fail(h, "imx_debug_fetch: no tap named '%s'", name ? name : "(null)");
+  int64_t n = 1;
+  for (int64_t v : it->second.shape) n *= v;
+  if (ndim_out) *ndim_out = (int)it->second.shape.size();
+  if (shape_out) for (size_t i = 0; i < it->second.shape.size() && i < 4; ++i) shape_out[i] = it->second.shape[i];
+  if (!host_out) return 0;   // shape query
+  if (capacity < n) return fail(h, "imx_debug_fetch: capacity %lld < %lld elements", (long long)capacity, (long long)n);
+  HIP_OK(h, hipSetDevice(h->device));
+  HIP_OK(h, hipDeviceSynchronize());
+  HIP_OK(h, hipMemcpy(host_out, it->second.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int imx_set_timing(imx_handle_t h, int enable) {
+  if (!h) return -1;
+  h->timing = enable != 0;
+  return 0;
+}
+
+int imx_timing_reset(imx_handle_t h) {
+  if (!h) return -1;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (auto& e : h->events) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+  h->events.clear();
+  h->report.clear();
+  return 0;
+}
+
+int imx_timing_report(imx_handle_t h, int index, const char** name_out, int64_t* launches_out, double* total_ms_out) {
+  if (!h) return -1;
+  if (index < 0) {   // (re)build the report; returns the number of rows
+    HIP_OK(h, hipSetDevice(h->device));
+    HIP_OK(h, hipDeviceSynchronize());
+    std::map<std::string, TimingRow> agg;
+    std::vector<std::string> order;
+    for (auto& e : h->events) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e.e0, e.e1) != hipSuccess) continue;
+      auto it = agg.find(e.name);
+      if (it == agg.end()) { agg[e.name] = TimingRow{e.name, 1, ms}; order.push_back(e.name); }
+      else { it->second.launches++; it->second.ms += ms; }
+    }
+    h->report.clear();
+    for (auto& n : order) h->report.push_back(agg[n]);
+    return (int)h->report.size();
+  }
+  if ((size_t)index >= h->report.size()) return fail(h, "imx_timing_report: index %d out of range", index);
+  if (name_out) *name_out = h->report[index].name.c_str();
+  if (launches_out) *launches_out = h->report[index].launches;
+  if (total_ms_out) *total_ms_out = h->report[index].ms;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+// imx_kernels.h — internal launch interface between the C-ABI host code (imx_api.cpp) and the
+// gfx950 kernels.  Activations are fp32, channels-last: images (B,H,W,C) "NHWC", keypoint
+// features (rows, C).  See DESIGN.md for the data layout in HBM and per-kernel rooflines.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace imx {
+
+// ---------------------------------------------------------------- conv3x3 (MFMA fp32, implicit GEMM)
+struct ConvArgs {
+  const float* in;    // NHWC (B,H,W,Cin); FIRST mode: grayscale images (B,H,W), images >= split come from in2
+  const float* in2;
+  int split;
+  const float* w;     // [9][Cin][Cout]  (BN folded)
+  const float* bias;  // [Cout]
+  const float* w1;    // FIRST mode: conv1a weights [9][64] and bias [64] (BN folded), Cin == 64
+  const float* b1;
+  float* out;         // NHWC (B,Ho,Wo,Cout); Ho,Wo = H/2,W/2 (floor) when pool
+  int B, H, W, Cin, Cout;
+  int relu, pool, first;
+};
+// Cin % 16 == 0, Cout % 64 == 0.
+hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- GEMM (MFMA fp32): 1x1 conv / linear
+// out[r][n] = act( sum_k A[r][k] * W[k][n] + bias[n] ) (+ res[r][n]);  A = [a0 | a1] column concat.
+struct GemmArgs {
+  const float* a0; int lda0; int K0;   // rows x K0
+  const float* a1; int lda1; int K1;   // rows x K1 (may be null / 0)
+  const float* w;                      // [K0+K1][Npad] row-major, Npad = ceil(N/64)*64, zero padded
+  const float* bias;                   // [Npad]
+  const float* res; int ldr;           // optional residual (may alias out)
+  float* out; int ldo;
+  int M, N, Npad;
+  int relu;
+};
+// (K0, K1) % 32 == 0.
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// scores[b][i][j] = scale * sum_k m0[b][i][k] * m1[b][j][k]   ("NT" GEMM, per pair)
+struct ScoreArgs {
+  const float* m0; const float* m1;    // rows (b*N0p + i) / (b*N1p + j), leading dim = d
+  float* out;                          // (B, N0p, N1p)
+  int B, N0p, N1p, d;
+  float scale;
+};
+hipError_t launch_score_gemm(const ScoreArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- SuperPoint tail
+// softmax over 65 channels + drop dustbin + 8x8 pixel shuffle.  semi: (B,Hc,Wc,ld) -> scores (B,8Hc,8Wc)
+hipError_t launch_softmax_shuffle(const float* semi, int ld, float* scores, int B, int Hc, int Wc, hipStream_t s);
+// simple_nms (3 rounds, radius r<=8) fused; out = where(max_mask, scores, 0)
+hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int radius, hipStream_t s);
+// threshold + border removal + row-major compaction, then top-k (score desc, index asc on ties).
+struct KeypointArgs {
+  const float* nms;          // (B,H,W)
+  int B, H, W;
+  float threshold; int border; int max_keypoints;   // -1 = keep all
+  int* row_count;            // (B,H) scratch
+  int* row_off;              // (B,H) scratch
+  int* cand_count;           // (B)   number of candidates after threshold+border
+  int* cand_idx;             // (B,H*W) linear index y*W+x, row-major order
+  float* cand_score;         // (B,H*W)
+  int* sel_count;            // (B)   kept keypoints
+  int* sel_idx;              // (B,Ksel)  Ksel = max_keypoints >=0 ? max_keypoints : H*W
+  float* sel_score;          // (B,Ksel)
+  int Ksel;
+};
+hipError_t launch_keypoints(const KeypointArgs& a, hipStream_t s);
+// flip to (x,y), bilinear descriptor sampling from the raw dense descriptor map (B,Hc,Wc,ld),
+// dense channel-L2 normalisation applied on the fly, final L2 normalise (eps 1e-12).
+struct DescribeArgs {
+  const float* dense; int ld; int d; int Hc, Wc; int W8;   // W8 = 8*Wc (score-map width for idx decode)
+  const int* sel_count; const int* sel_idx; const float* sel_score; int Ksel;
+  int b0;                                    // first image (index into dense / sel_*) of this call
+  int B, Kcap;
+  float* kpts; float* scores; float* desc;   // (B,Kcap,2) (B,Kcap) (B,Kcap,d); rows >= count zeroed
+  int align_corners; int dense_eps;          // dense_eps: 1 = F.normalize(eps 1e-12), 0 = plain division
+};
+hipError_t launch_describe(const DescribeArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- SuperGlue pieces
+// normalize_keypoints + first kenc layer (3 -> C1, BN folded, ReLU); rows laid out side-major.
+struct Kenc0Args {
+  const float* kpts; const float* scores;  // (B,N,2), (B,N)
+  int B, N, Np;                            // Np = padded rows per image in the internal layout
+  float cx, cy, scaling;                   // center and scaling (superglue_test.py:63-70)
+  const float* w; const float* bias;       // [3][C1], [C1]
+  int C1;
+  float* out;                              // rows (b*Np + i), ld = C1; rows >= N zeroed
+};
+hipError_t launch_kenc0(const Kenc0Args& a, hipStream_t s);
+// copy descriptors (arbitrary strides) into rows (b*Np+i), ld=d; rows >= N zero.
+hipError_t launch_gather_desc(const float* src, int64_t sb, int64_t sc, int64_t sn, int B, int N, int Np, int d,
+                              float* out, hipStream_t s);
+
+// flash-style multi-head attention, fp32 MFMA.  qkv rows: [side0: B*N0p rows][side1: B*N1p rows],
+// ld = 3*d, columns [q | k | v], each head-major (head*32 + dim).  out same rows, ld = d.
+struct AttnArgs {
+  const float* qkv; float* out;
+  int B, N0p, N1p, d, heads;     // head dim fixed at 32
+  const int* n0; const int* n1;  // valid counts per pair (device), may be null => N0/N1
+  int N0, N1;
+  int cross;
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+// log-domain Sinkhorn with implicit dustbins (superglue_test.py:141-170).
+struct SinkhornArgs {
+  const float* S;            // (B,N0p,N1p) scores
+  float* u; float* v;        // (B,N0p+1) / (B,N1p+1); entries [n0] / [n1] hold the dustbin terms
+  int B, N0p, N1p;
+  const int* n0; const int* n1; int N0, N1;
+  float alpha;               // bin_score
+  int iters;
+};
+hipError_t launch_sinkhorn(const SinkhornArgs& a, hipStream_t s);
+
+struct MatchArgs {
+  const float* S; const float* u; const float* v;
+  int B, N0p, N1p; const int* n0; const int* n1; int N0, N1;
+  float alpha; float threshold;
+  float* max0; int* idx0; float* max1; int* idx1;   // scratch (B,N0p) / (B,N1p)
+  int64_t* matches0; int64_t* matches1; float* ms0; float* ms1;  // (B,N0) / (B,N1)
+};
+hipError_t launch_matches(const MatchArgs& a, hipStream_t s);
+
+}  // namespace imx

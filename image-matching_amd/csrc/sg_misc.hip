@@ -1,0 +1,275 @@
+// sg_misc.hip — SuperGlue stages that are bandwidth/latency bound (no matrix work):
+//   normalize_keypoints + first keypoint-encoder layer   superglue_test.py:63-82
+//   descriptor gather into the row layout
+//   log-domain Sinkhorn with implicit dustbins           superglue_test.py:141-170
+//   mutual-nearest-neighbour match extraction            superglue_test.py:268-285
+#include "imx_kernels.h"
+#include <math.h>
+
+namespace imx {
+namespace {
+
+struct LSE { float m, s; };   // running max and sum of exp(x - m)
+
+__device__ __forceinline__ void lse_add(LSE& a, float x) {
+  const float nm = fmaxf(a.m, x);
+  // a.m == -inf only while a.s == 0; exp(-inf - nm) = 0 for finite nm.
+  a.s = a.s * expf(a.m - nm) + expf(x - nm);
+  a.m = nm;
+}
+__device__ __forceinline__ LSE lse_merge(const LSE& a, const LSE& b) {
+  const float nm = fmaxf(a.m, b.m);
+  const float ea = (a.m == -INFINITY) ? 0.f : expf(a.m - nm);
+  const float eb = (b.m == -INFINITY) ? 0.f : expf(b.m - nm);
+  return LSE{nm, a.s * ea + b.s * eb};
+}
+__device__ __forceinline__ LSE wave_lse(LSE a) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    LSE b{__shfl_xor(a.m, o), __shfl_xor(a.s, o)};
+    a = lse_merge(a, b);
+  }
+  return a;
+}
+
+// ------------------------------------------------------------------ kenc layer 0
+__global__ __launch_bounds__(256) void kenc0_kernel(Kenc0Args a, float scaling) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)a.B * a.Np * a.C1;
+  if (e >= total) return;
+  const int c = (int)(e % a.C1);
+  const long row = e / a.C1;
+  const int i = (int)(row % a.Np), b = (int)(row / a.Np);
+  float v = 0.f;
+  if (i < a.N) {
+    const float* kp = a.kpts + ((size_t)b * a.N + i) * 2;
+    const float xn = (kp[0] - a.cx) / scaling;          // normalize_keypoints (:63-70)
+    const float yn = (kp[1] - a.cy) / scaling;
+    const float sc = a.scores[(size_t)b * a.N + i];
+    v = a.bias[c];
+    v = fmaf(a.w[c], xn, v);
+    v = fmaf(a.w[a.C1 + c], yn, v);
+    v = fmaf(a.w[2 * a.C1 + c], sc, v);
+    v = fmaxf(v, 0.f);
+  }
+  a.out[e] = v;
+}
+
+__global__ __launch_bounds__(256) void gather_desc_kernel(const float* __restrict__ src, long sb, long sc, long sn,
+                                                          int B, int N, int Np, int d, float* __restrict__ out) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * Np * d;
+  if (e >= total) return;
+  const int c = (int)(e % d);
+  const long row = e / d;
+  const int i = (int)(row % Np), b = (int)(row / Np);
+  out[e] = i < N ? src[b * sb + c * sc + i * sn] : 0.f;
+}
+
+// ------------------------------------------------------------------ Sinkhorn
+// Implicit couplings (:157-160): Z[i][j] = S[i][j] (i<m, j<n), alpha on the dustbin row/column.
+// u has m+1 entries (u[m] = dustbin row), v has n+1.
+__device__ __forceinline__ void counts(const SinkhornArgs& a, int b, int& m, int& n) {
+  m = a.n0 ? a.n0[b] : a.N0;
+  n = a.n1 ? a.n1[b] : a.N1;
+}
+
+// one wave per row i in [0, m]:  u[i] = log_mu[i] - logsumexp_j(Z[i][j] + v[j])      (:145)
+__global__ __launch_bounds__(256) void sinkhorn_rows(SinkhornArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  int m, n;
+  counts(a, b, m, n);
+  if (m == 0 || n == 0 || i > m) return;
+  const float* v = a.v + (size_t)b * (a.N1p + 1);
+  LSE acc{-INFINITY, 0.f};
+  if (i < m) {
+    const float* Srow = a.S + ((size_t)b * a.N0p + i) * a.N1p;
+    for (int j = lane; j < n; j += 64) lse_add(acc, Srow[j] + v[j]);
+  } else {
+    for (int j = lane; j < n; j += 64) lse_add(acc, a.alpha + v[j]);
+  }
+  if (lane == 0) lse_add(acc, a.alpha + v[n]);
+  acc = wave_lse(acc);
+  if (lane == 0) {
+    const float norm = -logf((float)(m + n));                                          // (:162)
+    const float log_mu = i < m ? norm : logf((float)n) + norm;                         // (:163)
+    a.u[(size_t)b * (a.N0p + 1) + i] = log_mu - (acc.m + logf(acc.s));
+  }
+}
+
+// block = 64 columns x 16 row groups:  v[j] = log_nu[j] - logsumexp_i(Z[i][j] + u[i])  (:146)
+__global__ __launch_bounds__(1024) void sinkhorn_cols(SinkhornArgs a) {
+  __shared__ float pm[16][64], ps[16][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  const int b = blockIdx.y;
+  int m, n;
+  counts(a, b, m, n);
+  if (m == 0 || n == 0) return;
+  const float* u = a.u + (size_t)b * (a.N0p + 1);
+  LSE acc{-INFINITY, 0.f};
+  if (j < n) {
+    const float* Scol = a.S + (size_t)b * a.N0p * a.N1p + j;
+    for (int i = g; i < m; i += 16) lse_add(acc, Scol[(size_t)i * a.N1p] + u[i]);
+  } else if (j == n) {
+    for (int i = g; i < m; i += 16) lse_add(acc, a.alpha + u[i]);
+  }
+  if (g == 0 && j <= n) lse_add(acc, a.alpha + u[m]);
+  pm[g][c] = acc.m;
+  ps[g][c] = acc.s;
+  __syncthreads();
+  if (g == 0 && j <= n) {
+    LSE t{pm[0][c], ps[0][c]};
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t = lse_merge(t, LSE{pm[k][c], ps[k][c]});
+    const float norm = -logf((float)(m + n));
+    const float log_nu = j < n ? norm : logf((float)m) + norm;                         // (:164)
+    a.v[(size_t)b * (a.N1p + 1) + j] = log_nu - (t.m + logf(t.s));
+  }
+}
+
+// ------------------------------------------------------------------ matches
+// Z'[i][j] = ((S[i][j] + u[i]) + v[j]) - norm   (:147, :169) — same operation order as the reference.
+__device__ __forceinline__ void mcounts(const MatchArgs& a, int b, int& m, int& n) {
+  m = a.n0 ? a.n0[b] : a.N0;
+  n = a.n1 ? a.n1[b] : a.N1;
+}
+
+__global__ __launch_bounds__(256) void match_rowmax(MatchArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  int m, n;
+  mcounts(a, b, m, n);
+  if (m == 0 || n == 0 || i >= m) return;
+  const float norm = -logf((float)(m + n));
+  const float ui = a.u[(size_t)b * (a.N0p + 1) + i];
+  const float* v = a.v + (size_t)b * (a.N1p + 1);
+  const float* Srow = a.S + ((size_t)b * a.N0p + i) * a.N1p;
+  float best = -INFINITY;
+  int bj = 0x7fffffff;
+  for (int j = lane; j < n; j += 64) {
+    const float z = ((Srow[j] + ui) + v[j]) - norm;
+    if (z > best) { best = z; bj = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o);
+    const int oj = __shfl_xor(bj, o);
+    if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+  }
+  if (lane == 0) { a.max0[(size_t)b * a.N0p + i] = best; a.idx0[(size_t)b * a.N0p + i] = bj; }
+}
+
+__global__ __launch_bounds__(1024) void match_colmax(MatchArgs a) {
+  __shared__ float pv[16][64];
+  __shared__ int pi[16][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  const int b = blockIdx.y;
+  int m, n;
+  mcounts(a, b, m, n);
+  if (m == 0 || n == 0) return;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  if (j < n) {
+    const float norm = -logf((float)(m + n));
+    const float vj = a.v[(size_t)b * (a.N1p + 1) + j];
+    const float* u = a.u + (size_t)b * (a.N0p + 1);
+    const float* Scol = a.S + (size_t)b * a.N0p * a.N1p + j;
+    for (int i = g; i < m; i += 16) {
+      const float z = ((Scol[(size_t)i * a.N1p] + u[i]) + vj) - norm;
+      if (z > best) { best = z; bi = i; }
+    }
+  }
+  pv[g][c] = best;
+  pi[g][c] = bi;
+  __syncthreads();
+  if (g == 0 && j < n) {
+    for (int k = 1; k < 16; ++k) {
+      const float ob = pv[k][c];
+      const int oi = pi[k][c];
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    a.max1[(size_t)b * a.N1p + j] = best;
+    a.idx1[(size_t)b * a.N1p + j] = bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void match_finalize(MatchArgs a) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  int m, n;
+  mcounts(a, b, m, n);
+  const bool empty = (m == 0 || n == 0);                                               // (:235-242)
+  const int* idx0 = a.idx0 + (size_t)b * a.N0p;
+  const int* idx1 = a.idx1 + (size_t)b * a.N1p;
+  const float* max0 = a.max0 + (size_t)b * a.N0p;
+  if (t < a.N0) {
+    long mi = -1;
+    float ms = 0.f;
+    if (!empty && t < m) {
+      const int j = idx0[t];
+      const bool mutual = idx1[j] == t;                                                // (:270)
+      ms = mutual ? expf(max0[t]) : 0.f;                                               // (:273)
+      if (mutual && ms > a.threshold) mi = j;                                          // (:275,277)
+    }
+    a.matches0[(size_t)b * a.N0 + t] = mi;
+    a.ms0[(size_t)b * a.N0 + t] = ms;
+  }
+  if (t < a.N1) {
+    long mi = -1;
+    float ms = 0.f;
+    if (!empty && t < n) {
+      const int i = idx1[t];
+      const bool mutual = idx0[i] == t;                                                // (:271)
+      // mutual1 implies mutual0 at i, so mscores0[i] = exp(max0[i])                   (:274)
+      ms = mutual ? expf(max0[i]) : 0.f;
+      if (mutual && ms > a.threshold) mi = i;                                          // (:276,278)
+    }
+    a.matches1[(size_t)b * a.N1 + t] = mi;
+    a.ms1[(size_t)b * a.N1 + t] = ms;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_kenc0(const Kenc0Args& a, hipStream_t s) {
+  long total = (long)a.B * a.Np * a.C1;
+  hipLaunchKernelGGL(kenc0_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, a.scaling);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_desc(const float* src, int64_t sb, int64_t sc, int64_t sn, int B, int N, int Np, int d,
+                              float* out, hipStream_t s) {
+  long total = (long)B * Np * d;
+  hipLaunchKernelGGL(gather_desc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, (long)sb, (long)sc,
+                     (long)sn, B, N, Np, d, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_sinkhorn(const SinkhornArgs& a, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(a.v, 0, (size_t)a.B * (a.N1p + 1) * sizeof(float), s);   // v = 0 (:143)
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(a.u, 0, (size_t)a.B * (a.N0p + 1) * sizeof(float), s);
+  if (e != hipSuccess) return e;
+  dim3 gr((unsigned)((a.N0p + 1 + 3) / 4), (unsigned)a.B);
+  dim3 gc((unsigned)((a.N1p + 1 + 63) / 64), (unsigned)a.B);
+  for (int it = 0; it < a.iters; ++it) {
+    hipLaunchKernelGGL(sinkhorn_rows, gr, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(sinkhorn_cols, gc, dim3(1024), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_matches(const MatchArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(match_rowmax, dim3((unsigned)((a.N0p + 3) / 4), (unsigned)a.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(match_colmax, dim3((unsigned)((a.N1p + 63) / 64), (unsigned)a.B), dim3(1024), 0, s, a);
+  const int nmax = a.N0 > a.N1 ? a.N0 : a.N1;
+  hipLaunchKernelGGL(match_finalize, dim3((unsigned)((nmax + 255) / 256), (unsigned)a.B), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace imx

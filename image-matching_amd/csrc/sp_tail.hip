@@ -1,0 +1,454 @@
+// sp_tail.hip — SuperPoint post-network stages (HBM/LDS-bound, no matrix work):
+//   softmax over 65 channels + pixel shuffle      superpoint_test.py:128-131
+//   simple_nms (all 5 max-pools fused in LDS)     superpoint_test.py:7-22
+//   threshold / remove_borders / top-k            superpoint_test.py:135-149, :25-37
+//   flip + sample_descriptors                     superpoint_test.py:151-155, :40-52
+#include "imx_kernels.h"
+#include <math.h>
+
+namespace imx {
+namespace {
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------ softmax + pixel shuffle
+// One wave per 8x8 cell: lane c holds channel c (c<64), channel 64 (dustbin) is read by all lanes.
+__global__ __launch_bounds__(256) void softmax_shuffle_kernel(const float* __restrict__ semi, int ld,
+                                                              float* __restrict__ scores, int B, int Hc, int Wc) {
+  const int lane = threadIdx.x & 63;
+  const long cell = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long total = (long)B * Hc * Wc;
+  if (cell >= total) return;
+  const int x = (int)(cell % Wc);
+  const int y = (int)((cell / Wc) % Hc);
+  const int b = (int)(cell / ((long)Wc * Hc));
+  const float* s = semi + cell * ld;
+  const float v = s[lane], vd = s[64];
+  const float m = fmaxf(wave_max(v), vd);
+  const float e = expf(v - m), ed = expf(vd - m);
+  const float sum = wave_sum(e) + ed;
+  const int W8 = Wc * 8;
+  scores[((size_t)b * Hc * 8 + (size_t)y * 8 + (lane >> 3)) * W8 + x * 8 + (lane & 7)] = e / sum;
+}
+
+// ------------------------------------------------------------------ simple_nms
+// Output tile T x T, halo 5r (five dependent radius-r max-pools).  Separable row/column maxima
+// are exact, so the result is bit-identical to the reference given the same score map.
+template <int T>
+__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ scores, float* __restrict__ out,
+                                                  int H, int W, int r) {
+  extern __shared__ float sm[];
+  const int halo = 5 * r, side = T + 2 * halo, n = side * side;
+  float* S = sm;               // scores (-inf outside the image)
+  float* X = S + n;            // supp_scores
+  float* tmp = X + n;          // row-pass scratch
+  unsigned char* M = reinterpret_cast<unsigned char*>(tmp + n);   // max_mask
+  unsigned char* Q = M + n;                                       // supp_mask / row-pass of masks
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, gy0 = blockIdx.y * T - halo, gx0 = blockIdx.x * T - halo;
+  const float* img = scores + (size_t)b * H * W;
+  const float NEG = -INFINITY;
+
+  for (int e = tid; e < n; e += 256) {
+    int ry = e / side, rx = e - ry * side, gy = gy0 + ry, gx = gx0 + rx;
+    S[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : NEG;
+  }
+  __syncthreads();
+
+  auto pool_f = [&](const float* src, float* dst) {   // dst = maxpool(src), via tmp
+    for (int e = tid; e < n; e += 256) {
+      int ry = e / side, rx = e - ry * side;
+      int lo = max(rx - r, 0), hi = min(rx + r, side - 1);
+      float m = NEG;
+      for (int k = lo; k <= hi; ++k) m = fmaxf(m, src[ry * side + k]);
+      tmp[e] = m;
+    }
+    __syncthreads();
+    for (int e = tid; e < n; e += 256) {
+      int ry = e / side, rx = e - ry * side;
+      int lo = max(ry - r, 0), hi = min(ry + r, side - 1);
+      float m = NEG;
+      for (int k = lo; k <= hi; ++k) m = fmaxf(m, tmp[k * side + rx]);
+      dst[e] = m;
+    }
+    __syncthreads();
+  };
+  auto inside = [&](int e) {
+    int ry = e / side, rx = e - ry * side, gy = gy0 + ry, gx = gx0 + rx;
+    return gy >= 0 && gy < H && gx >= 0 && gx < W;
+  };
+
+  // max_mask = scores == max_pool(scores)                                  (:16)
+  pool_f(S, X);
+  for (int e = tid; e < n; e += 256) M[e] = (inside(e) && S[e] == X[e]) ? 1 : 0;
+  __syncthreads();
+
+  for (int it = 0; it < 2; ++it) {                                        // (:17-21)
+    // supp_mask = max_pool(max_mask.float()) > 0  (OR over the window)
+    unsigned char* R = reinterpret_cast<unsigned char*>(tmp);
+    for (int e = tid; e < n; e += 256) {
+      int ry = e / side, rx = e - ry * side;
+      int lo = max(rx - r, 0), hi = min(rx + r, side - 1);
+      unsigned char m = 0;
+      for (int k = lo; k <= hi; ++k) m |= M[ry * side + k];
+      R[e] = m;
+    }
+    __syncthreads();
+    for (int e = tid; e < n; e += 256) {
+      int ry = e / side, rx = e - ry * side;
+      int lo = max(ry - r, 0), hi = min(ry + r, side - 1);
+      unsigned char m = 0;
+      for (int k = lo; k <= hi; ++k) m |= R[k * side + rx];
+      Q[e] = m;
+    }
+    __syncthreads();
+    // supp_scores = where(supp_mask, 0, scores); outside the image stays -inf (max_pool padding)
+    for (int e = tid; e < n; e += 256) X[e] = inside(e) ? (Q[e] ? 0.f : S[e]) : NEG;
+    __syncthreads();
+    // new_max_mask = supp_scores == max_pool(supp_scores); max_mask |= new & ~supp
+    // (pool result goes to `tmp2` = reuse of dst X is not possible in place: use S2 region = tmp after pool)
+    // pool_f reads src fully in pass 1 before pass 2 writes dst, so dst may alias neither src nor tmp;
+    // we need X afterwards, so pool into a fourth float view: reuse Q/M? no - allocate P below.
+    float* P = reinterpret_cast<float*>(Q + n + ((4 - ((2 * n) & 3)) & 3));   // 4-B aligned scratch after masks
+    pool_f(X, P);
+    for (int e = tid; e < n; e += 256)
+      if (inside(e) && !Q[e] && X[e] == P[e]) M[e] = 1;
+    __syncthreads();
+  }
+
+  float* o = out + (size_t)b * H * W;
+  for (int e = tid; e < T * T; e += 256) {
+    int ty = e / T, tx = e - ty * T;
+    int gy = blockIdx.y * T + ty, gx = blockIdx.x * T + tx;
+    if (gy < H && gx < W) {
+      int idx = (ty + halo) * side + tx + halo;
+      o[(size_t)gy * W + gx] = M[idx] ? S[idx] : 0.f;                     // (:22)
+    }
+  }
+}
+
+// ------------------------------------------------------------------ keypoint extraction
+__device__ __forceinline__ bool kp_flag(const float* nms, int H, int W, int y, int x, float thr, int border) {
+  return y >= border && y < H - border && x >= border && x < W - border && nms[(size_t)y * W + x] > thr;
+}
+
+// one wave per image row
+__global__ __launch_bounds__(256) void kp_count_rows(KeypointArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)a.B * a.H) return;
+  const int b = (int)(row / a.H), y = (int)(row % a.H);
+  const float* nms = a.nms + (size_t)b * a.H * a.W;
+  int cnt = 0;
+  for (int x0 = 0; x0 < a.W; x0 += 64) {
+    int x = x0 + lane;
+    bool f = x < a.W && kp_flag(nms, a.H, a.W, y, x, a.threshold, a.border);
+    cnt += __popcll(__ballot(f));
+  }
+  if (lane == 0) a.row_count[row] = cnt;
+}
+
+// one block per image: exclusive scan of the row counts
+__global__ __launch_bounds__(256) void kp_scan_rows(KeypointArgs a) {
+  __shared__ int part[256];
+  __shared__ int carry;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int y0 = 0; y0 < a.H; y0 += 256) {
+    int y = y0 + tid;
+    int v = y < a.H ? a.row_count[(size_t)b * a.H + y] : 0;
+    part[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      int t = tid >= o ? part[tid - o] : 0;
+      __syncthreads();
+      part[tid] += t;
+      __syncthreads();
+    }
+    if (y < a.H) a.row_off[(size_t)b * a.H + y] = carry + part[tid] - v;
+    __syncthreads();
+    if (tid == 255) carry += part[255];
+    __syncthreads();
+  }
+  if (tid == 0) a.cand_count[b] = carry;
+}
+
+__global__ __launch_bounds__(256) void kp_scatter_rows(KeypointArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)a.B * a.H) return;
+  const int b = (int)(row / a.H), y = (int)(row % a.H);
+  const float* nms = a.nms + (size_t)b * a.H * a.W;
+  int off = a.row_off[row];
+  int* ci = a.cand_idx + (size_t)b * a.H * a.W;
+  float* cs = a.cand_score + (size_t)b * a.H * a.W;
+  for (int x0 = 0; x0 < a.W; x0 += 64) {
+    int x = x0 + lane;
+    bool f = x < a.W && kp_flag(nms, a.H, a.W, y, x, a.threshold, a.border);
+    unsigned long long m = __ballot(f);
+    if (f) {
+      int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+      ci[pos] = y * a.W + x;
+      cs[pos] = nms[(size_t)y * a.W + x];
+    }
+    off += __popcll(m);
+  }
+}
+
+// block-wide exclusive scan of one int per thread (1024 threads); returns exclusive prefix, total in *tot
+__device__ int block_scan_1024(int v, int* wsum /*[17]*/, int* tot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int w = 0; w < 16; ++w) { int t = wsum[w]; wsum[w] = c; c += t; }
+    wsum[16] = c;
+  }
+  __syncthreads();
+  int res = wsum[wave] + inc - v;
+  *tot = wsum[16];
+  __syncthreads();
+  return res;
+}
+
+// top-k per image: radix select of the k-th largest score, ordered tie handling (lowest index
+// first), then bitonic sort of the k survivors by (score desc, index asc) = torch.topk's sorted
+// output (:33-37) with a deterministic tie rule.  If count <= k (or k < 0) the row-major
+// candidate order is kept unchanged, as the reference does.
+__global__ __launch_bounds__(1024) void kp_topk(KeypointArgs a, int P /* pow2 >= k */) {
+  extern __shared__ unsigned long long keys[];   // P entries
+  __shared__ int hist[256];
+  __shared__ int wsum[17];
+  __shared__ unsigned sh_prefix;
+  __shared__ int sh_kth, sh_npos;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = a.cand_count[b];
+  const int K = a.max_keypoints;
+  const int* ci = a.cand_idx + (size_t)b * a.H * a.W;
+  const float* cs = a.cand_score + (size_t)b * a.H * a.W;
+  int* si = a.sel_idx + (size_t)b * a.Ksel;
+  float* ss = a.sel_score + (size_t)b * a.Ksel;
+
+  if (K == 0) {
+    if (tid == 0) a.sel_count[b] = 0;
+    return;
+  }
+  if (K < 0 || n <= K) {
+    for (int i = tid; i < n; i += 1024) { si[i] = ci[i]; ss[i] = cs[i]; }
+    if (tid == 0) a.sel_count[b] = n;
+    return;
+  }
+  // ---- radix select (scores are positive floats: bit pattern is monotone)
+  unsigned prefix = 0, mask = 0;
+  int kth = K;
+  for (int pass = 3; pass >= 0; --pass) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const int sh = 8 * pass;
+    for (int i = tid; i < n; i += 1024) {
+      unsigned key = __float_as_uint(cs[i]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> sh) & 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int cum = 0, d = 255;
+      for (; d > 0; --d) {
+        if (cum + hist[d] >= kth) break;
+        cum += hist[d];
+      }
+      sh_kth = kth - cum;
+      sh_prefix = prefix | ((unsigned)d << sh);
+    }
+    __syncthreads();
+    kth = sh_kth;
+    prefix = sh_prefix;
+    mask |= 0xFFu << sh;
+    __syncthreads();
+  }
+  const unsigned pivot = prefix;       // bit pattern of the k-th largest score
+  const int take_eq = kth;             // how many scores == pivot to keep (lowest indices first)
+  // ---- gather survivors into LDS
+  for (int i = tid; i < P; i += 1024) keys[i] = 0ull;
+  if (tid == 0) sh_npos = 0;
+  __syncthreads();
+  int eq_base = 0;
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    int i = i0 + tid;
+    unsigned key = i < n ? __float_as_uint(cs[i]) : 0u;
+    int idx = i < n ? ci[i] : 0;
+    bool gt = i < n && key > pivot, eq = i < n && key == pivot;
+    int tot;
+    int er = block_scan_1024(eq ? 1 : 0, wsum, &tot);
+    bool take = gt || (eq && (eq_base + er) < take_eq);
+    eq_base += tot;
+    if (take) {
+      int pos = atomicAdd(&sh_npos, 1);
+      keys[pos] = ((unsigned long long)key << 32) | (unsigned)(~(unsigned)idx);
+    }
+  }
+  __syncthreads();
+  // ---- bitonic sort, descending
+  for (int k2 = 2; k2 <= P; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P; i += 1024) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          unsigned long long x = keys[i], y = keys[ixj];
+          bool desc = (i & k2) == 0;
+          if (desc ? (x < y) : (x > y)) { keys[i] = y; keys[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < K; i += 1024) {
+    unsigned long long kk = keys[i];
+    si[i] = (int)(~(unsigned)(kk & 0xFFFFFFFFull));
+    ss[i] = __uint_as_float((unsigned)(kk >> 32));
+  }
+  if (tid == 0) a.sel_count[b] = K;
+}
+
+// ------------------------------------------------------------------ descriptors
+// One wave per keypoint slot.  Channel c of lane handles c = lane, lane+64, ...
+template <int MAXC>
+__global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long slot = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (slot >= (long)a.B * a.Kcap) return;
+  const int bl = (int)(slot / a.Kcap), i = (int)(slot % a.Kcap);
+  const int b = a.b0 + bl;                     // image index into dense / sel_* arrays
+  const int cnt = a.sel_count[b];
+  float* kp = a.kpts + slot * 2;
+  float* dsc = a.desc + slot * a.d;
+  if (i >= cnt) {
+    if (lane < 2) kp[lane] = 0.f;
+    if (lane == 0) a.scores[slot] = 0.f;
+    for (int c = lane; c < a.d; c += 64) dsc[c] = 0.f;
+    return;
+  }
+  const int idx = a.sel_idx[(size_t)b * a.Ksel + i];
+  const int py = idx / a.W8, px = idx - py * a.W8;
+  const float kx = (float)px, ky = (float)py;                                   // flip (y,x)->(x,y) (:151)
+  if (lane == 0) { kp[0] = kx; kp[1] = ky; a.scores[slot] = a.sel_score[(size_t)b * a.Ksel + i]; }
+
+  const int w = a.Wc, h = a.Hc;
+  // sample_descriptors (:43-46), s = 8
+  float xn = ((kx - 4.0f) + 0.5f) / ((float)(w * 8) - 4.0f - 0.5f);
+  float yn = ((ky - 4.0f) + 0.5f) / ((float)(h * 8) - 4.0f - 0.5f);
+  xn = xn * 2.0f - 1.0f;
+  yn = yn * 2.0f - 1.0f;
+  // grid_sample un-normalisation (bilinear, zeros padding)
+  float ix, iy;
+  if (a.align_corners) {
+    ix = ((xn + 1.0f) / 2.0f) * (float)(w - 1);
+    iy = ((yn + 1.0f) / 2.0f) * (float)(h - 1);
+  } else {
+    ix = ((xn + 1.0f) * (float)w - 1.0f) / 2.0f;
+    iy = ((yn + 1.0f) * (float)h - 1.0f) / 2.0f;
+  }
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+  const float cw[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};            // nw, ne, sw, se
+  const int cx[4] = {x0, x0 + 1, x0, x0 + 1}, cy[4] = {y0, y0, y0 + 1, y0 + 1};
+
+  float acc[MAXC];
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (cx[q] < 0 || cx[q] >= w || cy[q] < 0 || cy[q] >= h) continue;          // zeros padding
+    const float* cell = a.dense + ((size_t)(b * h + cy[q]) * w + cx[q]) * a.ld;
+    float v[MAXC];
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) {
+      int c = lane + 64 * j;
+      v[j] = c < a.d ? cell[c] : 0.f;
+      s2 += v[j] * v[j];
+    }
+    float dn = sqrtf(wave_sum(s2));                                             // torch.norm(desc, dim=1) (:125)
+    if (a.dense_eps) dn = fmaxf(dn, 1e-12f);                                    // official: F.normalize
+#pragma unroll
+    for (int j = 0; j < MAXC; ++j) acc[j] += (v[j] / dn) * cw[q];
+  }
+  float n2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) n2 += acc[j] * acc[j];
+  const float denom = fmaxf(sqrtf(wave_sum(n2)), 1e-12f);                       // F.normalize (:50-51)
+#pragma unroll
+  for (int j = 0; j < MAXC; ++j) {
+    int c = lane + 64 * j;
+    if (c < a.d) dsc[c] = acc[j] / denom;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_softmax_shuffle(const float* semi, int ld, float* scores, int B, int Hc, int Wc, hipStream_t s) {
+  long cells = (long)B * Hc * Wc;
+  hipLaunchKernelGGL(softmax_shuffle_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, semi, ld, scores, B, Hc, Wc);
+  return hipGetLastError();
+}
+
+hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int radius, hipStream_t s) {
+  if (radius < 0 || radius > 8) return hipErrorInvalidValue;
+  if (radius == 0) return hipMemcpyAsync(out, scores, (size_t)B * H * W * sizeof(float), hipMemcpyDeviceToDevice, s);
+  auto lds_bytes = [&](int T) {
+    size_t side = T + 10 * radius, n = side * side;
+    return n * 4 * 3 + n * 2 + 4 + n * 4;   // S, X, tmp, M, Q, pad, P
+  };
+  if (radius <= 4) {
+    constexpr int T = 32;
+    dim3 grid((W + T - 1) / T, (H + T - 1) / T, B);
+    hipLaunchKernelGGL(nms_kernel<T>, grid, dim3(256), lds_bytes(T), s, scores, out, H, W, radius);
+  } else {
+    constexpr int T = 8;
+    dim3 grid((W + T - 1) / T, (H + T - 1) / T, B);
+    hipLaunchKernelGGL(nms_kernel<T>, grid, dim3(256), lds_bytes(T), s, scores, out, H, W, radius);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_keypoints(const KeypointArgs& a, hipStream_t s) {
+  long rows = (long)a.B * a.H;
+  hipLaunchKernelGGL(kp_count_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(kp_scan_rows, dim3(a.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(kp_scatter_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
+  int P = 1;
+  if (a.max_keypoints > 0) { while (P < a.max_keypoints) P <<= 1; }
+  if (P > 16384) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kp_topk, dim3(a.B), dim3(1024), (size_t)P * 8, s, a, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_describe(const DescribeArgs& a, hipStream_t s) {
+  long slots = (long)a.B * a.Kcap;
+  if (slots == 0) return hipSuccess;
+  dim3 grid((unsigned)((slots + 3) / 4));
+  if (a.d <= 128) hipLaunchKernelGGL(describe_kernel<2>, grid, dim3(256), 0, s, a);
+  else if (a.d <= 256) hipLaunchKernelGGL(describe_kernel<4>, grid, dim3(256), 0, s, a);
+  else if (a.d <= 512) hipLaunchKernelGGL(describe_kernel<8>, grid, dim3(256), 0, s, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace imx

@@ -1,0 +1,219 @@
+"""Host-side engine: one libimx handle per (device, config), weight upload, and tensor-level
+wrappers of the C-ABI entry points.  torch tensors are containers only (data_ptr + stream)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+SP_DEFAULT = {                      # superpoint/models/superpoint_test.py:57-63
+    "descriptor_dim": 256, "nms_radius": 4, "keypoint_threshold": 0.005,
+    "max_keypoints": -1, "remove_borders": 4,
+}
+SG_DEFAULT = {                      # superglue/models/superglue_test.py:195-202
+    "descriptor_dim": 256, "weights": "indoor", "keypoint_encoder": [32, 64, 128, 256],
+    "GNN_layers": ["self", "cross"] * 9, "sinkhorn_iterations": 100, "match_threshold": 0.2,
+}
+
+
+def reference_align_corners():
+    """What `int(torch.__version__[2]) > 2` (superpoint_test.py:47) evaluates to under the torch
+    in this process: True for torch 1.3-1.9, False for 1.10+/2.x (third character '1'/'0')."""
+    try:
+        return int(torch.__version__[2]) > 2
+    except ValueError:
+        return False
+
+
+class ImxError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Engine:
+    """Owns an imx handle.  `sp_cfg` / `sg_cfg` are the merged reference-style config dicts."""
+
+    def __init__(self, sp_cfg, sg_cfg, device, sp_variant=L.SP_VARIANT_BN, align_corners=None):
+        self.lib = L.load_library()
+        if not torch.cuda.is_available():
+            raise ImxError("image_matching_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback on the product path")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ImxError(f"image_matching_amd runs on 'cuda' (HIP) devices only, got {device!r}")
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        sp = {**SP_DEFAULT, **(sp_cfg or {})}
+        sg = {**SG_DEFAULT, **(sg_cfg or {})}
+        cfg = L.ImxConfig()
+        cfg.descriptor_dim = int(sp["descriptor_dim"])
+        cfg.nms_radius = int(sp["nms_radius"])
+        cfg.keypoint_threshold = float(sp["keypoint_threshold"])
+        cfg.max_keypoints = int(sp["max_keypoints"])
+        cfg.remove_borders = int(sp["remove_borders"])
+        cfg.align_corners = int(reference_align_corners() if align_corners is None else bool(align_corners))
+        cfg.sp_variant = int(sp_variant)
+        layers = list(sg["GNN_layers"])
+        if len(layers) > L.IMX_MAX_GNN_LAYERS:
+            raise ImxError(f"at most {L.IMX_MAX_GNN_LAYERS} GNN layers supported")
+        cfg.num_gnn_layers = len(layers)
+        for i, name in enumerate(layers):
+            cfg.gnn_layer_is_cross[i] = 1 if name == "cross" else 0
+        kenc = [int(c) for c in sg["keypoint_encoder"]]
+        cfg.kenc_n = len(kenc)
+        for i, c in enumerate(kenc):
+            cfg.kenc_channels[i] = c
+        cfg.sinkhorn_iterations = int(sg["sinkhorn_iterations"])
+        cfg.match_threshold = float(sg["match_threshold"])
+        self.cfg = cfg
+        self.d = cfg.descriptor_dim
+        self.max_keypoints = cfg.max_keypoints
+        self.handle = ctypes.c_void_p()
+        if self.lib.imx_create(idx, ctypes.byref(cfg), ctypes.byref(self.handle)) != 0:
+            raise ImxError(self.lib.imx_last_error(None).decode())
+        self.loaded = {L.NET_SUPERPOINT: False, L.NET_SUPERGLUE: False}
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.handle.value:
+                self.lib.imx_destroy(self.handle)
+                self.handle = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ImxError(self.lib.imx_last_error(self.handle).decode())
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, net, state_dict):
+        for key, val in state_dict.items():
+            if key.endswith("num_batches_tracked"):
+                continue
+            arr = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (ctypes.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            self._check(self.lib.imx_load_weight(self.handle, net, key.encode(), arr.ctypes.data_as(ctypes.c_void_p),
+                                                 arr.ndim, shape))
+        self._check(self.lib.imx_finalize_weights(self.handle, net))
+        self.loaded[net] = True
+
+    # ------------------------------------------------------------------ SuperPoint
+    def superpoint(self, x):
+        """x (B,1,H,W) float32 cuda -> (kpts (B,K,2), scores (B,K), desc (B,K,d), counts list)."""
+        x = self._image(x)
+        B, _, H, W = x.shape
+        counts = torch.empty(B, dtype=torch.int32, device=self.device)
+        st = _stream(self.device)
+        self._check(self.lib.imx_superpoint_detect(self.handle, _ptr(x), B, H, W, _ptr(counts), st))
+        n = counts.cpu().tolist()                       # device sync (the reference syncs at nonzero())
+        K = max(n) if n else 0
+        kpts = torch.empty(B, K, 2, dtype=torch.float32, device=self.device)
+        scores = torch.empty(B, K, dtype=torch.float32, device=self.device)
+        desc = torch.empty(B, K, self.d, dtype=torch.float32, device=self.device)
+        if K > 0:
+            self._check(self.lib.imx_superpoint_describe(self.handle, B, K, _ptr(kpts), _ptr(scores), _ptr(desc), st))
+        return kpts, scores, desc, n
+
+    def _image(self, x):
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 1:
+            raise ImxError(f"expected an image tensor of shape (B,1,H,W), got {getattr(x, 'shape', type(x))}")
+        if x.device.type != "cuda":
+            raise ImxError("image tensor must live on the GPU (the reference CLI moves it with .to(device)); "
+                           "there is no CPU path")
+        return x.to(device=self.device, dtype=torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ SuperGlue
+    def superglue(self, kpts0, scores0, desc0, shape0, kpts1, scores1, desc1, shape1, n0=None, n1=None):
+        """desc{0,1}: (B,d,N) tensors with arbitrary strides.  Returns matches0/1 (int64), mscores0/1."""
+        dev = self.device
+        kpts0 = kpts0.to(dev, torch.float32).contiguous()
+        kpts1 = kpts1.to(dev, torch.float32).contiguous()
+        scores0 = scores0.to(dev, torch.float32).contiguous()
+        scores1 = scores1.to(dev, torch.float32).contiguous()
+        desc0 = desc0.to(dev, torch.float32)
+        desc1 = desc1.to(dev, torch.float32)
+        B, N0 = kpts0.shape[0], kpts0.shape[1]
+        N1 = kpts1.shape[1]
+        if desc0.shape[1] != self.d or desc1.shape[1] != self.d:
+            raise ImxError(f"descriptor dim {desc0.shape[1]} != configured descriptor_dim {self.d}")
+        m0 = torch.empty(B, N0, dtype=torch.int64, device=dev)
+        m1 = torch.empty(B, N1, dtype=torch.int64, device=dev)
+        ms0 = torch.empty(B, N0, dtype=torch.float32, device=dev)
+        ms1 = torch.empty(B, N1, dtype=torch.float32, device=dev)
+        s0, s1 = desc0.stride(), desc1.stride()
+        self._check(self.lib.imx_superglue_forward(
+            self.handle, B,
+            _ptr(kpts0), _ptr(scores0), _ptr(desc0), s0[0], s0[1], s0[2], _ptr(n0), N0, int(shape0[-2]), int(shape0[-1]),
+            _ptr(kpts1), _ptr(scores1), _ptr(desc1), s1[0], s1[1], s1[2], _ptr(n1), N1, int(shape1[-2]), int(shape1[-1]),
+            _ptr(m0), _ptr(m1), _ptr(ms0), _ptr(ms1), _stream(dev)))
+        return m0, m1, ms0, ms1
+
+    # ------------------------------------------------------------------ fused pairs
+    def match_pairs(self, img0, img1, want_desc=False):
+        """Fused Matching.forward for B pairs (max_keypoints = K > 0); no host sync.
+        Returns dict of padded tensors: keypoints{0,1} (B,K,2), scores{0,1} (B,K), counts{0,1} (B),
+        matches{0,1} (B,K) int64, matching_scores{0,1} (B,K) [, descriptors{0,1} (B,K,d)]."""
+        img0, img1 = self._image(img0), self._image(img1)
+        if img0.shape != img1.shape:
+            raise ImxError("match_pairs needs equal image shapes on both sides")
+        B, _, H, W = img0.shape
+        K, dev = self.max_keypoints, self.device
+        if K <= 0:
+            raise ImxError("match_pairs needs max_keypoints > 0")
+        f32, out = torch.float32, {}
+        for s in "01":
+            out["keypoints" + s] = torch.empty(B, K, 2, dtype=f32, device=dev)
+            out["scores" + s] = torch.empty(B, K, dtype=f32, device=dev)
+            out["counts" + s] = torch.empty(B, dtype=torch.int32, device=dev)
+            out["matches" + s] = torch.empty(B, K, dtype=torch.int64, device=dev)
+            out["matching_scores" + s] = torch.empty(B, K, dtype=f32, device=dev)
+            if want_desc:
+                out["descriptors" + s] = torch.empty(B, K, self.d, dtype=f32, device=dev)
+        self._check(self.lib.imx_match_pairs(
+            self.handle, _ptr(img0), _ptr(img1), B, H, W,
+            _ptr(out["keypoints0"]), _ptr(out["keypoints1"]), _ptr(out["scores0"]), _ptr(out["scores1"]),
+            _ptr(out["counts0"]), _ptr(out["counts1"]),
+            _ptr(out.get("descriptors0")), _ptr(out.get("descriptors1")),
+            _ptr(out["matches0"]), _ptr(out["matches1"]),
+            _ptr(out["matching_scores0"]), _ptr(out["matching_scores1"]), _stream(dev)))
+        return out
+
+    # ------------------------------------------------------------------ debug / timing
+    def set_debug(self, on=True):
+        self._check(self.lib.imx_set_debug(self.handle, int(on)))
+
+    def fetch(self, name):
+        shape = (ctypes.c_int64 * 4)()
+        nd = ctypes.c_int(0)
+        self._check(self.lib.imx_debug_fetch(self.handle, name.encode(), None, 0, shape, ctypes.byref(nd)))
+        shp = tuple(shape[i] for i in range(nd.value))
+        out = np.empty(shp, dtype=np.float32)
+        self._check(self.lib.imx_debug_fetch(self.handle, name.encode(), out.ctypes.data_as(ctypes.c_void_p),
+                                             out.size, shape, ctypes.byref(nd)))
+        return out
+
+    def set_timing(self, on=True):
+        self._check(self.lib.imx_set_timing(self.handle, int(on)))
+
+    def timing_reset(self):
+        self._check(self.lib.imx_timing_reset(self.handle))
+
+    def timing_report(self):
+        n = self.lib.imx_timing_report(self.handle, -1, None, None, None)
+        if n < 0:
+            self._check(n)
+        rows = []
+        for i in range(n):
+            name, cnt, ms = ctypes.c_char_p(), ctypes.c_int64(), ctypes.c_double()
+            self._check(self.lib.imx_timing_report(self.handle, i, ctypes.byref(name), ctypes.byref(cnt), ctypes.byref(ms)))
+            rows.append((name.value.decode(), cnt.value, ms.value))
+        return rows

@@ -1,0 +1,248 @@
+"""Portable synthetic weights and images for the SuperPoint+SuperGlue hot path.
+
+All `.pth` files in the reference tree are git-LFS pointers, so parity and
+benchmarks run on seeded synthetic weights.  Everything here is integer hashing plus IEEE
+float32 add/mul/div/sqrt — no transcendental functions, no torch RNG — so the same seed
+gives bit-identical tensors in the build container and on the GPU box.
+
+State-dict key names and shapes are those of the reference modules:
+  SuperPoint-BN  superpoint/models/superpoint_test.py:64-85, unet_parts.py:10-48
+  SuperPoint     superglue/models/superpoint.py:111-134 (official, no BN)
+  SuperGlue      superglue/models/superglue_test.py:49-60,73-82,92-119,207-219
+"""
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _stream_base(seed, name, sub=0):
+    tag = zlib.crc32(name.encode()) & 0xFFFFFFFF
+    s = np.array([(int(seed) * 0x100000001B3 + tag * 0x10001 + sub) & 0xFFFFFFFFFFFFFFFF],
+                 dtype=np.uint64)
+    return _splitmix64(_splitmix64(s))[0]
+
+
+def uniform(seed, name, n, sub=0):
+    """n float32 in [0,1), 24-bit resolution (exact)."""
+    base = _stream_base(seed, name, sub)
+    with np.errstate(over="ignore"):
+        h = _splitmix64(base + np.arange(n, dtype=np.uint64) * np.uint64(0xD1342543DE82EF95))
+    return (h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))
+
+
+def normal(seed, name, n):
+    """Approximately N(0,1): (sum of 4 uniforms - 2) * sqrt(3); exact float32 arithmetic."""
+    acc = uniform(seed, name, n, 1)
+    for sub in (2, 3, 4):
+        acc = acc + uniform(seed, name, n, sub)
+    return (acc - np.float32(2.0)) * np.float32(np.sqrt(np.float32(3.0)))
+
+
+# ----------------------------------------------------------------------------- shapes
+def _double_conv_shapes(prefix, cin, cout):
+    s = OrderedDict()
+    for ci, idx in ((cin, 0), (cout, 3)):
+        s[f"{prefix}.{idx}.weight"] = (cout, ci, 3, 3)
+        s[f"{prefix}.{idx}.bias"] = (cout,)
+        for nm in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{prefix}.{idx + 1}.{nm}"] = (cout,)
+        s[f"{prefix}.{idx + 1}.num_batches_tracked"] = ()
+    return s
+
+
+def superpoint_bn_shapes(descriptor_dim=128):
+    """Key → shape of superpoint/models/superpoint_test.py:SuperPoint.state_dict()."""
+    c1, c2, c3, c4, c5 = 64, 64, 128, 128, 256
+    s = OrderedDict()
+    s.update(_double_conv_shapes("inc.conv.conv", 1, c1))
+    s.update(_double_conv_shapes("down1.mpconv.1.conv", c1, c2))
+    s.update(_double_conv_shapes("down2.mpconv.1.conv", c2, c3))
+    s.update(_double_conv_shapes("down3.mpconv.1.conv", c3, c4))
+    for head, cin, cout, k in (("Pa", c4, c5, 3), ("Pb", c5, 65, 1),
+                               ("Da", c4, c5, 3), ("Db", c5, descriptor_dim, 1)):
+        s[f"conv{head}.weight"] = (cout, cin, k, k)
+        s[f"conv{head}.bias"] = (cout,)
+        for nm in ("weight", "bias", "running_mean", "running_var"):
+            s[f"bn{head}.{nm}"] = (cout,)
+        s[f"bn{head}.num_batches_tracked"] = ()
+    return s
+
+
+def superpoint_official_shapes(descriptor_dim=256):
+    """Key → shape of superglue/models/superpoint.py:SuperPoint.state_dict() (no BN)."""
+    c1, c2, c3, c4, c5 = 64, 64, 128, 128, 256
+    s = OrderedDict()
+    for nm, cin, cout, k in (("conv1a", 1, c1, 3), ("conv1b", c1, c1, 3),
+                             ("conv2a", c1, c2, 3), ("conv2b", c2, c2, 3),
+                             ("conv3a", c2, c3, 3), ("conv3b", c3, c3, 3),
+                             ("conv4a", c3, c4, 3), ("conv4b", c4, c4, 3),
+                             ("convPa", c4, c5, 3), ("convPb", c5, 65, 1),
+                             ("convDa", c4, c5, 3), ("convDb", c5, descriptor_dim, 1)):
+        s[f"{nm}.weight"] = (cout, cin, k, k)
+        s[f"{nm}.bias"] = (cout,)
+    return s
+
+
+def superglue_shapes(descriptor_dim=128, keypoint_encoder=(32, 64, 128), n_layers=18):
+    """Key → shape of superglue/models/superglue_test.py:SuperGlue.state_dict()."""
+    d = descriptor_dim
+    s = OrderedDict()
+    s["bin_score"] = ()
+    ch = [3] + list(keypoint_encoder) + [d]
+    for i in range(1, len(ch)):
+        j = 3 * (i - 1)
+        s[f"kenc.encoder.{j}.weight"] = (ch[i], ch[i - 1], 1)
+        s[f"kenc.encoder.{j}.bias"] = (ch[i],)
+        if i < len(ch) - 1:
+            for nm in ("weight", "bias", "running_mean", "running_var"):
+                s[f"kenc.encoder.{j + 1}.{nm}"] = (ch[i],)
+            s[f"kenc.encoder.{j + 1}.num_batches_tracked"] = ()
+    for l in range(n_layers):
+        p = f"gnn.layers.{l}"
+        s[f"{p}.attn.merge.weight"] = (d, d, 1)
+        s[f"{p}.attn.merge.bias"] = (d,)
+        for k in range(3):
+            s[f"{p}.attn.proj.{k}.weight"] = (d, d, 1)
+            s[f"{p}.attn.proj.{k}.bias"] = (d,)
+        s[f"{p}.mlp.0.weight"] = (2 * d, 2 * d, 1)
+        s[f"{p}.mlp.0.bias"] = (2 * d,)
+        for nm in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{p}.mlp.1.{nm}"] = (2 * d,)
+        s[f"{p}.mlp.1.num_batches_tracked"] = ()
+        s[f"{p}.mlp.3.weight"] = (d, 2 * d, 1)
+        s[f"{p}.mlp.3.bias"] = (d,)
+    s["final_proj.weight"] = (d, d, 1)
+    s["final_proj.bias"] = (d,)
+    return s
+
+
+# ---------------------------------------------------------------------------- weights
+def _is_bn_key(key, shapes):
+    stem = key.rsplit(".", 1)[0]
+    return f"{stem}.running_mean" in shapes
+
+
+def synth_state_dict(shapes, seed, gains=None):
+    """Numpy state dict for `shapes`: conv weight ~N(0, 2/fan_in), conv bias ~N(0,0.05²),
+    BN γ~U(0.5,1.5), β~N(0,0.1²), running_mean 0, running_var 1 (calibrate separately),
+    num_batches_tracked 0 (int64).  `gains` maps a key substring to a weight multiplier."""
+    gains = gains or {}
+    sd = OrderedDict()
+    for key, shape in shapes.items():
+        n = int(np.prod(shape)) if len(shape) else 1
+        leaf = key.rsplit(".", 1)[1] if "." in key else key
+        if leaf == "num_batches_tracked":
+            sd[key] = np.zeros((), dtype=np.int64)
+            continue
+        if key == "bin_score":
+            sd[key] = np.float32(1.0).reshape(())
+            continue
+        if _is_bn_key(key, shapes):
+            if leaf == "weight":
+                v = np.float32(0.5) + uniform(seed, key, n)
+            elif leaf == "bias":
+                v = normal(seed, key, n) * np.float32(0.1)
+            elif leaf == "running_mean":
+                v = np.zeros(n, dtype=np.float32)
+            else:
+                v = np.ones(n, dtype=np.float32)
+        elif leaf == "weight":
+            fan_in = int(np.prod(shape[1:]))
+            v = normal(seed, key, n) * np.float32(np.sqrt(np.float32(2.0 / fan_in)))
+            for sub, g in gains.items():
+                if sub in key:
+                    v = v * np.float32(g)
+        else:  # conv bias
+            v = normal(seed, key, n) * np.float32(0.05)
+        sd[key] = v.reshape(shape).astype(np.float32)
+    return sd
+
+
+def bn_stat_keys(shapes):
+    return [k for k in shapes if k.endswith("running_mean") or k.endswith("running_var")]
+
+
+def apply_bn_stats(sd, stats):
+    """Overwrite running_mean / running_var entries with calibrated ones (dict of arrays)."""
+    for k, v in stats.items():
+        assert k in sd and sd[k].shape == np.asarray(v).shape, k
+        sd[k] = np.asarray(v, dtype=np.float32)
+    return sd
+
+
+# ----------------------------------------------------------------------------- images
+def _box5_wrap(a):
+    out = np.zeros_like(a)
+    for dy in (-2, -1, 0, 1, 2):
+        row = np.roll(a, dy, axis=0)
+        for dx in (-2, -1, 0, 1, 2):
+            out = out + np.roll(row, dx, axis=1)
+    return out * np.float32(1.0 / 25.0)
+
+
+def synth_image(seed, H, W):
+    """Smooth random texture in [0,1]: uniform noise, 5×5 box blur twice, min-max rescale."""
+    a = uniform(seed, "image", H * W).reshape(H, W)
+    a = _box5_wrap(_box5_wrap(a))
+    lo, hi = a.min(), a.max()
+    return ((a - lo) / (hi - lo)).astype(np.float32)
+
+
+def synth_pair(seed, H, W, shift=(8, 16), noise=0.01):
+    """(image0, image1) float32 (H,W): image1 = roll(image0, shift) + noise·N(0,1), clamped."""
+    im0 = synth_image(seed, H, W)
+    im1 = np.roll(im0, shift, axis=(0, 1)) + normal(seed, "image1_noise", H * W).reshape(H, W) * np.float32(noise)
+    return im0, np.clip(im1, np.float32(0.0), np.float32(1.0)).astype(np.float32)
+
+
+# ------------------------------------------------------------- canonical synthetic weight sets
+# Shared by tests, bench.py and tests/golden/make_golden.py.  BatchNorm running statistics were
+# calibrated once with the reference's own modules (make_golden.py) and are shipped as data.
+SP_SEED, SG_SEED = 123, 456
+SG_GAINS = {".mlp.3.weight": 0.3, "final_proj.weight": 0.7}
+SG_CONFIGS = {      # descriptor_dim -> (keypoint_encoder, sinkhorn_iterations, match_threshold)
+    128: ([32, 64, 128], 30, 0.1),            # superpoint_glue_test.py:23,33-35 defaults (C3)
+    256: ([32, 64, 128, 256], 100, 0.2),      # SuperGlue.default_config (C5)
+}
+_STATS = None
+
+
+def _stats():
+    global _STATS
+    if _STATS is None:
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "synth_bn_stats.npz")
+        with np.load(path) as z:
+            _STATS = {k: z[k] for k in z.files}
+    return _STATS
+
+
+def calibrated_stats(prefix):
+    """prefix 'sp128' | 'sp256' | 'sg128' | 'sg256' -> {state-dict key: running stat array}."""
+    return {k.split("/", 1)[1]: v for k, v in _stats().items()
+            if k.startswith(prefix + "/") and not k.endswith("bin_score")}
+
+
+def make_superpoint_state_dict(descriptor_dim=128):
+    sd = synth_state_dict(superpoint_bn_shapes(descriptor_dim), SP_SEED)
+    return apply_bn_stats(sd, calibrated_stats(f"sp{descriptor_dim}"))
+
+
+def make_superglue_state_dict(descriptor_dim=128, keypoint_encoder=None, n_layers=18):
+    kenc = list(keypoint_encoder) if keypoint_encoder is not None else SG_CONFIGS[descriptor_dim][0]
+    sd = synth_state_dict(superglue_shapes(descriptor_dim, kenc, n_layers), SG_SEED, gains=SG_GAINS)
+    apply_bn_stats(sd, {k: v for k, v in calibrated_stats(f"sg{descriptor_dim}").items() if k in sd})
+    sd["bin_score"] = np.float32(_stats()[f"sg{descriptor_dim}/bin_score"]).reshape(())
+    return sd

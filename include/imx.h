@@ -1,0 +1,145 @@
+/* imx.h — C ABI of libimx.so: MI355X-native SuperPoint + SuperGlue inference hot path.
+ *
+ * The reference (PH8411/image-matching) is pure Python and has no FFI of its own; the
+ * boundary it exposes for this path is the nn.Module API
+ *     SuperPoint.forward   superpoint/models/superpoint_test.py:103-161
+ *                          (official variant superglue/models/superpoint.py:145-202)
+ *     SuperGlue.forward    superglue/models/superglue_test.py:230-285
+ *     Matching.forward     superglue/models/matching_test.py:54-82
+ * Each entry point below names the reference call it replaces.  The Python drop-in classes
+ * (image-matching_amd/superpoint, image-matching_amd/superglue) bind these through ctypes;
+ * INTEGRATION.md shows the binding a maintainer would add to the reference.
+ *
+ * Conventions
+ *   - every call returns int: 0 = ok, <0 = error (imx_last_error gives the text); nothing
+ *     throws or aborts across the ABI;
+ *   - `*_dev` pointers are device (HBM) pointers owned by the CALLER (e.g. torch tensors);
+ *     the library borrows them for the duration of the call only;
+ *   - work is enqueued asynchronously on the caller's HIP stream (`stream`, a hipStream_t
+ *     passed as void*; NULL = the default stream); results are ready when the stream is;
+ *   - workspace and weights are owned by the handle; a handle is bound to one device and is
+ *     not thread-safe (one host thread per handle/GPU); handles are independent;
+ *   - all tensors are fp32 unless stated; images are (B,1,H,W) contiguous in [0,1].
+ */
+#ifndef IMX_H
+#define IMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMX_MAX_GNN_LAYERS 64
+#define IMX_MAX_KENC 8
+
+#define IMX_NET_SUPERPOINT 0
+#define IMX_NET_SUPERGLUE 1
+
+#define IMX_SP_VARIANT_BN 0        /* superpoint/models/superpoint_test.py (BatchNorm, desc/‖desc‖ no eps) */
+#define IMX_SP_VARIANT_OFFICIAL 1  /* superglue/models/superpoint.py (no BN, F.normalize eps 1e-12)       */
+
+typedef struct imx_handle_s* imx_handle_t;
+
+/* Mirrors SuperPoint.default_config (superpoint_test.py:57-63) and SuperGlue.default_config
+ * (superglue_test.py:195-202), merged with the user's config by the Python classes. */
+typedef struct imx_config {
+  /* SuperPoint */
+  int32_t descriptor_dim;      /* 'descriptor_dim' (multiple of 32; 4 heads => multiple of 128 for SuperGlue) */
+  int32_t nms_radius;          /* 'nms_radius' (0..8)                                   */
+  float keypoint_threshold;    /* 'keypoint_threshold'                                  */
+  int32_t max_keypoints;       /* 'max_keypoints' (-1 = keep all)                       */
+  int32_t remove_borders;      /* 'remove_borders'                                      */
+  int32_t align_corners;       /* grid_sample mode chosen at superpoint_test.py:47      */
+  int32_t sp_variant;          /* IMX_SP_VARIANT_*                                      */
+  /* SuperGlue */
+  int32_t num_gnn_layers;                       /* len('GNN_layers')                    */
+  int32_t gnn_layer_is_cross[IMX_MAX_GNN_LAYERS]; /* 0 = 'self', 1 = 'cross'            */
+  int32_t kenc_n;                               /* len('keypoint_encoder')              */
+  int32_t kenc_channels[IMX_MAX_KENC];          /* 'keypoint_encoder'                   */
+  int32_t sinkhorn_iterations;                  /* 'sinkhorn_iterations'                */
+  float match_threshold;                        /* 'match_threshold'                    */
+} imx_config_t;
+
+/* Replaces Matching.__init__ / `.to(device)` (matching_test.py:49-52, superpoint_glue_test.py:69). */
+int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out);
+int imx_destroy(imx_handle_t h);
+/* Text of the last error on this handle (h == NULL: last error of a failed imx_create). */
+const char* imx_last_error(imx_handle_t h);
+
+/* Replaces load_state_dict (superpoint_test.py:87-99, superglue_test.py:221-227,
+ * superglue/models/superpoint.py:136-137).  `name` is the reference state-dict key, `host` a
+ * HOST pointer to the fp32 tensor in the reference's layout (Conv2d: (Cout,Cin,kh,kw), Conv1d:
+ * (Cout,Cin,1), BN vectors, bin_score: scalar).  The library copies.  Unknown keys are an error;
+ * '*.num_batches_tracked' need not be passed. */
+int imx_load_weight(imx_handle_t h, int net, const char* name, const float* host,
+                    int ndim, const int64_t* shape);
+/* Folds eval-mode BatchNorm (eps 1e-5) into the preceding conv, re-lays weights out for the
+ * kernels and uploads them.  Fails listing the first missing key. */
+int imx_finalize_weights(imx_handle_t h, int net);
+
+/* SuperPoint.forward, detection half: encoder, heads, softmax+pixel-shuffle, simple_nms,
+ * threshold, remove_borders, top-k (superpoint_test.py:113-149).  img_dev: (B,1,H,W).
+ * counts_dev (may be NULL): B int32, number of keypoints kept per image. */
+int imx_superpoint_detect(imx_handle_t h, const float* img_dev, int B, int H, int W,
+                          int32_t* counts_dev, void* stream);
+/* SuperPoint.forward, description half (superpoint_test.py:151-155) for the images of the last
+ * imx_superpoint_detect: writes, per image b, rows [0,count_b) of
+ *   kpts_dev   (B,Kcap,2)  (x,y) float         scores_dev (B,Kcap)
+ *   desc_dev   (B,Kcap,d)  one L2-normalised descriptor per row (the transpose of the
+ *                          reference's (d,K) tensor; rows >= count_b are zero-filled)
+ * Kcap must be >= every count (for max_keypoints >= 0, Kcap = max_keypoints suffices). */
+int imx_superpoint_describe(imx_handle_t h, int B, int Kcap, float* kpts_dev, float* scores_dev,
+                            float* desc_dev, void* stream);
+
+/* SuperGlue.forward (superglue_test.py:230-285) on B pairs.
+ *   kpts{0,1}_dev (B,N{0,1},2) (x,y) px;  scores{0,1}_dev (B,N{0,1});
+ *   desc{0,1}_dev: element (b, c, i) at  b*desc_stride_b + c*desc_stride_c + i*desc_stride_n
+ *                  (reference layout (B,d,N): stride_c = N, stride_n = 1);
+ *   n{0,1}_dev: B int32 valid counts per pair, or NULL = all N{0,1} valid;
+ *   H,W per side: only the image *shape* is used (normalize_keypoints, :63-70).
+ * Outputs (B,N0)/(B,N1): matches int64 (-1 = unmatched), matching_scores fp32; entries at
+ * i >= count are -1 / 0.  A pair with a zero count yields all -1 / 0 (:235-242). */
+int imx_superglue_forward(imx_handle_t h, int B,
+                          const float* kpts0_dev, const float* scores0_dev, const float* desc0_dev,
+                          int64_t desc0_stride_b, int64_t desc0_stride_c, int64_t desc0_stride_n,
+                          const int32_t* n0_dev, int N0, int H0, int W0,
+                          const float* kpts1_dev, const float* scores1_dev, const float* desc1_dev,
+                          int64_t desc1_stride_b, int64_t desc1_stride_c, int64_t desc1_stride_n,
+                          const int32_t* n1_dev, int N1, int H1, int W1,
+                          int64_t* matches0_dev, int64_t* matches1_dev,
+                          float* mscores0_dev, float* mscores1_dev, void* stream);
+
+/* Matching.forward (matching_test.py:54-82) fused for B pairs of equal-size images with
+ * max_keypoints = K >= 0: SuperPoint on img0/img1 (each (B,1,H,W)), then SuperGlue, no host
+ * synchronisation.  Outputs per side s: kpts (B,K,2), scores (B,K), counts (B) int32,
+ * desc (B,K,d) or NULL, matches (B,K) int64, mscores (B,K). */
+int imx_match_pairs(imx_handle_t h, const float* img0_dev, const float* img1_dev, int B, int H, int W,
+                    float* kpts0_dev, float* kpts1_dev, float* scores0_dev, float* scores1_dev,
+                    int32_t* counts0_dev, int32_t* counts1_dev, float* desc0_dev, float* desc1_dev,
+                    int64_t* matches0_dev, int64_t* matches1_dev,
+                    float* mscores0_dev, float* mscores1_dev, void* stream);
+
+/* Parity-test taps: when enabled, forwards keep copies of named intermediates
+ * ("x4","semi","desc","score_map","nms","kenc","gnn<i>","mdesc","scores_in","u","v", ...).
+ * imx_debug_fetch copies one to HOST (synchronises the device); shape_out gets up to 4 dims. */
+int imx_set_debug(imx_handle_t h, int enable);
+int imx_debug_fetch(imx_handle_t h, const char* name, float* host_out, int64_t capacity,
+                    int64_t* shape_out, int* ndim_out);
+
+/* Per-kernel timing for bench.py's roofline block: when enabled, every kernel launch is
+ * bracketed by HIP events on the launch stream.  imx_timing_report(h, -1, ...) synchronises,
+ * aggregates by kernel name and returns the number of rows; imx_timing_report(h, i>=0, ...)
+ * returns row i as (name, launches, total_ms). */
+int imx_set_timing(imx_handle_t h, int enable);
+int imx_timing_report(imx_handle_t h, int index, const char** name_out, int64_t* launches_out,
+                      double* total_ms_out);
+int imx_timing_reset(imx_handle_t h);
+
+/* Library build string, e.g. "imx 0.1 gfx950 hip-7.2". */
+const char* imx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMX_H */

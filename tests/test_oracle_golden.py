@@ -1,0 +1,96 @@
+"""The oracle (CPU restatement) against golden vectors produced by the reference's own modules
+(tests/golden/make_golden.py).  This is what pins the oracle; runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import matching_ref, superglue_ref, superpoint_ref
+from tests import util
+
+
+@pytest.mark.parametrize("name", ["sp_small.npz", "sp_ragged.npz"])
+def test_superpoint_dense_and_keypoints(name):
+    g = util.golden(name)
+    H, W, seed, K = int(g["H"]), int(g["W"]), int(g["seed"]), int(g["max_keypoints"])
+    x = torch.cat(util.pair(seed, H, W))
+    out = superpoint_ref.superpoint_forward(x, util.sp_sd(128), util.sp_config(128, K), return_dense=True)
+    for key in ("x4", "semi", "desc", "score_map"):
+        util.assert_close(out[key], g[key], f"{name}:{key}", atol=1e-5, rtol=1e-5)
+    assert np.array_equal(out["nms"].numpy(), g["nms"]) or np.allclose(out["nms"].numpy(), g["nms"], atol=1e-6)
+    for b in range(2):
+        assert np.array_equal(out["keypoints"][b].numpy(), g[f"keypoints{b}"]), "keypoints (order and values)"
+        util.assert_close(out["scores"][b], g[f"scores{b}"], "scores", atol=1e-6, rtol=1e-6)
+        util.assert_close(out["descriptors"][b], g[f"descriptors{b}"], "descriptors", atol=1e-5, rtol=1e-5)
+
+
+def test_nms_bit_exact_given_reference_score_map():
+    g = util.golden("sp_small.npz")
+    nms = superpoint_ref.simple_nms(torch.from_numpy(g["score_map"]), 4)
+    assert np.array_equal(nms.numpy(), g["nms"])
+
+
+def test_sample_descriptors_both_align_modes():
+    g = util.golden("sample_desc.npz")
+    kp, dmap = torch.from_numpy(g["kp"]), torch.from_numpy(g["dmap"])
+    for mode, key in ((False, "out_false"), (True, "out_true")):
+        out = superpoint_ref.sample_descriptors(kp.clone(), dmap, 8, align_corners=mode)
+        util.assert_close(out, g[key], f"sample_descriptors align_corners={mode}", atol=1e-6, rtol=1e-6)
+    assert np.abs(g["out_false"] - g["out_true"]).max() > 0.05      # the modes really differ
+
+
+def _sg_inputs(g, n0=None, n1=None):
+    d = {k: torch.from_numpy(g[k]) for k in ("keypoints0", "keypoints1", "scores0", "scores1", "descriptors0", "descriptors1")}
+    if n0 is not None:
+        d["keypoints0"], d["scores0"], d["descriptors0"] = d["keypoints0"][:, :n0], d["scores0"][:, :n0], d["descriptors0"][:, :, :n0]
+        d["keypoints1"], d["scores1"], d["descriptors1"] = d["keypoints1"][:, :n1], d["scores1"][:, :n1], d["descriptors1"][:, :, :n1]
+    d["image_shape0"] = d["image_shape1"] = (1, 1, 120, 160)
+    return d
+
+
+def test_superglue_dense_and_matches():
+    g = util.golden("sg_small.npz")
+    out = superglue_ref.superglue_forward(_sg_inputs(g), util.sg_sd(128), util.sg_config(128), return_dense=True)
+    dn = out["dense"]
+    util.assert_close(dn["kenc0"], g["kenc0"], "kenc0", atol=1e-5, rtol=1e-5)
+    util.assert_close(dn["gnn_taps"][0][0], g["tap0_0"], "gnn layer 0", atol=1e-5, rtol=1e-5)
+    util.assert_close(dn["gnn_taps"][1][1], g["tap1_1"], "gnn layer 1", atol=1e-5, rtol=1e-5)
+    util.assert_close(dn["gnn0"], g["gnn0"], "gnn out", atol=1e-4, rtol=1e-5)
+    util.assert_close(dn["scores_in"], g["scores_in"], "scores_in", atol=1e-4, rtol=1e-5)
+    util.assert_close(dn["Z"], g["Z"], "Z", atol=1e-4, rtol=1e-5)
+    assert np.array_equal(out["matches0"].numpy(), g["matches0"])
+    assert np.array_equal(out["matches1"].numpy(), g["matches1"])
+    util.assert_close(out["matching_scores0"], g["matching_scores0"], "mscores0", atol=1e-5, rtol=1e-4)
+    util.assert_close(out["matching_scores1"], g["matching_scores1"], "mscores1", atol=1e-5, rtol=1e-4)
+    assert (g["matches0"] > -1).sum() >= 20       # the fixture really exercises matching
+
+
+def test_superglue_ragged_and_empty():
+    g, gs = util.golden("sg_ragged.npz"), util.golden("sg_small.npz")
+    out = superglue_ref.superglue_forward(_sg_inputs(gs, 150, 97), util.sg_sd(128), util.sg_config(128), return_dense=True)
+    util.assert_close(out["dense"]["Z"], g["Z"], "Z ragged", atol=1e-4, rtol=1e-5)
+    assert np.array_equal(out["matches0"].numpy(), g["matches0"])
+    assert np.array_equal(out["matches1"].numpy(), g["matches1"])
+    assert out["matches0"].dtype == torch.int64 and str(g["normal_dtype"]) == "torch.int64"
+    e = superglue_ref.superglue_forward(_sg_inputs(gs, 150, 0), util.sg_sd(128), util.sg_config(128))
+    assert e["matches0"].dtype == torch.int32 and str(g["empty_dtype"]) == "torch.int32"
+    assert np.array_equal(e["matches0"].numpy(), g["empty_matches0"]) and e["matches1"].shape == (1, 0)
+    assert np.array_equal(e["matching_scores0"].numpy(), g["empty_scores0"])
+
+
+@pytest.mark.parametrize("name", ["c3_pair_s59.npz", "c3_pair_s55.npz"])
+def test_matching_c3_end_to_end(name):
+    g = util.golden(name)
+    H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
+    x0, x1 = util.pair(seed, H, W)
+    cfg = {"superpoint": util.sp_config(d, K), "superglue": util.sg_config(d)}
+    pred = matching_ref.matching_forward({"image0": x0, "image1": x1}, util.sp_sd(d), util.sg_sd(d), cfg)
+    assert np.array_equal(pred["keypoints0"][0].numpy(), g["keypoints0"])
+    assert np.array_equal(pred["keypoints1"][0].numpy(), g["keypoints1"])
+    util.assert_close(pred["descriptors0"][0][:, ::16], g["descriptors0_sub"], "descriptors0", atol=1e-5, rtol=1e-5)
+    assert np.array_equal(pred["matches0"].numpy(), g["matches0"])
+    assert np.array_equal(pred["matches1"].numpy(), g["matches1"])
+    util.assert_close(pred["matching_scores0"], g["matching_scores0"], "mscores0", atol=1e-5, rtol=1e-4)
+    # container types / dtypes of Matching.forward
+    assert isinstance(pred["keypoints0"], list) and isinstance(pred["scores0"], tuple) and isinstance(pred["descriptors0"], list)
+    assert pred["matches0"].dtype == torch.int64 and pred["matching_scores0"].dtype == torch.float32
+    assert pred["descriptors0"][0].shape == (d, K) and pred["keypoints0"][0].shape == (K, 2)
