@@ -14,7 +14,7 @@ SP_VARIANT_BN, SP_VARIANT_OFFICIAL = 0, 1
 EXPORTS = (
     "imx_create", "imx_destroy", "imx_last_error", "imx_load_weight", "imx_finalize_weights",
     "imx_superpoint_detect", "imx_superpoint_describe", "imx_superglue_forward",
-    "imx_match_pairs", "imx_set_debug", "imx_debug_fetch", "imx_set_timing",
+    "imx_match_pairs", "imx_op_nms", "imx_set_debug", "imx_debug_fetch", "imx_set_timing",
     "imx_timing_report", "imx_timing_reset", "imx_version",
 )
 
@@ -65,6 +65,7 @@ def load_library():
                                           f32p, f32p, f32p, i64, i64, i64, vp, i32, i32, i32,
                                           vp, vp, f32p, f32p, vp]
     lib.imx_match_pairs.argtypes = [vp, f32p, f32p, i32, i32, i32] + [vp] * 12 + [vp]
+    lib.imx_op_nms.argtypes = [vp, f32p, f32p, i32, i32, i32, i32, vp]
     lib.imx_set_debug.argtypes = [vp, i32]
     lib.imx_debug_fetch.argtypes = [vp, ctypes.c_char_p, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i32)]
     lib.imx_set_timing.argtypes = [vp, i32]

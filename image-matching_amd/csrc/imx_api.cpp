@@ -744,6 +744,14 @@ int imx_match_pairs(imx_handle_t h, const float* img0_dev, const float* img1_dev
   return sg_forward(h, B, sd, matches0_dev, matches1_dev, mscores0_dev, mscores1_dev, s);
 }
 
+int imx_op_nms(imx_handle_t h, const float* scores_dev, float* out_dev, int B, int H, int W, int radius, void* stream) {
+  if (!h) return -1;
+  HIP_OK(h, hipSetDevice(h->device));
+  hipStream_t s = as_stream(stream);
+  RUN("nms", launch_nms(scores_dev, out_dev, B, H, W, radius, s));
+  return 0;
+}
+
 int imx_set_debug(imx_handle_t h, int enable) {
   if (!h) return -1;
   h->debug = enable != 0;

@@ -187,6 +187,14 @@ class Engine:
             _ptr(out["matching_scores0"]), _ptr(out["matching_scores1"]), _stream(dev)))
         return out
 
+    def op_nms(self, scores, radius):
+        """simple_nms on a (B,H,W) score map (single-stage entry point, used by parity tests)."""
+        scores = scores.to(self.device, torch.float32).contiguous()
+        out = torch.empty_like(scores)
+        B, H, W = scores.shape
+        self._check(self.lib.imx_op_nms(self.handle, _ptr(scores), _ptr(out), B, H, W, int(radius), _stream(self.device)))
+        return out
+
     # ------------------------------------------------------------------ debug / timing
     def set_debug(self, on=True):
         self._check(self.lib.imx_set_debug(self.handle, int(on)))

@@ -120,6 +120,11 @@ int imx_match_pairs(imx_handle_t h, const float* img0_dev, const float* img1_dev
                     int64_t* matches0_dev, int64_t* matches1_dev,
                     float* mscores0_dev, float* mscores1_dev, void* stream);
 
+/* Single-stage entry point: simple_nms (superpoint_test.py:7-22) on a caller-supplied score map
+ * (B,H,W) -> out (B,H,W).  Compare-only arithmetic: bit-exact given identical input. */
+int imx_op_nms(imx_handle_t h, const float* scores_dev, float* out_dev, int B, int H, int W,
+               int radius, void* stream);
+
 /* Parity-test taps: when enabled, forwards keep copies of named intermediates
  * ("x4","semi","desc","score_map","nms","kenc","gnn<i>","mdesc","scores_in","u","v", ...).
  * imx_debug_fetch copies one to HOST (synchronises the device); shape_out gets up to 4 dims. */
