@@ -1,0 +1,258 @@
+#!/usr/bin/env python
+"""bench.py — image-pairs/sec of the SuperPoint+SuperGlue hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is one pass of the hot path over one batch of synthetic pairs already resident in HBM:
+B pairs per GPU (weak scaling; pair i of the job goes to rank i % world) through the fused C-ABI
+call imx_match_pairs (SuperPoint on both images, SuperGlue, match extraction), followed — when
+world > 1 — by the one collective of the path, an RCCL all-gather of the fixed-size match records.
+Workload = BASELINE.json configs[2]/[3] shape ("C3"): 640x480 grayscale, d=128, 1024 keypoints,
+30 Sinkhorn iterations, synthetic BN-calibrated weights (no trained weights exist: LFS pointers).
+
+Rank 0 prints ONE JSON line (contract in the task statement) including
+  "roofline":     dominant kernel's achieved algorithmic FLOP/s (or B/s) vs the gfx950 peak, from
+                  per-launch HIP events on the launch stream over a second, instrumented pass of
+                  the same K steps;
+  "cpu_baseline": the oracle (CPU restatement of the reference, torch CPU ops) timed on this
+                  host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from image_matching_amd import shard, synth                                    # noqa: E402
+from image_matching_amd.superglue.models.matching_test import Matching         # noqa: E402
+
+WORKLOADS = {
+    "c3": dict(H=480, W=640, d=128, K=1024, name="C3 SuperPoint+SuperGlue 640x480 d=128 1024 kpts 30 Sinkhorn iters"),
+    "c5": dict(H=960, W=1280, d=256, K=2048, name="C5 SuperPoint+SuperGlue 1280x960 d=256 2048 kpts 100 Sinkhorn iters"),
+}
+PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def algorithmic_work(B, H, W, d, K, kenc, iters, n_layers=18):
+    """Per-launch algorithmic work of every kernel name of one step (B pairs = 2B images):
+    ('mfma', FLOPs) for matrix kernels, ('hbm', bytes) for streaming kernels.  FLOPs = 2 x MACs of
+    the reference's dense ops; bytes = compulsory reads+writes of the stage."""
+    I = 2 * B
+    H2, W2, H4, W4, Hc, Wc = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
+    R = 2 * B * K
+    w = {
+        "conv1ab_pool": ("mfma", 2.0 * I * H * W * (9 * 64 + 576 * 64)),
+        "conv2a": ("mfma", 2.0 * I * H2 * W2 * 576 * 64),
+        "conv2b_pool": ("mfma", 2.0 * I * H2 * W2 * 576 * 64),
+        "conv3a": ("mfma", 2.0 * I * H4 * W4 * 576 * 128),
+        "conv3b_pool": ("mfma", 2.0 * I * H4 * W4 * 1152 * 128),
+        "conv4a": ("mfma", 2.0 * I * Hc * Wc * 1152 * 128),
+        "conv4b": ("mfma", 2.0 * I * Hc * Wc * 1152 * 128),
+        "convPaDa": ("mfma", 2.0 * I * Hc * Wc * 1152 * 512),
+        "convPb": ("mfma", 2.0 * I * Hc * Wc * 256 * 65),
+        "convDb": ("mfma", 2.0 * I * Hc * Wc * 256 * d),
+        "softmax_shuffle": ("hbm", 4.0 * I * Hc * Wc * (65 + 64)),
+        "nms": ("hbm", 4.0 * I * 2 * H * W),
+        "keypoints": ("hbm", 4.0 * I * H * W),
+        "describe": ("hbm", 4.0 * I * K * (4 * d + d + 3)),
+        "gather_desc": ("hbm", 4.0 * 2 * R * d / 2),
+        "kenc0": ("hbm", 4.0 * R * (3 + kenc[0])),
+        "qkv_proj": ("mfma", 2.0 * R * d * 3 * d),
+        "attention": ("mfma", 2.0 * 2 * B * 2 * K * K * d),
+        "attn_merge": ("mfma", 2.0 * R * d * d),
+        "gnn_mlp1": ("mfma", 2.0 * R * 2 * d * 2 * d),
+        "gnn_mlp2": ("mfma", 2.0 * R * 2 * d * d),
+        "final_proj": ("mfma", 2.0 * R * d * d),
+        "score_gemm": ("mfma", 2.0 * B * K * K * d),
+        "sinkhorn": ("hbm", 4.0 * B * K * K * 2 * iters),       # one launch group = all iterations
+        "matches": ("hbm", 4.0 * B * K * K * 2),
+    }
+    ch = list(kenc) + [d]
+    w["kenc"] = ("mfma", 2.0 * R * sum(ch[i] * ch[i + 1] for i in range(len(ch) - 1)) / (len(ch) - 1))
+    return w
+
+
+def build_matching(wl, device):
+    d, K = wl["d"], wl["K"]
+    kenc, iters, thr = synth.SG_CONFIGS[d]
+    cfg = {"superpoint": {"weights": None, "descriptor_dim": d, "nms_radius": 4, "keypoint_threshold": 0.005,
+                          "max_keypoints": K},
+           "superglue": {"weights": None, "descriptor_dim": d, "keypoint_encoder": kenc,
+                         "sinkhorn_iterations": iters, "match_threshold": thr}}
+    m = Matching(cfg).eval().to(device)
+    sd_sp = {k: torch.from_numpy(np.array(v)) for k, v in synth.make_superpoint_state_dict(d).items()}
+    sd_sg = {k: torch.from_numpy(np.array(v)) for k, v in synth.make_superglue_state_dict(d).items()}
+    m.superpoint.load_state_dict(sd_sp)
+    m.superglue.load_state_dict(sd_sg)
+    return m, cfg, sd_sp, sd_sg
+
+
+def cpu_baseline(wl, cfg, sd_sp, sd_sg, budget_s=20.0, max_pairs=16):
+    """The oracle (port of the reference's PyTorch CPU forward) on this host's cores."""
+    from oracle import matching_ref            # checker code: used here only as the CPU baseline leg
+    try:
+        avail = len(os.sched_getaffinity(0))       # cores this process may run on (cgroup/affinity aware)
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, torch.get_num_threads()))
+    torch.set_num_threads(cores)
+    times = []
+    t_all = time.perf_counter()
+    for i in range(max_pairs + 1):
+        im0, im1 = synth.synth_pair(1000 + i, wl["H"], wl["W"])
+        x0, x1 = torch.from_numpy(im0)[None, None], torch.from_numpy(im1)[None, None]
+        t = time.perf_counter()
+        matching_ref.matching_forward({"image0": x0, "image1": x1}, sd_sp, sd_sg, cfg)
+        dt = time.perf_counter() - t
+        if i > 0:                              # first pair = warm-up
+            times.append(dt)
+        if time.perf_counter() - t_all > budget_s and len(times) >= 3:
+            break
+    med = float(np.median(times))
+    return {"value": round(1.0 / med, 4), "unit": "image-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"median of {len(times)} pairs after 1 warm-up, {wl['H']}x{wl['W']}, torch {torch.__version__} CPU, "
+                      f"{torch.get_num_threads()} threads"}
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs-per-gpu", type=int, default=16, help="pairs per step per GPU (weak scaling)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-pass", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
+
+    wl = WORKLOADS[args.workload]
+    H, W, d, K = wl["H"], wl["W"], wl["d"], wl["K"]
+    B = args.pairs_per_gpu
+    matching, cfg, sd_sp, sd_sg = build_matching(wl, device)
+    # this rank's pairs of the global batch (pair i -> rank i % world), resident in HBM
+    pair_ids = shard.shard_indices(world * B, rank, world)
+    ims = [synth.synth_pair(pid, H, W) for pid in pair_ids]
+    img0 = torch.from_numpy(np.stack([p[0] for p in ims]))[:, None].to(device)
+    img1 = torch.from_numpy(np.stack([p[1] for p in ims]))[:, None].to(device)
+
+    def step():
+        out = matching.match_batch(img0, img1)
+        rec = shard.pack_records(pair_ids, out)
+        return out, shard.gather_records(rec)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def timed(n):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out, rec = step()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, out, rec
+
+    log(f"inputs resident: {B} pairs/GPU, world {world}; warm-up x{args.warmup}")
+    for _ in range(max(args.warmup, 0)):
+        step()
+    torch.cuda.synchronize()
+    log("timed region")
+    dt, out, rec = timed(args.steps)
+    log(f"timed region done: {dt:.3f}s for {args.steps} steps")
+
+    # harness checks: every image yields exactly K keypoints; the gather holds every pair once
+    c0, c1 = out["counts0"].cpu().numpy(), out["counts1"].cpu().numpy()
+    assert (c0 == K).all() and (c1 == K).all(), f"keypoint counts != {K}: {c0} {c1}"
+    assert rec.shape == (world * B, shard.record_width(K))
+    assert sorted(rec[:, 0].long().cpu().tolist()) == list(range(world * B))
+    n_matches = int((out["matches0"] > -1).sum().item())
+    assert n_matches > 0
+
+    total_pairs = world * B * args.steps
+    value = total_pairs / dt
+    line = {
+        "metric": "image-pairs/sec (640x480, 1024 kpts, 30 Sinkhorn iters)" if args.workload == "c3"
+                  else "image-pairs/sec (1280x960, 2048 kpts, 100 Sinkhorn iters)",
+        "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["name"], "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B,
+                   "parallelism": f"pair-sharded x{world}" + (" + RCCL all_gather of match records" if world > 1 else ""),
+                   "weights": "synthetic, BN-calibrated (synth.py seeds 123/456)", "matches_per_pair": round(n_matches / B, 1)},
+    }
+
+    # ---- roofline: second pass of the same K steps with per-launch HIP events on the launch stream
+    if rank == 0 and not args.no_roofline_pass:
+        eng = matching._shared.engine
+        kenc, iters, _ = synth.SG_CONFIGS[d]
+        work = algorithmic_work(B, H, W, d, K, kenc, iters)
+        log("roofline pass (per-launch HIP events)")
+        eng.timing_reset()
+        eng.set_timing(True)
+        for _ in range(args.steps):
+            matching.match_batch(img0, img1)
+        rows = eng.timing_report()
+        eng.set_timing(False)
+        eng.timing_reset()
+        tot_ms = sum(r[2] for r in rows)
+        name, launches, ms = max(rows, key=lambda r: r[2])
+        bound, units = work[name]
+        avg_s = ms / launches * 1e-3
+        if bound == "mfma":
+            achieved, peak, unit = units / avg_s / 1e12, PEAK_MFMA_F32_TFLOPS, "TFLOP/s"
+        else:
+            achieved, peak, unit = units / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
+        line["roofline"] = {"bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+                            "frac": round(achieved / peak, 4), "traffic": None, "kernel": name,
+                            "avg_launch_ms": round(ms / launches, 4), "share_of_gpu_time": round(ms / tot_ms, 4)}
+        # whole-pair view: algorithmic dense FLOPs of the step / measured step time vs the fp32 MFMA peak
+        per_step = {r[0]: r[1] / args.steps for r in rows}          # launches per step
+        flops_step = sum(u * per_step.get(k, 0.0) for k, (bd, u) in work.items() if bd == "mfma")
+        line["roofline"]["pair_mfma_frac"] = round(flops_step / (dt / args.steps) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)
+        line["roofline"]["kernels"] = {r[0]: {"launches": r[1], "ms_per_step": round(r[2] / args.steps, 4)} for r in rows}
+    if world > 1:
+        barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline (oracle on host cores)")
+        line["cpu_baseline"] = cpu_baseline(wl, cfg, sd_sp, sd_sg)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

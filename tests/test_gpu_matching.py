@@ -1,0 +1,97 @@
+"""Matching (SuperPoint x2 + SuperGlue) end to end through the drop-in classes, the fused batch
+path, and the bench/smoke entry points.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _matching(d=128, K=1024):
+    from image_matching_amd.superglue.models.matching_test import Matching
+    cfg = {"superpoint": util.sp_config(d, K), "superglue": util.sg_config(d)}
+    m = Matching(cfg).eval().to("cuda")
+    m.superpoint.load_state_dict(util.sp_sd(d))
+    m.superglue.load_state_dict(util.sg_sd(d))
+    return m
+
+
+def _pair_set(k0, k1, m0):
+    k0, k1, m0 = np.asarray(k0), np.asarray(k1), np.asarray(m0)
+    return {(tuple(k0[i].astype(int)), tuple(k1[j].astype(int))) for i, j in enumerate(m0) if j >= 0}
+
+
+@pytest.mark.parametrize("name", ["c3_pair_s59.npz", "c3_pair_s55.npz"])
+def test_matching_forward_vs_reference_golden(name):
+    g = util.golden(name)
+    H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
+    m = _matching(d, K)
+    x0, x1 = util.pair(seed, H, W)
+    pred = m({"image0": x0.cuda(), "image1": x1.cuda()})
+    # containers / dtypes of the reference
+    assert isinstance(pred["keypoints0"], list) and isinstance(pred["scores0"], tuple) and isinstance(pred["descriptors0"], list)
+    assert pred["keypoints0"][0].shape == (K, 2) and pred["descriptors0"][0].shape == (d, K)
+    assert pred["matches0"].dtype == torch.int64 and pred["matches0"].shape == (1, K)
+    assert pred["matching_scores0"].dtype == torch.float32
+    assert set(pred) == {"keypoints0", "scores0", "descriptors0", "keypoints1", "scores1", "descriptors1",
+                         "matches0", "matches1", "matching_scores0", "matching_scores1"}
+    k0, k1 = pred["keypoints0"][0].cpu().numpy(), pred["keypoints1"][0].cpu().numpy()
+    assert set(map(tuple, k0.astype(int))) == set(map(tuple, g["keypoints0"].astype(int)))
+    assert set(map(tuple, k1.astype(int))) == set(map(tuple, g["keypoints1"].astype(int)))
+    mine = _pair_set(k0, k1, pred["matches0"][0].cpu().numpy())
+    ref = _pair_set(g["keypoints0"], g["keypoints1"], g["matches0"][0])
+    assert mine == ref, f"matched pairs differ: only-ref {len(ref - mine)}, only-mine {len(mine - ref)}"
+    # matches1 consistent with matches0
+    m0, m1 = pred["matches0"][0].cpu().numpy(), pred["matches1"][0].cpu().numpy()
+    i = np.nonzero(m0 > -1)[0]
+    assert np.array_equal(m1[m0[i]], i)
+
+
+def test_fused_batch_equals_per_pair_forward():
+    d, K, H, W = 128, 1024, 480, 640
+    m = _matching(d, K)
+    pairs = [util.pair(s, H, W) for s in (59, 55, 7)]
+    i0 = torch.cat([p[0] for p in pairs]).cuda()
+    i1 = torch.cat([p[1] for p in pairs]).cuda()
+    out = m.match_batch(i0, i1, want_desc=True)
+    torch.cuda.synchronize()
+    assert out["counts0"].tolist() == [K] * 3 and out["counts1"].tolist() == [K] * 3
+    for b, (x0, x1) in enumerate(pairs):
+        pred = m({"image0": x0.cuda(), "image1": x1.cuda()})
+        assert torch.equal(out["keypoints0"][b], pred["keypoints0"][0])
+        assert torch.equal(out["descriptors1"][b].t(), pred["descriptors1"][0])
+        assert torch.equal(out["matches0"][b], pred["matches0"][0])
+        assert torch.equal(out["matching_scores1"][b], pred["matching_scores1"][0])
+
+
+def test_skip_superpoint_when_keypoints_supplied():
+    """matching_test.py:63,66: SuperPoint is skipped when keypoints are already in `data`."""
+    d, K, H, W = 128, 207, 120, 160
+    m = _matching(d, K)
+    x0, x1 = util.pair(12, H, W)
+    full = m({"image0": x0.cuda(), "image1": x1.cuda()})
+    data = {"image0": x0.cuda(), "image1": x1.cuda(),
+            **{k: full[k] for k in ("keypoints0", "scores0", "descriptors0", "keypoints1", "scores1", "descriptors1")}}
+    again = m(data)
+    assert set(again) == {"matches0", "matches1", "matching_scores0", "matching_scores1"}
+    assert torch.equal(again["matches0"], full["matches0"])
+
+
+def test_official_matching_signature():
+    from image_matching_amd import synth
+    from image_matching_amd.superglue.models.matching import Matching
+    cfg = {"superpoint": {"weights_path": None, "descriptor_dim": 256, "max_keypoints": 128},
+           "superglue": util.sg_config(256)}
+    m = Matching(cfg).eval().to("cuda")
+    m.superpoint.load_state_dict(util.to_torch(synth.synth_state_dict(synth.superpoint_official_shapes(256), 77)))
+    m.superglue.load_state_dict(util.sg_sd(256))
+    x0, x1 = util.pair(3, 120, 160)
+    pred = m({"image0": x0.cuda(), "image1": x1.cuda()})
+    assert pred["descriptors0"][0].shape[0] == 256 and pred["matches0"].dtype == torch.int64
+
+
+def test_smoke_entry_point():
+    import __graft_entry__ as ge
+    ge.smoke()

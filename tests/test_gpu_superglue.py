@@ -1,0 +1,146 @@
+"""SuperGlue parity: HIP path vs reference goldens and vs the oracle, keypoints injected so the
+comparison of match indices is bit-exact.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+KEYS = ("keypoints0", "keypoints1", "scores0", "scores1", "descriptors0", "descriptors1")
+
+
+def _engine(d=128, **kw):
+    from image_matching_amd import _lib as L
+    from image_matching_amd.engine import Engine
+    eng = Engine(util.sp_config(d, 1024), util.sg_config(d, **kw), "cuda")
+    return eng, L
+
+
+def _run(eng, t, shp, n0=None, n1=None):
+    out = eng.superglue(t["keypoints0"], t["scores0"], t["descriptors0"], shp,
+                        t["keypoints1"], t["scores1"], t["descriptors1"], shp, n0, n1)
+    torch.cuda.synchronize()
+    return [o.cpu().numpy() for o in out]
+
+
+def test_small_dense_and_matches_vs_reference_golden():
+    g = util.golden("sg_small.npz")
+    eng, L = _engine()
+    sd = util.sg_sd(128)
+    eng.load_state_dict(L.NET_SUPERGLUE, sd)
+    eng.set_debug(True)
+    t = {k: torch.from_numpy(g[k]).cuda() for k in KEYS}
+    m0, m1, ms0, ms1 = _run(eng, t, (1, 1, 120, 160))
+    N0, N1 = g["keypoints0"].shape[1], g["keypoints1"].shape[1]
+    N0p = (N0 + 31) // 32 * 32
+
+    def rows(a):
+        return a[:N0].T[None], a[N0p:N0p + N1].T[None]
+    for tap, (r0, r1) in (("kenc", (g["kenc0"], g["kenc1"])), ("gnn0", (g["tap0_0"], g["tap0_1"])),
+                          ("gnn1", (g["tap1_0"], g["tap1_1"])), ("gnn17", (g["gnn0"], g["gnn1"]))):
+        a0, a1 = rows(eng.fetch(tap))
+        util.assert_close(a0, r0, tap + " side0", scale_atol=True)
+        util.assert_close(a1, r1, tap + " side1", scale_atol=True)
+    S = eng.fetch("scores_in")[:, :N0, :N1]
+    util.assert_close(S, g["scores_in"], "scores_in", scale_atol=True)
+    u, v = eng.fetch("u")[0], eng.fetch("v")[0]
+    Z = np.full((N0 + 1, N1 + 1), float(sd["bin_score"]), dtype=np.float32)
+    Z[:N0, :N1] = S[0]
+    Z = (Z + u[:N0 + 1, None]) + v[None, :N1 + 1] + np.log(np.float32(N0 + N1))
+    util.assert_close(Z[None], g["Z"], "Z (optimal transport)", scale_atol=True)
+    # Appendix A.4: exp(Z) rows sum to 1 (dustbin row to N), after `iters` iterations columns nearly so
+    P = np.exp(Z.astype(np.float64))
+    np.testing.assert_allclose(P[:N0].sum(1), 1.0, rtol=0, atol=0.35)
+    np.testing.assert_allclose(P[:, :N1].sum(0), 1.0, rtol=1e-4)
+    assert np.array_equal(m0, g["matches0"]) and np.array_equal(m1, g["matches1"]), "match indices must be bit-exact"
+    util.assert_close(ms0, g["matching_scores0"], "matching_scores0")
+    util.assert_close(ms1, g["matching_scores1"], "matching_scores1")
+    assert m0.dtype == np.int64 and ms0.dtype == np.float32
+
+
+def test_ragged_counts_masked_counts_and_empty():
+    g, gs = util.golden("sg_ragged.npz"), util.golden("sg_small.npz")
+    eng, L = _engine()
+    eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(128))
+    n0, n1 = int(g["n0"]), int(g["n1"])
+    full = {k: torch.from_numpy(gs[k]).cuda() for k in KEYS}
+    cut = dict(full)
+    cut["keypoints0"], cut["scores0"], cut["descriptors0"] = full["keypoints0"][:, :n0], full["scores0"][:, :n0], full["descriptors0"][:, :, :n0]
+    cut["keypoints1"], cut["scores1"], cut["descriptors1"] = full["keypoints1"][:, :n1], full["scores1"][:, :n1], full["descriptors1"][:, :, :n1]
+    m0, m1, ms0, ms1 = _run(eng, cut, (1, 1, 120, 160))       # non-contiguous descriptor views: strides honoured
+    assert np.array_equal(m0, g["matches0"]) and np.array_equal(m1, g["matches1"])
+    util.assert_close(ms0, g["matching_scores0"], "mscores0 ragged")
+    # same result through device-side counts on the padded (full) buffers; tail is -1 / 0
+    c0 = torch.tensor([n0], dtype=torch.int32, device="cuda")
+    c1 = torch.tensor([n1], dtype=torch.int32, device="cuda")
+    p0, p1, ps0, ps1 = _run(eng, full, (1, 1, 120, 160), c0, c1)
+    assert np.array_equal(p0[:, :n0], g["matches0"]) and np.array_equal(p1[:, :n1], g["matches1"])
+    assert (p0[:, n0:] == -1).all() and (p1[:, n1:] == -1).all() and (ps0[:, n0:] == 0).all()
+    # zero count on one side -> all -1 (device-side early-out)
+    z = torch.tensor([0], dtype=torch.int32, device="cuda")
+    e0, e1, es0, es1 = _run(eng, full, (1, 1, 120, 160), c0, z)
+    assert (e0 == -1).all() and (e1 == -1).all() and (es0 == 0).all() and (es1 == 0).all()
+
+
+def test_empty_set_dtype_matches_reference():
+    from image_matching_amd.superglue.models.superglue_test import SuperGlue
+    g = util.golden("sg_ragged.npz")
+    sg = SuperGlue(util.sg_config(128)).eval().to("cuda")
+    data = {"keypoints0": torch.zeros(1, 150, 2).cuda(), "keypoints1": torch.zeros(1, 0, 2).cuda(),
+            "scores0": torch.zeros(1, 150).cuda(), "scores1": torch.zeros(1, 0).cuda(),
+            "descriptors0": torch.zeros(1, 128, 150).cuda(), "descriptors1": torch.zeros(1, 128, 0).cuda(),
+            "image0": torch.zeros(1, 1, 120, 160), "image1": torch.zeros(1, 1, 120, 160)}
+    out = sg(data)
+    assert str(out["matches0"].dtype) == str(g["empty_dtype"]) == "torch.int32"
+    assert np.array_equal(out["matches0"].cpu().numpy(), g["empty_matches0"])
+    assert out["matches1"].shape == (1, 0) and out["matching_scores0"].shape == (1, 150)
+
+
+def _oracle_pair_inputs(seed, H, W, d, K):
+    from oracle import superpoint_ref
+    sd = util.sp_sd(d)
+    x0, x1 = util.pair(seed, H, W)
+    o0 = superpoint_ref.superpoint_forward(x0, sd, util.sp_config(d, K))
+    o1 = superpoint_ref.superpoint_forward(x1, sd, util.sp_config(d, K))
+    return {"keypoints0": o0["keypoints"][0][None], "keypoints1": o1["keypoints"][0][None],
+            "scores0": o0["scores"][0][None], "scores1": o1["scores"][0][None],
+            "descriptors0": o0["descriptors"][0][None], "descriptors1": o1["descriptors"][0][None]}
+
+
+@pytest.mark.parametrize("name", ["c3_pair_s59.npz", "c3_pair_s55.npz", "c5_pair_s19.npz"])
+def test_full_size_matches_bit_exact_vs_reference_golden(name):
+    """C3 (N=1024, d=128, 30 iters) and C5 (N=2048, d=256, 100 iters): oracle keypoints in,
+    match indices out identical to the reference's."""
+    g = util.golden(name)
+    H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
+    data = _oracle_pair_inputs(seed, H, W, d, K)
+    assert np.array_equal(data["keypoints0"][0].numpy(), g["keypoints0"])     # the oracle is the reference here
+    eng, L = _engine(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(d))
+    t = {k: v.cuda() for k, v in data.items()}
+    m0, m1, ms0, ms1 = _run(eng, t, (1, 1, H, W))
+    S = eng.fetch("scores_in")[0]
+    util.assert_close(S[::8, ::8], g["scores_in_sub"], "scores_in (subsampled)", scale_atol=True)
+    nbad0, nbad1 = int((m0 != g["matches0"]).sum()), int((m1 != g["matches1"]).sum())
+    assert nbad0 == 0 and nbad1 == 0, f"{nbad0}/{nbad1} match indices differ (fixture decision margin {float(g['margin_decision_gap']):.2e})"
+    util.assert_close(ms0, g["matching_scores0"], "matching_scores0")
+    util.assert_close(ms1, g["matching_scores1"], "matching_scores1")
+    # structural properties of the output
+    i = np.nonzero(m0[0] > -1)[0]
+    assert np.array_equal(m1[0][m0[0][i]], i), "matches must be mutual"
+    assert (ms0[0][i] > eng.cfg.match_threshold).all()
+
+
+def test_batched_pairs_equal_single_pair_runs():
+    d, K, H, W = 128, 1024, 480, 640
+    eng, L = _engine(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(d))
+    a, b = _oracle_pair_inputs(59, H, W, d, K), _oracle_pair_inputs(55, H, W, d, K)
+    both = {k: torch.cat([a[k], b[k]]).cuda() for k in KEYS}
+    mb = _run(eng, both, (1, 1, H, W))
+    ma = _run(eng, {k: v.cuda() for k, v in a.items()}, (1, 1, H, W))
+    mbb = _run(eng, {k: v.cuda() for k, v in b.items()}, (1, 1, H, W))
+    for i in range(4):
+        assert np.array_equal(mb[i][0], ma[i][0]) and np.array_equal(mb[i][1], mbb[i][0]), \
+            "batched pairs must be bit-identical to single-pair runs"

@@ -1,0 +1,159 @@
+"""SuperPoint parity: HIP path (through the C ABI / ctypes) vs golden vectors of the reference and
+vs the oracle on the same seeded inputs.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(d=128, K=1024, variant=0, align_corners=None, **kw):
+    from image_matching_amd import _lib as L
+    from image_matching_amd.engine import Engine
+    eng = Engine(util.sp_config(d, K, **kw), util.sg_config(d), "cuda", variant, align_corners)
+    return eng, L
+
+
+def _nchw(a):
+    return np.transpose(a, (0, 3, 1, 2))
+
+
+def _check_against(eng, x, ref_kp, ref_sc, ref_desc, exact_order=True):
+    kpts, scores, desc, n = eng.superpoint(x.cuda())
+    for b in range(x.shape[0]):
+        km, sm, dm = kpts[b, :n[b]].cpu(), scores[b, :n[b]].cpu(), desc[b, :n[b]].t().cpu()
+        kr, sr, dr = ref_kp[b], ref_sc[b], ref_desc[b]
+        assert n[b] == len(kr), f"image {b}: {n[b]} keypoints vs reference {len(kr)}"
+        if exact_order:
+            assert np.array_equal(km.numpy(), np.asarray(kr)), f"image {b}: keypoints / order differ"
+            util.assert_close(sm, sr, "scores")
+            util.assert_close(dm, dr, "descriptors")
+        else:   # near-tied scores may legally swap under top-k: compare as sets, order canonicalised
+            a, r = util.canon_keypoints(km, sm, dm), util.canon_keypoints(kr, sr, dr)
+            assert np.array_equal(a[0], r[0]), f"image {b}: keypoint sets differ"
+            util.assert_close(a[1], r[1], "scores")
+            util.assert_close(a[2], r[2], "descriptors")
+    return kpts, scores, desc, n
+
+
+@pytest.mark.parametrize("name", ["sp_small.npz", "sp_ragged.npz"])
+def test_dense_stages_and_keypoints_vs_reference_golden(name):
+    g = util.golden(name)
+    H, W, seed, K = int(g["H"]), int(g["W"]), int(g["seed"]), int(g["max_keypoints"])
+    eng, L = _engine(128, K)
+    eng.load_state_dict(L.NET_SUPERPOINT, util.sp_sd(128))
+    x = torch.cat(util.pair(seed, H, W))
+    _check_against(eng, x, [g["keypoints0"], g["keypoints1"]], [g["scores0"], g["scores1"]],
+                   [g["descriptors0"], g["descriptors1"]])
+    util.assert_close(_nchw(eng.fetch("x4")), g["x4"], "x4")
+    a3_ref = torch.nn.functional.max_pool2d(torch.from_numpy(g["x3"]), 2).numpy()     # golden x3 holds channels ::2
+    util.assert_close(_nchw(eng.fetch("a3"))[:, ::2], a3_ref, "pool(x3)")
+    util.assert_close(_nchw(eng.fetch("semi")), g["semi"], "semi")
+    raw = _nchw(eng.fetch("desc_raw"))
+    util.assert_close(raw / np.linalg.norm(raw, axis=1, keepdims=True), g["desc"], "dense descriptors")
+    util.assert_close(eng.fetch("score_map"), g["score_map"], "score map", atol=1e-5)
+    # NMS is compare-only: bit-exact given the reference's own pre-NMS map
+    out = eng.op_nms(torch.from_numpy(g["score_map"]), 4).cpu().numpy()
+    assert np.array_equal(out, g["nms"]), "simple_nms not bit-exact on the reference score map"
+    # and the mask of the end-to-end map selects the same pixels
+    assert np.array_equal(eng.fetch("nms") > 0, g["nms"] > 0)
+
+
+@pytest.mark.parametrize("name", ["c3_pair_s59.npz", "c3_pair_s55.npz"])
+def test_c3_full_size_vs_reference_golden(name):
+    g = util.golden(name)
+    H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
+    eng, L = _engine(d, K)
+    eng.load_state_dict(L.NET_SUPERPOINT, util.sp_sd(d))
+    x = torch.cat(util.pair(seed, H, W))
+    kpts, scores, desc, n = eng.superpoint(x.cuda())
+    assert n == [K, K]
+    for b in range(2):
+        km, sm = kpts[b].cpu().numpy(), scores[b].cpu().numpy()
+        a = util.canon_keypoints(km, sm, desc[b].t().cpu().numpy())
+        r = util.canon_keypoints(g[f"keypoints{b}"], g[f"scores{b}"])
+        assert np.array_equal(a[0], r[0]), "keypoint set differs from the reference"
+        util.assert_close(a[1], r[1], "scores")
+        assert np.all(np.diff(sm) <= 0), "top-k output must be sorted by descending score"
+        # descriptors: golden holds every 16th keypoint in reference order
+        idx = {tuple(k): i for i, k in enumerate(km.astype(int))}
+        sel = [idx[tuple(k)] for k in g[f"keypoints{b}"][::16].astype(int)]
+        util.assert_close(desc[b].cpu().numpy()[sel].T, g[f"descriptors{b}_sub"], "descriptors")
+
+
+def test_c3_properties_and_batch_consistency():
+    d, K, H, W = 128, 1024, 480, 640
+    eng, L = _engine(d, K)
+    eng.load_state_dict(L.NET_SUPERPOINT, util.sp_sd(d))
+    xs = [util.pair(s, H, W)[0] for s in (3, 4)]
+    x = torch.cat([xs[0], xs[1], xs[0]]).cuda()
+    kpts, scores, desc, n = eng.superpoint(x)
+    assert n == [K, K, K]
+    k, s, dsc = kpts.cpu().numpy(), scores.cpu().numpy(), desc.cpu().numpy()
+    assert np.array_equal(k[0], k[2]) and np.array_equal(s[0], s[2]) and np.array_equal(dsc[0], dsc[2]), \
+        "same image in two batch slots must give bit-identical results"
+    single = eng.superpoint(xs[1].cuda())
+    assert np.array_equal(single[0][0].cpu().numpy(), k[1]) and np.array_equal(single[2][0].cpu().numpy(), dsc[1]), \
+        "batched and single-image results must be bit-identical"
+    for b in range(2):
+        assert (k[b][:, 0] >= 4).all() and (k[b][:, 0] < W - 4).all() and (k[b][:, 1] >= 4).all() and (k[b][:, 1] < H - 4).all()
+        assert (s[b] > 0.005).all() and np.all(np.diff(s[b]) <= 0)
+        np.testing.assert_allclose(np.linalg.norm(dsc[b], axis=1), 1.0, atol=1e-5)
+        # NMS property: no two keypoints with distinct scores closer than the radius (Chebyshev)
+        kk = k[b]
+        dist = np.abs(kk[:, None, :] - kk[None, :, :]).max(-1)
+        np.fill_diagonal(dist, 99)
+        close = np.argwhere(dist <= 4)
+        assert all(s[b][i] == s[b][j] for i, j in close), "two keypoints inside one NMS window with different scores"
+
+
+def test_align_corners_true_mode_vs_oracle():
+    from oracle import superpoint_ref
+    eng, L = _engine(128, 207, align_corners=True)
+    sd = util.sp_sd(128)
+    eng.load_state_dict(L.NET_SUPERPOINT, sd)
+    x = util.pair(12, 120, 160)[0]
+    ref = superpoint_ref.superpoint_forward(x, sd, util.sp_config(128, 207), align_corners=True)
+    ref_f = superpoint_ref.superpoint_forward(x, sd, util.sp_config(128, 207), align_corners=False)
+    assert (ref["descriptors"][0] - ref_f["descriptors"][0]).abs().max() > 0.05
+    _check_against(eng, x, ref["keypoints"], ref["scores"], ref["descriptors"])
+
+
+def test_official_variant_vs_oracle():
+    from image_matching_amd import synth
+    from oracle import superpoint_ref
+    d = 256
+    sd = util.to_torch(synth.synth_state_dict(synth.superpoint_official_shapes(d), 77))
+    eng, L = _engine(d, 300, variant=1)
+    eng.load_state_dict(L.NET_SUPERPOINT, sd)
+    x = util.pair(5, 128, 192)[0]
+    ref = superpoint_ref.superpoint_forward(x, sd, util.sp_config(d, 300), variant="official", return_dense=True)
+    kpts, scores, desc, n = eng.superpoint(x.cuda())
+    util.assert_close(_nchw(eng.fetch("x4")), ref["x4"], "x4 (official)")
+    util.assert_close(_nchw(eng.fetch("semi")), ref["semi"], "semi (official)")
+    _check_against(eng, x, ref["keypoints"], ref["scores"], ref["descriptors"], exact_order=False)
+
+
+@pytest.mark.parametrize("K", [-1, 50])
+def test_constant_image_all_ties(K):
+    """A constant image gives a constant score map: every pixel ties as a 9x9 maximum and the
+    reference keeps them all (equality test, no tie-break)."""
+    from oracle import superpoint_ref
+    sd = util.sp_sd(128)
+    eng, L = _engine(128, K)
+    eng.load_state_dict(L.NET_SUPERPOINT, sd)
+    x = torch.full((1, 1, 64, 96), 0.25)
+    ref = superpoint_ref.superpoint_forward(x, sd, util.sp_config(128, K), return_dense=True)
+    kpts, scores, desc, n = eng.superpoint(x.cuda())
+    assert n[0] == len(ref["scores"][0])
+    if K < 0:
+        assert np.array_equal(kpts[0].cpu().numpy(), ref["keypoints"][0].numpy())
+
+
+def test_empty_result_when_threshold_is_high():
+    eng, L = _engine(128, 100, keypoint_threshold=2.0)
+    eng.load_state_dict(L.NET_SUPERPOINT, util.sp_sd(128))
+    kpts, scores, desc, n = eng.superpoint(util.pair(1, 64, 64)[0].cuda())
+    assert n == [0] and kpts.shape == (1, 0, 2) and desc.shape == (1, 0, 128)

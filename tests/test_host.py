@@ -1,0 +1,124 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports what include/imx.h
+declares, config plumbing, state-dict key contracts, portable synthetic data, sharding/records."""
+import ctypes
+import os
+import re
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from image_matching_amd import _lib, shard, synth
+from tests import util
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load_library()
+    header = open(os.path.join(ROOT, "include", "imx.h")).read()
+    declared = set(re.findall(r"\b(imx_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"libimx.so does not export {name}"
+    assert set(_lib.EXPORTS) == declared
+    assert b"gfx950" in lib.imx_version()
+
+
+def test_config_struct_matches_header_layout():
+    # 7 SuperPoint words + 1 + 64 + 1 + 8 + 2 = 83 32-bit words
+    assert ctypes.sizeof(_lib.ImxConfig) == 4 * (7 + 1 + _lib.IMX_MAX_GNN_LAYERS + 1 + _lib.IMX_MAX_KENC + 2)
+
+
+def test_no_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from image_matching_amd.engine import Engine, ImxError
+    with pytest.raises(ImxError, match="no CPU fallback"):
+        Engine({}, {}, "cuda")
+    lib = _lib.load_library()
+    h = ctypes.c_void_p()
+    cfg = _lib.ImxConfig()
+    cfg.descriptor_dim, cfg.kenc_n, cfg.num_gnn_layers = 128, 3, 18
+    assert lib.imx_create(0, ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert b"no HIP device" in lib.imx_last_error(None)
+
+
+def test_create_rejects_bad_config():
+    lib = _lib.load_library()
+    h = ctypes.c_void_p()
+    cfg = _lib.ImxConfig()
+    cfg.descriptor_dim, cfg.kenc_n, cfg.num_gnn_layers = 100, 3, 18
+    assert lib.imx_create(0, ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert b"descriptor_dim" in lib.imx_last_error(None)
+
+
+def test_dropin_classes_config_and_state_dict_contract():
+    from image_matching_amd.superglue.models.matching_test import Matching
+    cfg = {"superpoint": util.sp_config(128, 1024), "superglue": util.sg_config(128)}
+    m = Matching(cfg).eval().to("cuda")                      # chainable like superpoint_glue_test.py:69
+    assert m.superpoint.config["keypoint_threshold"] == 0.005 and m.superglue.config["match_threshold"] == 0.1
+    assert m.superpoint.config["remove_borders"] == 4        # default merged in
+    assert m.superglue.config["GNN_layers"] == ["self", "cross"] * 9
+    sp_keys, sg_keys = set(m.superpoint.state_dict()), set(m.superglue.state_dict())
+    assert "inc.conv.conv.0.weight" in sp_keys and "down3.mpconv.1.conv.4.running_var" in sp_keys and "bnDb.bias" in sp_keys
+    assert "bin_score" in sg_keys and "gnn.layers.17.attn.proj.2.weight" in sg_keys and "kenc.encoder.9.bias" in sg_keys
+    n_sp = sum(v.numel() for k, v in m.superpoint.state_dict().items() if "running" not in k and "tracked" not in k)
+    n_sg = sum(v.numel() for k, v in m.superglue.state_dict().items() if "running" not in k and "tracked" not in k)
+    assert (n_sp, n_sg) == (1270915, 3018497)                # SURVEY §8b parameter counts at d=128
+    with pytest.raises(RuntimeError, match="Missing key"):
+        m.superpoint.load_state_dict({"convPa.weight": torch.zeros(256, 128, 3, 3)})
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        sd = m.superglue.state_dict()
+        sd["final_proj.weight"] = torch.zeros(64, 128, 1)
+        m.superglue.load_state_dict(sd)
+    with pytest.raises(KeyError):                            # reference quirk: no 'weights' default (superpoint_test.py:87)
+        from image_matching_amd.superpoint.models.superpoint_test import SuperPoint
+        SuperPoint({})
+    with pytest.raises(RuntimeError, match="inference-only"):
+        m.train()
+
+
+def test_module_prefix_checkpoint_loading(tmp_path):
+    """superpoint_test.py:87-99: {'model_state_dict': ...} with 'module.' prefixes from DataParallel."""
+    from image_matching_amd.superpoint.models.superpoint_test import SuperPoint
+    sd = util.sp_sd(128)
+    path = tmp_path / "ckpt.pth.tar"
+    torch.save({"n_iter": 1, "model_state_dict": {"module." + k: v for k, v in sd.items()}}, path)
+    sp = SuperPoint(util.sp_config(128, 10, weights=str(path)))
+    got = sp.state_dict()
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+
+
+def test_synth_is_portable_and_stable():
+    """Bit-identical synthetic data on any machine: CRCs recorded in the build container."""
+    im0, im1 = synth.synth_pair(59, 480, 640)
+    sd = synth.make_superpoint_state_dict(128)
+    sg = synth.make_superglue_state_dict(128)
+    crcs = (zlib.crc32(im0.tobytes()), zlib.crc32(im1.tobytes()),
+            zlib.crc32(sd["down2.mpconv.1.conv.3.weight"].tobytes()), zlib.crc32(sd["bnPb.running_var"].tobytes()),
+            zlib.crc32(sg["gnn.layers.7.mlp.0.weight"].tobytes()))
+    assert crcs == EXPECTED_CRCS, crcs
+    assert im0.dtype == np.float32 and 0.0 <= im0.min() and im0.max() <= 1.0
+
+
+EXPECTED_CRCS = (3817531681, 2015118848, 543481260, 1157619473, 3903334769)
+
+
+def test_shard_and_records_roundtrip():
+    assert shard.shard_indices(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((shard.shard_indices(512, r, 8) for r in range(8)), [])) == list(range(512))
+    B, K = 3, 16
+    g = torch.Generator().manual_seed(0)
+    out = {"keypoints0": torch.rand(B, K, 2, generator=g) * 600, "keypoints1": torch.rand(B, K, 2, generator=g) * 600,
+           "counts0": torch.tensor([16, 12, 0], dtype=torch.int32), "counts1": torch.tensor([16, 16, 5], dtype=torch.int32),
+           "matches0": torch.randint(-1, K, (B, K), generator=g), "matches1": torch.randint(-1, K, (B, K), generator=g),
+           "matching_scores0": torch.rand(B, K, generator=g), "matching_scores1": torch.rand(B, K, generator=g)}
+    rec = shard.pack_records([7, 8, 9], out)
+    assert rec.shape == (B, shard.record_width(K))
+    back = shard.unpack_records(rec)
+    assert back["pair_id"].tolist() == [7, 8, 9]
+    for k in out:
+        assert torch.equal(back[k], out[k]), k
+    assert shard.gather_records(rec) is rec                   # world_size 1: no process group needed

@@ -43,11 +43,17 @@ def sg_config(d=128, **kw):
             "sinkhorn_iterations": iters, "match_threshold": thr, **kw}
 
 
-def assert_close(a, b, what, atol=ATOL, rtol=RTOL):
+def assert_close(a, b, what, atol=ATOL, rtol=RTOL, scale_atol=False):
+    """|a-b| <= atol + rtol*|b|.  scale_atol: atol is taken relative to max|b| — for quantities that
+    are long fp32 reductions of O(max|b|) terms (GNN features after 18 layers, score matrix, Z), whose
+    rounding noise is proportional to the operand scale, not to the (possibly cancelling) result:
+    the reference's own fp32-vs-fp64 deviation on Z is 5e-6*max|Z| (tests/golden/make_golden.py)."""
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
     err = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    if scale_atol:
+        atol = atol * max(1.0, float(np.abs(b).max()))
     tol = atol + rtol * np.abs(b.astype(np.float64))
     bad = err > tol
     assert not bad.any(), (f"{what}: {bad.sum()} / {bad.size} elements out of tolerance; max err {err.max():.3e} "
