@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
 #pragma unroll
     for (int t = 0; t < HD / 2; t += 4) {
       float4 v = *reinterpret_cast<const float4*>(qp + t);
-      q[t] = v.x; q[t + 1] = v.y; q[t + 2] = v.z; q[t + 3] = v.w;
+      // fold 1/sqrt(HD) and log2(e) into Q: scores come out of the MFMA in the log2 domain
+      q[t] = v.x * scale; q[t + 1] = v.y * scale; q[t + 2] = v.z * scale; q[t + 3] = v.w * scale;
     }
   } else {
 #pragma unroll
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
 
   for (int kt = 0; kt < nt; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nt) { IMX_GLOAD(kt + 1) }
+    { IMX_GLOAD(kt + 1 < nt ? kt + 1 : kt) }   // branch-free prefetch (last tile re-fetches itself)
     if (wave_active) {
       // ---- S^T = K . Q^T
       f32x16 S;
@@ -102,23 +103,28 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
       const float* kp = &Kt[buf][l31 * KS + hi * (HD / 2)];
 #pragma unroll
       for (int t = 0; t < HD / 2; ++t) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[t], q[t], S, 0, 0, 0);
-      // ---- online softmax over this tile's 32 keys (16 here, 16 in lane^32)
+      // ---- online softmax over this tile's 32 keys (16 here, 16 in lane^32), log2 domain:
+      //      p = 2^(s2 - m2) = e^(s - m); |abs err| of the one-multiply form <= 6e-8*max|x e^x| ~ 2e-8
       float mx = -INFINITY;
+      if (kt * 32 + 32 <= nk) {           // full tile (block-uniform): no key masking
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float s = S[r] * scale;
-        s = key < nk ? s : -INFINITY;
-        S[r] = s;
-        mx = fmaxf(mx, s);
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const float s = key < nk ? S[r] : -INFINITY;
+          S[r] = s;
+          mx = fmaxf(mx, s);
+        }
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float mn = fmaxf(m, mx);
-      const float alpha = expf(m - mn);      // m = -inf on the first tile -> 0
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);      // m = -inf on the first tile -> 0
       float rs = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float pr = expf(S[r] - mn);
+        const float pr = __builtin_amdgcn_exp2f(S[r] - mn);
         S[r] = pr;
         rs += pr;
       }
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
         }
       }
     }
-    if (kt + 1 < nt) { IMX_LSTORE(buf ^ 1) }
+    { IMX_LSTORE(buf ^ 1) }
     __syncthreads();
   }
 
@@ -163,7 +169,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   const int hd = a.d / a.heads;
   const int nmax = a.N0p > a.N1p ? a.N0p : a.N1p;
   dim3 grid((unsigned)((nmax + 127) / 128), (unsigned)a.heads, (unsigned)(2 * a.B));
-  const float scale = (float)(1.0 / sqrt((double)hd));
+  const float scale = (float)(1.4426950408889634 / sqrt((double)hd));   // log2(e)/sqrt(HD)
   if (hd == 32) hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(256), 0, s, a, scale);
   else if (hd == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, s, a, scale);
   else return hipErrorInvalidValue;

@@ -21,13 +21,14 @@ constexpr int BM = 128, CK = 32, SA = CK + 1;
 template <int NT>
 __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
   constexpr int NB = NT / 32;
-  __shared__ __attribute__((aligned(16))) float smem[BM * SA + CK * NT];
-  float* a_tile = smem;
-  float* w_tile = smem + BM * SA;   // BM*SA = 4224 floats, 16-B aligned
+  constexpr int A_IT = BM * (CK / 4) / 256;   // 4 float4 per thread
+  constexpr int W_IT = CK * NT / 4 / 256;     // 2 or 4
+  constexpr int BUF = BM * SA + CK * NT;      // floats per stage (A tile then W tile; 4224 is 16-B aligned)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = blockIdx.x * BM, n0 = blockIdx.y * NT;
-  const int K = p.K0 + p.K1;
+  const int K = p.K0 + p.K1, nchunk = K / CK;
 
   f32x16 acc[NB];
 #pragma unroll
@@ -35,23 +36,43 @@ __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
-  for (int c0 = 0; c0 < K; c0 += CK) {
-    const float* src; int lda, cc;
-    if (c0 < p.K0) { src = p.a0; lda = p.lda0; cc = c0; } else { src = p.a1; lda = p.lda1; cc = c0 - p.K0; }
-    __syncthreads();
-    for (int e = tid; e < BM * (CK / 4); e += 256) {
-      int row = e / (CK / 4), v4 = e % (CK / 4);
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r0 + row < p.M) val = *reinterpret_cast<const float4*>(src + (size_t)(r0 + row) * lda + cc + 4 * v4);
-      float* d = a_tile + row * SA + 4 * v4;
-      d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
-    }
-    for (int e = tid; e < CK * NT / 4; e += 256) {
-      int idx = e * 4, k = idx / NT, col = idx % NT;
-      *reinterpret_cast<float4*>(w_tile + idx) =
-          *reinterpret_cast<const float4*>(p.w + (size_t)(c0 + k) * p.Npad + n0 + col);
-    }
-    __syncthreads();
+  // register-staged double buffering: chunk c+1 is fetched from L2/HBM while chunk c feeds the MFMAs
+  float4 areg[A_IT], wreg[W_IT];
+#define IMX_GLOAD(c0_)                                                                              \
+  {                                                                                                 \
+    const float* src; int lda, cc;                                                                  \
+    if ((c0_) < p.K0) { src = p.a0; lda = p.lda0; cc = (c0_); } else { src = p.a1; lda = p.lda1; cc = (c0_) - p.K0; } \
+    _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                           \
+      const int e = tid + it * 256, row = e / (CK / 4), v4 = e % (CK / 4);                          \
+      areg[it] = (r0 + row < p.M) ? *reinterpret_cast<const float4*>(src + (size_t)(r0 + row) * lda + cc + 4 * v4) \
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);                                \
+    }                                                                                               \
+    _Pragma("unroll") for (int it = 0; it < W_IT; ++it) {                                           \
+      const int idx = (tid + it * 256) * 4, k = idx / NT, col = idx % NT;                           \
+      wreg[it] = *reinterpret_cast<const float4*>(p.w + (size_t)((c0_) + k) * p.Npad + n0 + col);   \
+    }                                                                                               \
+  }
+#define IMX_LSTORE(buf_)                                                                            \
+  {                                                                                                 \
+    float* at = smem + (buf_) * BUF;                                                                \
+    float* wt = at + BM * SA;                                                                       \
+    _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                           \
+      const int e = tid + it * 256, row = e / (CK / 4), v4 = e % (CK / 4);                          \
+      float* d = at + row * SA + 4 * v4;                                                            \
+      d[0] = areg[it].x; d[1] = areg[it].y; d[2] = areg[it].z; d[3] = areg[it].w;                   \
+    }                                                                                               \
+    _Pragma("unroll") for (int it = 0; it < W_IT; ++it)                                             \
+      *reinterpret_cast<float4*>(wt + (tid + it * 256) * 4) = wreg[it];                             \
+  }
+
+  IMX_GLOAD(0)
+  IMX_LSTORE(0)
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    // branch-free prefetch: the last iteration re-fetches its own chunk into the idle buffer (harmless)
+    IMX_GLOAD((c + 1 < nchunk ? c + 1 : c) * CK)
+    const float* a_tile = smem + (c & 1) * BUF;
+    const float* w_tile = a_tile + BM * SA;
     const float* ap = a_tile + (32 * wave + (lane & 31)) * SA + (lane >> 5);
     const float* bp = w_tile + (lane >> 5) * NT + (lane & 31);
 #pragma unroll
@@ -61,7 +82,11 @@ __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
       for (int n = 0; n < NB; ++n)
         acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[2 * kk * NT + n * 32], acc[n], 0, 0, 0);
     }
+    IMX_LSTORE((c + 1) & 1)
+    __syncthreads();
   }
+#undef IMX_GLOAD
+#undef IMX_LSTORE
 
   const int hi = lane >> 5;
 #pragma unroll
@@ -141,9 +166,9 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.K0 % CK || a.K1 % CK || a.Npad % 64 || a.M <= 0) return hipErrorInvalidValue;
   const unsigned gm = (unsigned)((a.M + BM - 1) / BM);
   if (a.Npad % 128 == 0) {
-    hipLaunchKernelGGL(gemm_mfma<128>, dim3(gm, a.Npad / 128), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gemm_mfma<128>, dim3(gm, a.Npad / 128), dim3(256), 2 * (BM * SA + CK * 128) * sizeof(float), s, a);
   } else {
-    hipLaunchKernelGGL(gemm_mfma<64>, dim3(gm, a.Npad / 64), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gemm_mfma<64>, dim3(gm, a.Npad / 64), dim3(256), 2 * (BM * SA + CK * 64) * sizeof(float), s, a);
   }
   return hipGetLastError();
 }

@@ -136,6 +136,127 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ scor
   }
 }
 
+// Fast path for radius 1..4: 1024 threads, every max-pool separable and IN PLACE through registers.
+// A thread owns a strip of 8 consecutive outputs along the pass direction: it loads the 8+2R inputs
+// into registers (lanes run across the other axis with an odd pitch: conflict-free), the block
+// synchronises, and the strip is written back.  LDS traffic per element and pool: (8+2R)/8 reads +
+// 1 write per pass instead of 2R+1 reads.  Suppressed pixels are encoded as -1 in the
+// supp_scores copy (scores are >= 0): for an un-suppressed pixel the window maximum is its own
+// score either way, so `supp_scores == max_pool(supp_scores) & ~supp` is unchanged.
+template <int R>
+__global__ __launch_bounds__(1024) void nms_fast_kernel(const float* __restrict__ scores, float* __restrict__ out,
+                                                        int H, int W) {
+  constexpr int T = 32, HALO = 5 * R, SIDE = ((T + 2 * HALO + 7) / 8) * 8, PADN = SIDE + 2 * R;
+  constexpr int PITCH = PADN | 1, ST = 8, NS = SIDE / ST, NV = ST + 2 * R, N = PADN * PITCH;
+  extern __shared__ float sm[];
+  float* S = sm;          // scores, -inf outside the image and in the margin
+  float* M = S + N;       // max_mask as 0/1
+  float* X = M + N;       // supp_scores (-1 where suppressed)
+  float* P = X + N;       // pooling scratch (in place)
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, gy0 = blockIdx.y * T - HALO, gx0 = blockIdx.x * T - HALO;
+  const float* img = scores + (size_t)b * H * W;
+  const float NEG = -INFINITY;
+
+  for (int e = tid; e < N; e += 1024) {
+    const int py = e / PITCH, px = e - py * PITCH;
+    const int gy = gy0 + py - R, gx = gx0 + px - R;
+    const bool in_region = py >= R && py < R + SIDE && px >= R && px < R + SIDE;
+    const float v = (in_region && gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : NEG;
+    S[e] = v;
+    P[e] = v;
+    X[e] = NEG;
+    M[e] = 0.f;
+  }
+  __syncthreads();
+
+  const bool active = tid < SIDE * NS;
+  const int lane_i = tid % SIDE, strip = tid / SIDE;
+  auto pool_inplace = [&]() {       // P <- max_pool(P) on the region (margins stay -inf)
+    float v[NV];
+    const int hbase = (lane_i + R) * PITCH + strip * ST;          // row lane_i, padded cols strip*8 ..
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) v[k] = P[hbase + k];
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int o = 0; o < ST; ++o) {
+        float m = v[o];
+#pragma unroll
+        for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, v[o + k]);
+        P[hbase + R + o] = m;
+      }
+    }
+    __syncthreads();
+    const int vbase = (strip * ST) * PITCH + lane_i + R;          // col lane_i, padded rows strip*8 ..
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) v[k] = P[vbase + k * PITCH];
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int o = 0; o < ST; ++o) {
+        float m = v[o];
+#pragma unroll
+        for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, v[o + k]);
+        P[vbase + (R + o) * PITCH] = m;
+      }
+    }
+    __syncthreads();
+  };
+
+  // max_mask = scores == max_pool(scores)                                              (:16)
+  pool_inplace();
+  for (int e = tid; e < SIDE * SIDE; e += 1024) {
+    const int i = (e / SIDE + R) * PITCH + e % SIDE + R;
+    const float sv = S[i];
+    const float mk = (sv > NEG && sv == P[i]) ? 1.f : 0.f;
+    M[i] = mk;
+    P[i] = mk;
+  }
+  __syncthreads();
+  for (int it = 0; it < 2; ++it) {                                                      // (:17-21)
+    pool_inplace();                            // P = max_pool(max_mask) ; supp_mask = P > 0
+    for (int e = tid; e < SIDE * SIDE; e += 1024) {
+      const int i = (e / SIDE + R) * PITCH + e % SIDE + R;
+      const float sv = S[i];
+      const float x = sv > NEG ? (P[i] > 0.f ? -1.f : sv) : NEG;
+      X[i] = x;
+      P[i] = x;
+    }
+    __syncthreads();
+    pool_inplace();                            // P = max_pool(supp_scores)
+    for (int e = tid; e < SIDE * SIDE; e += 1024) {
+      const int i = (e / SIDE + R) * PITCH + e % SIDE + R;
+      const float x = X[i];
+      const float mk = (M[i] > 0.f || (x >= 0.f && x == P[i])) ? 1.f : 0.f;
+      M[i] = mk;
+      P[i] = mk;
+    }
+    __syncthreads();
+  }
+  float* o = out + (size_t)b * H * W;
+  for (int e = tid; e < T * T; e += 1024) {
+    const int ty = e / T, tx = e - ty * T;
+    const int gy = blockIdx.y * T + ty, gx = blockIdx.x * T + tx;
+    if (gy < H && gx < W) {
+      const int i = (ty + HALO + R) * PITCH + tx + HALO + R;
+      o[(size_t)gy * W + gx] = M[i] > 0.f ? S[i] : 0.f;                                 // (:22)
+    }
+  }
+}
+
+template <int R>
+hipError_t launch_nms_fast(const float* scores, float* out, int B, int H, int W, hipStream_t s) {
+  constexpr int T = 32, SIDE = ((T + 10 * R + 7) / 8) * 8, PADN = SIDE + 2 * R, PITCH = PADN | 1;
+  dim3 grid((W + T - 1) / T, (H + T - 1) / T, B);
+  hipLaunchKernelGGL(nms_fast_kernel<R>, grid, dim3(1024), (size_t)4 * PADN * PITCH * sizeof(float), s, scores, out, H, W);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ keypoint extraction
 __device__ __forceinline__ bool kp_flag(const float* nms, int H, int W, int y, int x, float thr, int border) {
   return y >= border && y < H - border && x >= border && x < W - border && nms[(size_t)y * W + x] > thr;
@@ -416,7 +537,14 @@ hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int 
     size_t side = T + 10 * radius, n = side * side;
     return n * 4 * 3 + n * 2 + 4 + n * 4;   // S, X, tmp, M, Q, pad, P
   };
-  if (radius <= 4) {
+  switch (radius) {
+    case 1: return launch_nms_fast<1>(scores, out, B, H, W, s);
+    case 2: return launch_nms_fast<2>(scores, out, B, H, W, s);
+    case 3: return launch_nms_fast<3>(scores, out, B, H, W, s);
+    case 4: return launch_nms_fast<4>(scores, out, B, H, W, s);
+    default: break;
+  }
+  if (radius <= 4) {   // (unreachable: kept as the generic reference implementation of the tile scheme)
     constexpr int T = 32;
     dim3 grid((W + T - 1) / T, (H + T - 1) / T, B);
     hipLaunchKernelGGL(nms_kernel<T>, grid, dim3(256), lds_bytes(T), s, scores, out, H, W, radius);
