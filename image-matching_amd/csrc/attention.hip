@@ -96,13 +96,23 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
     const int buf = kt & 1;
     { IMX_GLOAD(kt + 1 < nt ? kt + 1 : kt) }   // branch-free prefetch (last tile re-fetches itself)
     if (wave_active) {
+      // ---- fetch this tile's K and V fragments from LDS up front (V lands during the S MFMAs)
+      const float* kp = &Kt[buf][l31 * KS + hi * (HD / 2)];
+      const float* vp = &Vt[buf][(4 * hi) * HD + l31];
+      float kf[HD / 2], vf[OB][16];
+#pragma unroll
+      for (int t = 0; t < HD / 2; ++t) kf[t] = kp[t];
+#pragma unroll
+      for (int o = 0; o < OB; ++o)
+#pragma unroll
+        for (int st = 0; st < 16; ++st) vf[o][st] = vp[((st & 3) + 8 * (st >> 2)) * HD + o * 32];
+      __builtin_amdgcn_sched_barrier(0);
       // ---- S^T = K . Q^T
       f32x16 S;
 #pragma unroll
       for (int r = 0; r < 16; ++r) S[r] = 0.f;
-      const float* kp = &Kt[buf][l31 * KS + hi * (HD / 2)];
 #pragma unroll
-      for (int t = 0; t < HD / 2; ++t) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[t], q[t], S, 0, 0, 0);
+      for (int t = 0; t < HD / 2; ++t) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], q[t], S, 0, 0, 0);
       // ---- online softmax over this tile's 32 keys (16 here, 16 in lane^32), log2 domain:
       //      p = 2^(s2 - m2) = e^(s - m); |abs err| of the one-multiply form <= 6e-8*max|x e^x| ~ 2e-8
       float mx = -INFINITY;
@@ -132,16 +142,13 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
       l = l * alpha + rs;
       m = mn;
       // ---- O^T = O^T * alpha + V^T . P^T
-      const float* vp = &Vt[buf][(4 * hi) * HD + l31];
 #pragma unroll
       for (int o = 0; o < OB; ++o) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[o][r] *= alpha;
 #pragma unroll
-        for (int st = 0; st < 16; ++st) {
-          const int key_lo = (st & 3) + 8 * (st >> 2);
-          O[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[key_lo * HD + o * 32], S[st], O[o], 0, 0, 0);
-        }
+        for (int st = 0; st < 16; ++st)
+          O[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[o][st], S[st], O[o], 0, 0, 0);
       }
     }
     { IMX_LSTORE(buf ^ 1) }

@@ -27,16 +27,14 @@ constexpr int IN_TILE = PH * PW * S;                 // 5780 floats
 constexpr int IN_TILE_PAD = (IN_TILE + 3) & ~3;      // 16-B aligned start for the weight tile
 constexpr int W_TILE = 9 * CK * NT;                  // 9216 floats
 constexpr int IMG_H = TH + 4, IMG_W = TW + 4;        // FIRST: image patch 12 x 36
-constexpr int FIRST_EXTRA = IMG_H * IMG_W + 9 * 64 + 64;
+constexpr int FIRST_EXTRA = IMG_H * IMG_W;
 
 template <bool POOL, bool RELU, bool FIRST>
 __global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs p, int tiles_x, int tiles_y) {
   extern __shared__ float smem[];
   float* in_tile = smem;
   float* w_tile = smem + IN_TILE_PAD;
-  float* img = w_tile + W_TILE;          // FIRST only
-  float* w1s = img + IMG_H * IMG_W;      // [9][64]
-  float* b1s = w1s + 9 * 64;             // [64]
+  float* img = w_tile + W_TILE;          // FIRST only: (8+4) x (32+4) image patch
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int t = blockIdx.x;
@@ -54,8 +52,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs p, int tiles_x, int
       int gy = y0 + py - 2, gx = x0 + px - 2;
       img[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.f;
     }
-    for (int e = tid; e < 9 * 64; e += 256) w1s[e] = p.w1[e];
-    if (tid < 64) b1s[tid] = p.b1[tid];
   }
 
   f32x16 acc[2][NB];
@@ -71,20 +67,39 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs p, int tiles_x, int
     // ---- stage the input halo tile for channels [c0, c0+CK)
     if constexpr (FIRST) {
       // conv1a + folded BN + ReLU evaluated in place; positions outside the image are conv1b's
-      // zero padding (NOT conv1a evaluated out of range).
-      for (int e = tid; e < PH * PW * CK; e += 256) {
-        int pix = e / CK, c = e % CK;
-        int py = pix / PW, px = pix % PW;
-        int gy = y0 + py - 1, gx = x0 + px - 1;
-        float v = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-          v = b1s[c0 + c];
+      // zero padding (NOT conv1a evaluated out of range).  One work item = one halo pixel x 8
+      // channels: 9 patch reads feed 72 FMAs whose weights are wave-uniform (scalar loads from
+      // the 2.3 KB conv1a table), so the staging costs ~4x fewer instructions than one
+      // (pixel, channel) per thread.  Slots: [half 0: 384][half 1: 384], 340 valid per half.
+#pragma unroll 1
+      for (int it = 0; it < 3; ++it) {
+        const int slot = it * 256 + tid;
+        const int half = __builtin_amdgcn_readfirstlane(slot / 384);
+        const int pix = slot - half * 384;
+        if (pix < PH * PW) {
+          const int py = pix / PW, px = pix - py * PW;
+          const int gy = y0 + py - 1, gx = x0 + px - 1;
+          const int cb = c0 + 8 * half;
+          float v[8];
 #pragma unroll
-          for (int tp = 0; tp < 9; ++tp)
-            v = fmaf(img[(py + tp / 3) * IMG_W + px + tp % 3], w1s[tp * 64 + c0 + c], v);
-          v = fmaxf(v, 0.f);
+          for (int j = 0; j < 8; ++j) v[j] = 0.f;
+          if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            float im[9];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) im[tp] = img[(py + tp / 3) * IMG_W + px + tp % 3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p.b1[cb + j];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = fmaf(im[tp], p.w1[tp * 64 + cb + j], v[j]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          float* d = in_tile + pix * S + 8 * half;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) d[j] = v[j];
         }
-        in_tile[pix * S + c] = v;
       }
     } else {
       constexpr int V = CK / 4;
@@ -108,22 +123,38 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs p, int tiles_x, int
       *reinterpret_cast<float4*>(w_tile + idx) = val;
     }
     __syncthreads();
-    // ---- 9 taps x 8 k-steps x 4 MFMAs
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap - dy * 3;
-      const float* a0p = in_tile + ((2 * wave + dy) * PW + (lane & 31) + dx) * S + (lane >> 5);
-      const float* a1p = a0p + PW * S;
-      const float* bp = w_tile + (tap * CK + (lane >> 5)) * NT + (lane & 31);
+    // ---- 9 taps x 8 k-steps x 4 MFMAs, fully unrolled (all LDS offsets are immediates); the operand
+    //      fragments of step s+1 are fetched from LDS before the MFMAs of step s are issued
+    //      (sched_barrier pins that order: hipcc otherwise sinks each ds_read next to its use and
+    //      exposes the LDS latency every two MFMAs).
+    {
+      const float* a0p = in_tile + ((2 * wave) * PW + (lane & 31)) * S + (lane >> 5);
+      const float* bp = w_tile + (lane >> 5) * NT + (lane & 31);
+      constexpr int NSTEP = 9 * (CK / 2);
+      float af[2][2], bf[2][NB];
+      af[0][0] = a0p[0];
+      af[0][1] = a0p[PW * S];
 #pragma unroll
-      for (int kk = 0; kk < CK / 2; ++kk) {
-        float a0 = a0p[2 * kk], a1 = a1p[2 * kk];
+      for (int n = 0; n < NB; ++n) bf[0][n] = bp[n * 32];
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        const int cur = st & 1, nxt = cur ^ 1;
+        if (st + 1 < NSTEP) {
+          const int tap = (st + 1) / (CK / 2), kk = (st + 1) % (CK / 2);
+          const int dy = tap / 3, dx = tap % 3;
+          const int aoff = (dy * PW + dx) * S + 2 * kk;
+          af[nxt][0] = a0p[aoff];
+          af[nxt][1] = a0p[aoff + PW * S];
+#pragma unroll
+          for (int n = 0; n < NB; ++n) bf[nxt][n] = bp[(tap * CK + 2 * kk) * NT + n * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
-          float bv = bp[2 * kk * NT + n * 32];
-          acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][n], 0, 0, 0);
-          acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][n], 0, 0, 0);
+          acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0], bf[cur][n], acc[0][n], 0, 0, 0);
+          acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1], bf[cur][n], acc[1][n], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }

@@ -36,33 +36,46 @@ __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
-  // register-staged double buffering: chunk c+1 is fetched from L2/HBM while chunk c feeds the MFMAs
-  float4 areg[A_IT], wreg[W_IT];
+  // register-staged double buffering: chunk c+1 is fetched from L2/HBM while chunk c feeds the MFMAs.
+  // (named scalars, not arrays: hipcc keeps small float4 arrays in scratch once sched_barrier is used)
+  float4 ar0, ar1, ar2, ar3, wr0, wr1, wr2, wr3;
+  static_assert(A_IT == 4 && (W_IT == 2 || W_IT == 4), "staging map");
+#define IMX_GA(reg_, it_)                                                                           \
+  {                                                                                                 \
+    const int e = tid + (it_) * 256, row = e / (CK / 4), v4 = e % (CK / 4);                         \
+    reg_ = (r0 + row < p.M) ? *reinterpret_cast<const float4*>(src + (size_t)(r0 + row) * lda + cc + 4 * v4) \
+                            : make_float4(0.f, 0.f, 0.f, 0.f);                                      \
+  }
+#define IMX_GW(reg_, it_, c0_)                                                                      \
+  {                                                                                                 \
+    const int idx = (tid + (it_) * 256) * 4, k = idx / NT, col = idx % NT;                          \
+    reg_ = *reinterpret_cast<const float4*>(p.w + (size_t)((c0_) + k) * p.Npad + n0 + col);         \
+  }
 #define IMX_GLOAD(c0_)                                                                              \
   {                                                                                                 \
     const float* src; int lda, cc;                                                                  \
     if ((c0_) < p.K0) { src = p.a0; lda = p.lda0; cc = (c0_); } else { src = p.a1; lda = p.lda1; cc = (c0_) - p.K0; } \
-    _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                           \
-      const int e = tid + it * 256, row = e / (CK / 4), v4 = e % (CK / 4);                          \
-      areg[it] = (r0 + row < p.M) ? *reinterpret_cast<const float4*>(src + (size_t)(r0 + row) * lda + cc + 4 * v4) \
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);                                \
-    }                                                                                               \
-    _Pragma("unroll") for (int it = 0; it < W_IT; ++it) {                                           \
-      const int idx = (tid + it * 256) * 4, k = idx / NT, col = idx % NT;                           \
-      wreg[it] = *reinterpret_cast<const float4*>(p.w + (size_t)((c0_) + k) * p.Npad + n0 + col);   \
-    }                                                                                               \
+    IMX_GA(ar0, 0) IMX_GA(ar1, 1) IMX_GA(ar2, 2) IMX_GA(ar3, 3)                                     \
+    IMX_GW(wr0, 0, c0_) IMX_GW(wr1, 1, c0_)                                                         \
+    if constexpr (W_IT == 4) { IMX_GW(wr2, 2, c0_) IMX_GW(wr3, 3, c0_) }                            \
+  }
+#define IMX_SA(reg_, it_)                                                                           \
+  {                                                                                                 \
+    const int e = tid + (it_) * 256, row = e / (CK / 4), v4 = e % (CK / 4);                         \
+    float* d = at + row * SA + 4 * v4;                                                              \
+    d[0] = reg_.x; d[1] = reg_.y; d[2] = reg_.z; d[3] = reg_.w;                                     \
   }
 #define IMX_LSTORE(buf_)                                                                            \
   {                                                                                                 \
     float* at = smem + (buf_) * BUF;                                                                \
     float* wt = at + BM * SA;                                                                       \
-    _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                           \
-      const int e = tid + it * 256, row = e / (CK / 4), v4 = e % (CK / 4);                          \
-      float* d = at + row * SA + 4 * v4;                                                            \
-      d[0] = areg[it].x; d[1] = areg[it].y; d[2] = areg[it].z; d[3] = areg[it].w;                   \
+    IMX_SA(ar0, 0) IMX_SA(ar1, 1) IMX_SA(ar2, 2) IMX_SA(ar3, 3)                                     \
+    *reinterpret_cast<float4*>(wt + (tid + 0 * 256) * 4) = wr0;                                     \
+    *reinterpret_cast<float4*>(wt + (tid + 1 * 256) * 4) = wr1;                                     \
+    if constexpr (W_IT == 4) {                                                                      \
+      *reinterpret_cast<float4*>(wt + (tid + 2 * 256) * 4) = wr2;                                   \
+      *reinterpret_cast<float4*>(wt + (tid + 3 * 256) * 4) = wr3;                                   \
     }                                                                                               \
-    _Pragma("unroll") for (int it = 0; it < W_IT; ++it)                                             \
-      *reinterpret_cast<float4*>(wt + (tid + it * 256) * 4) = wreg[it];                             \
   }
 
   IMX_GLOAD(0)
@@ -75,18 +88,33 @@ __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
     const float* w_tile = a_tile + BM * SA;
     const float* ap = a_tile + (32 * wave + (lane & 31)) * SA + (lane >> 5);
     const float* bp = w_tile + (lane >> 5) * NT + (lane & 31);
+    // operand fragments are fetched from LDS one k-step ahead of the MFMAs that consume them
+    float af[2], bf[2][NB];
+    af[0] = ap[0];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) bf[0][n] = bp[n * 32];
 #pragma unroll
     for (int kk = 0; kk < CK / 2; ++kk) {
-      float a = ap[2 * kk];
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < CK / 2) {
+        af[nxt] = ap[2 * (kk + 1)];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) bf[nxt][n] = bp[2 * (kk + 1) * NT + n * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
 #pragma unroll
       for (int n = 0; n < NB; ++n)
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[2 * kk * NT + n * 32], acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur][n], acc[n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     IMX_LSTORE((c + 1) & 1)
     __syncthreads();
   }
 #undef IMX_GLOAD
 #undef IMX_LSTORE
+#undef IMX_GA
+#undef IMX_GW
+#undef IMX_SA
 
   const int hi = lane >> 5;
 #pragma unroll
@@ -139,12 +167,23 @@ __global__ __launch_bounds__(256) void score_mfma(ScoreArgs p) {
     __syncthreads();
     const float* ap = a_tile + (32 * wave + (lane & 31)) * SA + (lane >> 5);
     const float* bp = b_tile + (lane & 31) * SA + (lane >> 5);
+    float af[2], bf[2][NB];
+    af[0] = ap[0];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) bf[0][n] = bp[n * 32 * SA];
 #pragma unroll
     for (int kk = 0; kk < CK / 2; ++kk) {
-      float a = ap[2 * kk];
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < CK / 2) {
+        af[nxt] = ap[2 * (kk + 1)];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) bf[nxt][n] = bp[n * 32 * SA + 2 * (kk + 1)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < NB; ++n)
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[n * 32 * SA + 2 * kk], acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur][n], acc[n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   const int hi = lane >> 5;
