@@ -62,8 +62,56 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs p, int tiles_x, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
+  // Global -> register -> LDS staging.  All of a chunk's loads (6 float4 of the input halo tile +
+  // 9 float4 of weights per thread) are issued back to back so one memory latency covers the lot,
+  // and they are issued BEFORE the previous chunk's MFMA loop so that latency hides behind ~18k
+  // cycles of matrix work; the LDS write happens after the loop (barrier, write, barrier).
+  // Named float4 registers (not arrays): see gemm.hip.
+  float4 i0, i1, i2, i3, i4, i5, w0, w1r, w2, w3, w4, w5, w6, w7, w8;
+  constexpr int V = CK / 4;
+#define IMX_GI(reg_, it_)                                                                              \
+  {                                                                                                    \
+    const int e = tid + (it_) * 256;                                                                   \
+    reg_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                            \
+    if (e < PH * PW * V) {                                                                             \
+      const int pix = e / V, v4 = e % V, py = pix / PW, px = pix % PW;                                 \
+      const int gy = y0 + py - 1, gx = x0 + px - 1;                                                    \
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W)                                                      \
+        reg_ = *reinterpret_cast<const float4*>(p.in + ((size_t)(b * H + gy) * W + gx) * Cin + cc + 4 * v4); \
+    }                                                                                                  \
+  }
+#define IMX_SI(reg_, it_)                                                                              \
+  {                                                                                                    \
+    const int e = tid + (it_) * 256;                                                                   \
+    if (e < PH * PW * V) {                                                                             \
+      float* d = in_tile + (e / V) * S + 4 * (e % V);                                                  \
+      d[0] = reg_.x; d[1] = reg_.y; d[2] = reg_.z; d[3] = reg_.w;                                      \
+    }                                                                                                  \
+  }
+#define IMX_GWT(reg_, it_)                                                                             \
+  {                                                                                                    \
+    const int idx = (tid + (it_) * 256) * 4, col = idx % NT, row = idx / NT, tap = row / CK, k = row % CK; \
+    reg_ = *reinterpret_cast<const float4*>(p.w + ((size_t)(tap * Cin + cc + k)) * Cout + n0 + col);   \
+  }
+#define IMX_SWT(reg_, it_) *reinterpret_cast<float4*>(w_tile + (tid + (it_) * 256) * 4) = reg_;
+#define IMX_GLOAD(c0_)                                                                                 \
+  {                                                                                                    \
+    const int cc = (c0_);                                                                              \
+    if constexpr (!FIRST) { IMX_GI(i0, 0) IMX_GI(i1, 1) IMX_GI(i2, 2) IMX_GI(i3, 3) IMX_GI(i4, 4) IMX_GI(i5, 5) } \
+    IMX_GWT(w0, 0) IMX_GWT(w1r, 1) IMX_GWT(w2, 2) IMX_GWT(w3, 3) IMX_GWT(w4, 4)                        \
+    IMX_GWT(w5, 5) IMX_GWT(w6, 6) IMX_GWT(w7, 7) IMX_GWT(w8, 8)                                        \
+  }
+#define IMX_LSTORE()                                                                                   \
+  {                                                                                                    \
+    if constexpr (!FIRST) { IMX_SI(i0, 0) IMX_SI(i1, 1) IMX_SI(i2, 2) IMX_SI(i3, 3) IMX_SI(i4, 4) IMX_SI(i5, 5) } \
+    IMX_SWT(w0, 0) IMX_SWT(w1r, 1) IMX_SWT(w2, 2) IMX_SWT(w3, 3) IMX_SWT(w4, 4)                        \
+    IMX_SWT(w5, 5) IMX_SWT(w6, 6) IMX_SWT(w7, 7) IMX_SWT(w8, 8)                                        \
+  }
+  static_assert(W_TILE / 4 == 9 * 256 && PH * PW * V <= 6 * 256, "staging map");
+
+  IMX_GLOAD(0)
   for (int c0 = 0; c0 < Cin; c0 += CK) {
-    __syncthreads();
+    __syncthreads();          // every wave is done reading the previous chunk's tiles
     // ---- stage the input halo tile for channels [c0, c0+CK)
     if constexpr (FIRST) {
       // conv1a + folded BN + ReLU evaluated in place; positions outside the image are conv1b's
@@ -101,28 +149,11 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs p, int tiles_x, int
           for (int j = 0; j < 8; ++j) d[j] = v[j];
         }
       }
-    } else {
-      constexpr int V = CK / 4;
-      for (int e = tid; e < PH * PW * V; e += 256) {
-        int pix = e / V, v4 = e % V;
-        int py = pix / PW, px = pix % PW;
-        int gy = y0 + py - 1, gx = x0 + px - 1;
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-          val = *reinterpret_cast<const float4*>(p.in + ((size_t)(b * H + gy) * W + gx) * Cin + c0 + 4 * v4);
-        float* d = in_tile + pix * S + 4 * v4;
-        d[0] = val.x; d[1] = val.y; d[2] = val.z; d[3] = val.w;
-      }
     }
-    // ---- stage weights [9][CK][NT]
-    for (int e = tid; e < W_TILE / 4; e += 256) {
-      int idx = e * 4;
-      int col = idx % NT, row = idx / NT;
-      int tap = row / CK, k = row % CK;
-      float4 val = *reinterpret_cast<const float4*>(p.w + ((size_t)(tap * Cin + c0 + k)) * Cout + n0 + col);
-      *reinterpret_cast<float4*>(w_tile + idx) = val;
-    }
+    IMX_LSTORE()
     __syncthreads();
+    // prefetch the next chunk (branch-free: the last iteration re-fetches its own chunk, unused)
+    IMX_GLOAD(c0 + CK < Cin ? c0 + CK : c0)
     // ---- 9 taps x 8 k-steps x 4 MFMAs, fully unrolled (all LDS offsets are immediates); the operand
     //      fragments of step s+1 are fetched from LDS before the MFMAs of step s are issued
     //      (sched_barrier pins that order: hipcc otherwise sinks each ds_read next to its use and
@@ -158,6 +189,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(ConvArgs p, int tiles_x, int
       }
     }
   }
+
+#undef IMX_GI
+#undef IMX_SI
+#undef IMX_GWT
+#undef IMX_SWT
+#undef IMX_GLOAD
+#undef IMX_LSTORE
 
   // ---- epilogue.  acc[m][n][r]: pixel row y0+2*wave+m, pixel col x0 + (r&3)+8*(r>>2)+4*(lane>>5),
   //      output channel n0 + 32n + (lane&31).
