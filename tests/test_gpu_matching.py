@@ -95,3 +95,15 @@ def test_official_matching_signature():
 def test_smoke_entry_point():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_cli_end_to_end_on_synthetic_dataset(tmp_path):
+    """The reference CLI's contract: reads <img_dir>/source1/*, <img_dir>/template1/<one>, writes
+    <Result_dir>/<exper>/Transform/trans_* and .../Match/* (superpoint_glue_test.py:59-140)."""
+    import superpoint_glue_test as cli
+    img_dir, res_dir = str(tmp_path / "data") + "/", str(tmp_path / "out") + "/"
+    cli.main(["--img_dir", img_dir, "--Result_dir", res_dir, "--synthetic", "2", "--resize_scale", "0.5",
+              "--max_keypoints", "512", "--exper_name", "t"])
+    import os
+    assert sorted(os.listdir(os.path.join(res_dir, "t", "Match"))) == ["src_000.png", "src_001.png"]
+    assert sorted(os.listdir(os.path.join(res_dir, "t", "Transform"))) == ["trans_src_000.png", "trans_src_001.png"]

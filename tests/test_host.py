@@ -122,3 +122,37 @@ def test_shard_and_records_roundtrip():
     for k in out:
         assert torch.equal(back[k], out[k]), k
     assert shard.gather_records(rec) is rec                   # world_size 1: no process group needed
+
+
+def test_cli_flags_match_reference_and_kenc_string_parsing():
+    """superpoint_glue_test.py:17-35: every reference flag exists with the same default."""
+    import superpoint_glue_test as cli
+    opt = cli.build_parser().parse_args([])
+    ref_defaults = {"exper_name": "superpoint_glue_descriptor", "img_dir": "datasets/Amazon/", "Result_dir": "Results/Amazon/",
+                    "resize_scale": 0.125, "match_viz": True, "show_keypoints": True, "descriptor_dim": 128,
+                    "superpoint_weights": "superpoint/models/weights/superPointNet_allss_descriptor_128.pth.tar",
+                    "keypoint_threshold": 0.005, "nms_radius": 4, "max_keypoints": -1,
+                    "superglue_weights": "superglue/models/weights/SuperGlue_allss_descriptor_128.pth",
+                    "keypoint_encoder": [32, 64, 128], "sinkhorn_iterations": 30, "match_threshold": 0.1}
+    for k, v in ref_defaults.items():
+        assert getattr(opt, k) == v, k
+    opt = cli.build_parser().parse_args(["--keypoint_encoder", "[32, 64]", "--max_keypoints", "100"])
+    cfg = cli.make_config(opt)
+    assert cfg["superglue"]["keypoint_encoder"] == [32, 64] and cfg["superpoint"]["max_keypoints"] == 100
+    assert cfg["superpoint"]["weights"] is None            # LFS-pointer / absent checkpoint -> synthetic weights
+
+
+def test_hostops_similarity_ransac_and_warp():
+    from image_matching_amd import hostops
+    rng = np.random.RandomState(1)
+    src = rng.rand(60, 2) * 400
+    th, s = 0.1, 1.1
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]) * s
+    dst = src @ R.T + [5, -3]
+    dst[:12] += rng.rand(12, 2) * 200 + 20                  # outliers
+    M, mask = hostops.estimate_affine_partial_2d(src, dst, ransac_thresh=7)
+    np.testing.assert_allclose(M, np.concatenate([R, [[5], [-3]]], 1), atol=1e-6)
+    assert mask.sum() == 48 and not mask[:12].any()
+    img = rng.rand(40, 60) * 255
+    w = hostops.warp_affine(img, np.array([[1, 0, 3], [0, 1, 2.0]]), (60, 40))
+    np.testing.assert_allclose(w[5, 10], img[3, 7])
