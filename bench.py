@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs-per-gpu", type=int, default=16, help="pairs per step per GPU (weak scaling)")
+    ap.add_argument("--pairs-per-gpu", type=int, default=32, help="pairs per step per GPU (weak scaling)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-pass", action="store_true")

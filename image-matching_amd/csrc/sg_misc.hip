@@ -9,18 +9,26 @@
 namespace imx {
 namespace {
 
+// Online log-sum-exp with ONE v_exp_f32 per element (the running sum is rescaled only when the
+// maximum moves):   d = x - m;  e = exp(-|d|) = 2^(-|d|*log2 e);  s = d > 0 ? s*e + 1 : s + e;  m = max(m, x)
+// The maximum stays exact (natural domain); the one-multiply exponent form has absolute error
+// <= 6e-8 * max|t 2^t| ~ 2e-8 per term (terms far below the maximum are negligible anyway).
+constexpr float LOG2E = 1.4426950408889634f;
 struct LSE { float m, s; };   // running max and sum of exp(x - m)
 
+__device__ __forceinline__ float exp_neg(float t) {     // exp(-t), t >= 0 (t = +inf -> 0)
+  return __builtin_amdgcn_exp2f(-t * LOG2E);
+}
 __device__ __forceinline__ void lse_add(LSE& a, float x) {
-  const float nm = fmaxf(a.m, x);
-  // a.m == -inf only while a.s == 0; exp(-inf - nm) = 0 for finite nm.
-  a.s = a.s * expf(a.m - nm) + expf(x - nm);
-  a.m = nm;
+  const float d = x - a.m;                         // +inf on the first element (a.m = -inf)
+  const float e = exp_neg(fabsf(d));
+  a.s = d > 0.f ? fmaf(a.s, e, 1.0f) : a.s + e;
+  a.m = fmaxf(a.m, x);
 }
 __device__ __forceinline__ LSE lse_merge(const LSE& a, const LSE& b) {
   const float nm = fmaxf(a.m, b.m);
-  const float ea = (a.m == -INFINITY) ? 0.f : expf(a.m - nm);
-  const float eb = (b.m == -INFINITY) ? 0.f : expf(b.m - nm);
+  const float ea = (a.m == -INFINITY) ? 0.f : exp_neg(nm - a.m);
+  const float eb = (b.m == -INFINITY) ? 0.f : exp_neg(nm - b.m);
   return LSE{nm, a.s * ea + b.s * eb};
 }
 __device__ __forceinline__ LSE wave_lse(LSE a) {
@@ -31,6 +39,7 @@ __device__ __forceinline__ LSE wave_lse(LSE a) {
   }
   return a;
 }
+__device__ __forceinline__ float lse_value(const LSE& a) { return a.m + logf(a.s); }
 
 // ------------------------------------------------------------------ kenc layer 0
 __global__ __launch_bounds__(256) void kenc0_kernel(Kenc0Args a, float scaling) {
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256) void sinkhorn_rows(SinkhornArgs a) {
   if (lane == 0) {
     const float norm = -logf((float)(m + n));                                          // (:162)
     const float log_mu = i < m ? norm : logf((float)n) + norm;                         // (:163)
-    a.u[(size_t)b * (a.N0p + 1) + i] = log_mu - (acc.m + logf(acc.s));
+    a.u[(size_t)b * (a.N0p + 1) + i] = log_mu - lse_value(acc);
   }
 }
 
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_cols(SinkhornArgs a) {
     for (int k = 1; k < 16; ++k) t = lse_merge(t, LSE{pm[k][c], ps[k][c]});
     const float norm = -logf((float)(m + n));
     const float log_nu = j < n ? norm : logf((float)m) + norm;                         // (:164)
-    a.v[(size_t)b * (a.N1p + 1) + j] = log_nu - (t.m + logf(t.s));
+    a.v[(size_t)b * (a.N1p + 1) + j] = log_nu - lse_value(t);
   }
 }
 

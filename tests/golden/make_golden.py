@@ -234,6 +234,21 @@ def main():
             **{f"scores{b}": o["scores"][b] for b in range(2)},
             **{f"descriptors{b}": o["descriptors"][b] for b in range(2)})
 
+    # ---------------------------------------------------------------- official (no-BN) SuperPoint
+    print("sp_official (superglue/models/superpoint.py, d=256, torch.load bypassed)")
+    from superglue.models import superpoint as ref_off_mod
+    sd_off = synth.synth_state_dict(synth.superpoint_official_shapes(256), 77)
+    real_load = torch.load
+    torch.load = lambda *a, **k: to_torch(sd_off)        # weights/superpoint_v1.pth is an LFS pointer
+    try:
+        spo = ref_off_mod.SuperPoint({"descriptor_dim": 256, "max_keypoints": 300}).eval()
+    finally:
+        torch.load = real_load
+    xo = pair_tensor(5, 128, 192)[0]
+    oo = spo({"image": xo})
+    npz("sp_official.npz", H=128, W=192, seed=5, max_keypoints=300, weight_seed=77,
+        keypoints0=oo["keypoints"][0], scores0=oo["scores"][0], descriptors0=oo["descriptors"][0])
+
     # ---------------------------------------------------------------- align_corners=True unit
     print("sample_descriptors align_corners=True (torch.__version__ patched to 1.7.1)")
     dmap = torch.from_numpy(synth.normal(7, "dmap", 32 * 15 * 20).reshape(1, 32, 15, 20))

@@ -94,3 +94,15 @@ def test_matching_c3_end_to_end(name):
     assert isinstance(pred["keypoints0"], list) and isinstance(pred["scores0"], tuple) and isinstance(pred["descriptors0"], list)
     assert pred["matches0"].dtype == torch.int64 and pred["matching_scores0"].dtype == torch.float32
     assert pred["descriptors0"][0].shape == (d, K) and pred["keypoints0"][0].shape == (K, 2)
+
+
+def test_official_superpoint_variant():
+    """superglue/models/superpoint.py (no BN, F.normalize): oracle vs the reference module's output."""
+    from image_matching_amd import synth
+    g = util.golden("sp_official.npz")
+    sd = util.to_torch(synth.synth_state_dict(synth.superpoint_official_shapes(256), int(g["weight_seed"])))
+    x = util.pair(int(g["seed"]), int(g["H"]), int(g["W"]))[0]
+    out = superpoint_ref.superpoint_forward(x, sd, util.sp_config(256, int(g["max_keypoints"])), variant="official")
+    assert np.array_equal(out["keypoints"][0].numpy(), g["keypoints0"])
+    util.assert_close(out["scores"][0], g["scores0"], "scores", atol=1e-6, rtol=1e-6)
+    util.assert_close(out["descriptors"][0], g["descriptors0"], "descriptors", atol=1e-5, rtol=1e-5)
