@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -31,7 +32,8 @@ struct DevBuf {
   size_t bytes = 0;
 };
 struct ConvW {
-  float* w = nullptr;
+  float* w = nullptr;    // direct form  [9][Cin][Cout]
+  float* wu = nullptr;   // Winograd F(2x2,3x3) form (conv3x3_wino.hip layout)
   float* b = nullptr;
   int cin = 0, cout = 0;
 };
@@ -86,6 +88,7 @@ struct imx_handle_s {
   int det_B = 0, det_H = 0, det_W = 0, det_Hc = 0, det_Wc = 0, det_Ksel = 0;
   // debug / timing
   bool debug = false, timing = false;
+  bool use_wino = true;   // IMX_CONV=direct selects the direct-form 3x3 kernels (A/B, fallback)
   std::map<std::string, Tap> taps;
   std::vector<TimedEvent> events;
   std::vector<TimingRow> report;
@@ -257,15 +260,47 @@ void put_conv3(const std::map<std::string, HostTensor>& raw, const std::string& 
   }
 }
 
+// Winograd F(2x2,3x3) weight transform U = G g G^T of folded direct-form weights w[tap][ci][co]
+// (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), laid out per (64-channel output group, 8-channel
+// input chunk) exactly as conv3x3_wino.hip stages it into LDS: [16 pos][ci>>1 (4)][co>>4 (4)][ci&1][16].
+std::vector<float> wino_transform(const std::vector<float>& w, int cin, int cout) {
+  const int nchunk = cin / 8, ncog = cout / 64;
+  std::vector<float> u((size_t)ncog * nchunk * 8192, 0.f);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci) {
+      double g[3][3], gg[4][3], uu[4][4];
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((size_t)(ky * 3 + kx) * cin + ci) * cout + co];
+      for (int kx = 0; kx < 3; ++kx) {
+        gg[0][kx] = g[0][kx];
+        gg[1][kx] = 0.5 * (g[0][kx] + g[1][kx] + g[2][kx]);
+        gg[2][kx] = 0.5 * (g[0][kx] - g[1][kx] + g[2][kx]);
+        gg[3][kx] = g[2][kx];
+      }
+      for (int r = 0; r < 4; ++r) {
+        uu[r][0] = gg[r][0];
+        uu[r][1] = 0.5 * (gg[r][0] + gg[r][1] + gg[r][2]);
+        uu[r][2] = 0.5 * (gg[r][0] - gg[r][1] + gg[r][2]);
+        uu[r][3] = gg[r][2];
+      }
+      const int cog = co / 64, col = co % 64, chunk = ci / 8, k = ci % 8;
+      float* blk = u.data() + ((size_t)cog * nchunk + chunk) * 8192;
+      for (int q = 0; q < 16; ++q)
+        blk[(((q * 4 + (k >> 1)) * 4 + (col >> 4)) * 2 + (k & 1)) * 16 + (col & 15)] = (float)uu[q / 4][q % 4];
+    }
+  return u;
+}
+
 int make_conv(imx_handle_t h, ConvW& out, const std::map<std::string, HostTensor>& raw, const std::string& conv,
               const std::string& bn, int cin, int cout) {
   std::vector<float> w((size_t)9 * cin * cout), b(cout);
   put_conv3(raw, conv, bn, cin, cout, cout, 0, w, b);
   out.w = upload(h, w);
+  out.wu = upload(h, wino_transform(w, cin, cout));
   out.b = upload(h, b);
   out.cin = cin;
   out.cout = cout;
-  return (out.w && out.b) ? 0 : fail(h, "weight upload failed (%s)", conv.c_str());
+  return (out.w && out.wu && out.b) ? 0 : fail(h, "weight upload failed (%s)", conv.c_str());
 }
 
 // linear weight (N,K[,1[,1]]) -> W[k_perm(k)][n_perm(n)] padded to Npad columns, folded BN
@@ -323,10 +358,11 @@ int finalize_superpoint(imx_handle_t h) {
     put_conv3(raw, "convPa", bn ? "bnPa" : "", 128, 256, 512, 0, w, b);
     put_conv3(raw, "convDa", bn ? "bnDa" : "", 128, 256, 512, 256, w, b);
     h->conv[7].w = upload(h, w);
+    h->conv[7].wu = upload(h, wino_transform(w, 128, 512));
     h->conv[7].b = upload(h, b);
     h->conv[7].cin = 128;
     h->conv[7].cout = 512;
-    if (!h->conv[7].w || !h->conv[7].b) return fail(h, "weight upload failed (heads)");
+    if (!h->conv[7].w || !h->conv[7].wu || !h->conv[7].b) return fail(h, "weight upload failed (heads)");
   }
   if (make_gemm(h, h->pb, raw, "convPb", bn ? "bnPb" : "", 256, 65)) return -1;
   if (make_gemm(h, h->db, raw, "convDb", bn ? "bnDb" : "", 256, d)) return -1;
@@ -443,9 +479,9 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   auto conv = [&](const char* name, const ConvW& w, const float* in, float* out, int hh, int ww, bool pool, bool first) -> int {
     ConvArgs a{};
     a.in = in; a.in2 = first ? img1 : nullptr; a.split = first ? split : 0;
-    a.w = w.w; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
+    a.w = w.w; a.wu = w.wu; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
     a.B = B; a.H = hh; a.W = ww; a.Cin = w.cin; a.Cout = w.cout; a.relu = 1; a.pool = pool ? 1 : 0; a.first = first ? 1 : 0;
-    RUN(name, launch_conv3x3(a, s));
+    RUN(name, h->use_wino ? launch_conv3x3_wino(a, s) : launch_conv3x3(a, s));
     return 0;
   };
   if (conv("conv1ab_pool", h->conv[0], img0, a1, H, W, true, true)) return -1;
@@ -637,6 +673,7 @@ int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
   imx_handle_s* h = new imx_handle_s();
   h->device = device_id;
   h->cfg = *cfg;
+  if (const char* e = getenv("IMX_CONV")) h->use_wino = std::string(e) != "direct";
   build_expected(h);
   *out = h;
   return 0;
