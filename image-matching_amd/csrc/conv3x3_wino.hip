@@ -13,13 +13,21 @@
 //   positions -> 32 accumulators of 4 VGPRs.  The 16x16 MFMA's D layout gives each lane one output
 //   channel and 4 wtiles with all 16 positions: the output transform, bias, ReLU and the 2x2
 //   max-pool (one wtile = one pooled pixel) are in-lane, no LDS exchange.
-// K loop: 8 input channels per chunk:
-//   regs (prefetched behind the previous chunk's MFMAs) -> raw patch [10][20][9] and U [16][4][4][2][16]
-//   -> input transform (one (wtile, channel) per thread, 32 adds) -> V [16][4][32][2]
-//   -> 64 MFMAs per wave.  LDS 57 KB -> 2 workgroups per CU so one group's staging/transform
-//   overlaps the other's matrix work.  V/U layouts make every MFMA operand read 32 consecutive floats.
-// FIRST mode fuses conv1a (1->64, K=9) into the raw-patch staging, as in conv3x3.hip.
+// K loop, 8 input channels per chunk, two barriers per chunk:
+//   raw 10x18x8 input patch (fetched + written to LDS inside the previous chunk's MFMA loop)
+//   -> input transform (one (channel, wtile) per thread, 32 adds) -> V [16 pos][4 ch pairs][72]
+//   -> 64 MFMAs per wave in 8 groups; A operands (V) from LDS one group ahead, B operands (U) read
+//   straight from global/L2 into 64 registers while the transform runs (layout
+//   [pos][k-step][co-block][4 k][16 co]: one wave load = 256 contiguous bytes; U never touches LDS).
+//   LDS 27 KB, <=224 VGPRs -> 2 workgroups per CU.
+// FIRST mode fuses conv1a (1->64, K=9, weights broadcast from LDS) into the raw-patch staging.
+// Measured (round 1, PMC + in-kernel cycle trace, IMX_WINO_TRACE=1): MFMA phase 2.5-2.7k cycles of a
+// 5.6k-cycle chunk period with two co-resident groups; the limiter is operand delivery (a 16x16x4 fp32
+// MFMA consumes 512 B of operands per 32 cycles) - see DESIGN.md for the planned 32x32x2 / 256-accumulator
+// variant.
 #include "imx_kernels.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace imx {
 
@@ -28,21 +36,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 constexpr int TR = 4, TC = 8, OH = 2 * TR, OW = 2 * TC;   // wtiles / output pixels per workgroup
 constexpr int RH = OH + 2, RW = OW + 2;                   // raw patch (pad 1 halo)
-constexpr int RPITCH = 20, RS = 9;                        // raw patch LDS pitch / pixel stride (2-way max)
+constexpr int RPITCH = RW, RS = 12;                       // FIRST: raw conv1a patch [10][18][12]: (4 wtiles x 8 ch) reads conflict-free
 constexpr int CK = 8, NT = 64;
-constexpr int RAW = RH * RPITCH * RS;                     // 1800
-constexpr int RAW_PAD = (RAW + 3) & ~3;
-constexpr int VSZ = 16 * 4 * 32 * 2;                      // 4096
-constexpr int USZ = 16 * 4 * 4 * 2 * 16;                  // 8192 = 16 positions x 8 ci x 64 co
+constexpr int RAW = RH * RPITCH * RS;                     // 2160 (FIRST only)
+constexpr int VK = 72;                                    // V channel-pair stride (64 + 8 pad: conflict-free transform writes)
+constexpr int VSZ = 16 * 4 * VK;                          // 4608
+constexpr int USZ = 16 * 2 * 4 * 4 * 16;                  // 8192 = [16 pos][2 k-steps][4 co-blocks][4 k][16 co] per (64 co, 8 ci)
 constexpr int IMG_H = RH + 2, IMG_W = RW + 2;             // FIRST: image patch 12 x 20
 
-template <bool POOL, bool RELU, bool FIRST>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, int tiles_y) {
+template <bool POOL, bool RELU, bool FIRST, bool TRACE = false>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, int tiles_y, unsigned* trace = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* raw = smem;
-  float* V = smem + RAW_PAD;
-  float* U = V + VSZ;
-  float* img = U + USZ;   // FIRST only
+  float* V = smem;
+  float* raw = V + VSZ;                 // raw input patch [10][18][12]
+  float* img = raw + RAW;               // FIRST only: image patch, conv1a weights + bias
+  float* w1s = img + IMG_H * IMG_W;
+  float* b1s = w1s + 9 * 64;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ib = wave & 1, cg = wave >> 1;
@@ -63,6 +72,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
       const int gy = y0 + py - 2, gx = x0 + px - 2;
       img[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.f;
     }
+    for (int e = tid; e < 9 * 64; e += 256) w1s[e] = p.w1[e];
+    if (tid < 64) b1s[tid] = p.b1[tid];
   }
 
   f32x4 acc[16][2];
@@ -73,50 +84,61 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[q][j][r] = 0.f;
 
-  // ---- global -> register prefetch (named registers; issued before the previous chunk's MFMAs)
-  float4 r0, r1, u0, u1, u2, u3, u4, u5, u6, u7;
-#define IMX_GR(reg_, it_)                                                                              \
-  {                                                                                                    \
-    const int e = tid + (it_) * 256;                                                                   \
-    reg_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                            \
-    if (e < RH * RW * 2) {                                                                             \
-      const int pix = e >> 1, half = e & 1, py = pix / RW, px = pix % RW;                              \
-      const int gy = y0 + py - 1, gx = x0 + px - 1;                                                    \
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W)                                                      \
-        reg_ = *reinterpret_cast<const float4*>(p.in + ((size_t)(b * H + gy) * W + gx) * Cin + cc + 4 * half); \
-    }                                                                                                  \
+  // ---- staging pipeline.  Per chunk c, inside the MFMA loop of chunk c-1 (so their latency and issue
+  //      cost hide behind matrix work): the raw 10x18x8 input patch of chunk c is fetched (2 float4 per
+  //      thread) and written to LDS `raw`, and the U block of chunk c is fetched into registers.
+  //      After the barrier that ends MFMA(c-1): U registers -> LDS, input transform raw -> V (thread =
+  //      (channel tc, wtile tw); raw pixel stride 12 makes the 4 wtiles x 8 channels of a half-wave
+  //      conflict free), second barrier, MFMA(c).  Two barriers per chunk.
+  const int tc = tid & 7, tw = tid >> 3, twr = tw >> 3, twc = tw & 7;
+  float4 r0, r1;
+  // raw patch items: e = tid + 256*it, e < 360: pixel e>>1 (py = pix / 18, px = pix % 18), channel half e&1
+  const float* rsrc0 = nullptr; const float* rsrc1 = nullptr;   // null = zero padding / no item
+  int rdst0 = -1, rdst1 = -1;
+  if constexpr (!FIRST) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int e = tid + it * 256;
+      if (e < RH * RW * 2) {
+        const int pix = e >> 1, half = e & 1, py = pix / RW, px = pix % RW;
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        const float* src = (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                               ? p.in + ((size_t)(b * H + gy) * W + gx) * Cin + 4 * half : nullptr;
+        const int dst = (py * RPITCH + px) * RS + 4 * half;
+        if (it == 0) { rsrc0 = src; rdst0 = dst; } else { rsrc1 = src; rdst1 = dst; }
+      }
+    }
   }
-#define IMX_SR(reg_, it_)                                                                              \
-  {                                                                                                    \
-    const int e = tid + (it_) * 256;                                                                   \
-    if (e < RH * RW * 2) {                                                                             \
-      const int pix = e >> 1, half = e & 1, py = pix / RW, px = pix % RW;                              \
-      float* d = raw + (py * RPITCH + px) * RS + 4 * half;                                             \
-      d[0] = reg_.x; d[1] = reg_.y; d[2] = reg_.z; d[3] = reg_.w;                                      \
-    }                                                                                                  \
+#define IMX_GRAW(cc_)                                                                                  \
+  if constexpr (!FIRST) {                                                                              \
+    r0 = rsrc0 ? *reinterpret_cast<const float4*>(rsrc0 + (cc_)) : make_float4(0.f, 0.f, 0.f, 0.f);    \
+    r1 = rsrc1 ? *reinterpret_cast<const float4*>(rsrc1 + (cc_)) : make_float4(0.f, 0.f, 0.f, 0.f);    \
   }
-#define IMX_GU(reg_, it_) reg_ = *reinterpret_cast<const float4*>(uc + (tid + (it_) * 256) * 4);
-#define IMX_SU(reg_, it_) *reinterpret_cast<float4*>(U + (tid + (it_) * 256) * 4) = reg_;
-#define IMX_GLOAD(chunk_)                                                                              \
-  {                                                                                                    \
-    const int cc = (chunk_) * CK;                                                                      \
-    const float* uc = ublk + (size_t)(chunk_) * USZ;                                                   \
-    (void)cc;                                                                                          \
-    if constexpr (!FIRST) { IMX_GR(r0, 0) IMX_GR(r1, 1) }                                              \
-    IMX_GU(u0, 0) IMX_GU(u1, 1) IMX_GU(u2, 2) IMX_GU(u3, 3) IMX_GU(u4, 4) IMX_GU(u5, 5) IMX_GU(u6, 6) IMX_GU(u7, 7) \
-  }
-#define IMX_LSTORE()                                                                                   \
-  {                                                                                                    \
-    if constexpr (!FIRST) { IMX_SR(r0, 0) IMX_SR(r1, 1) }                                              \
-    IMX_SU(u0, 0) IMX_SU(u1, 1) IMX_SU(u2, 2) IMX_SU(u3, 3) IMX_SU(u4, 4) IMX_SU(u5, 5) IMX_SU(u6, 6) IMX_SU(u7, 7) \
+#define IMX_SRAW()                                                                                     \
+  if constexpr (!FIRST) {                                                                              \
+    if (rdst0 >= 0) *reinterpret_cast<float4*>(raw + rdst0) = r0;                                      \
+    if (rdst1 >= 0) *reinterpret_cast<float4*>(raw + rdst1) = r1;                                      \
   }
 
-  IMX_GLOAD(0)
+  // TRACE: per-phase s_memtime deltas summed over chunks (bring-up instrumentation, off in the product build)
+  unsigned tph[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = 0;
+#define IMX_TS(i_)                                                   \
+  if constexpr (TRACE) {                                             \
+    const unsigned long long now = __builtin_readcyclecounter();     \
+    tph[i_] += (unsigned)(now - tprev);                              \
+    tprev = now;                                                     \
+  }
+  IMX_GRAW(0)
+  IMX_SRAW()
+  if constexpr (TRACE) tprev = __builtin_readcyclecounter();
   for (int ch = 0; ch < nchunk; ++ch) {
     __syncthreads();               // previous chunk's MFMA phase is done with raw / V / U
+    IMX_TS(0)
+    float d[16];
     if constexpr (FIRST) {
-      // conv1a + folded BN + ReLU for channels [8ch, 8ch+8) at the 10x18 halo pixels; positions
-      // outside the image are conv1b's zero padding.
+      // conv1a + folded BN + ReLU for channels [8ch, 8ch+8) at the 10x18 halo pixels (weights from
+      // LDS, broadcast reads); positions outside the image are conv1b's zero padding.
       if (tid < RH * RW) {
         const int py = tid / RW, px = tid % RW;
         const int gy = y0 + py - 1, gx = x0 + px - 1;
@@ -129,81 +151,105 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
 #pragma unroll
           for (int tp = 0; tp < 9; ++tp) im9[tp] = img[(py + tp / 3) * IMG_W + px + tp % 3];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = p.b1[cb + j];
+          for (int j = 0; j < 8; ++j) v[j] = b1s[cb + j];
 #pragma unroll
           for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaf(im9[tp], p.w1[tp * 64 + cb + j], v[j]);
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(im9[tp], w1s[tp * 64 + cb + j], v[j]);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
         }
-        float* d = raw + (py * RPITCH + px) * RS;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) d[j] = v[j];
+        float4* dst = reinterpret_cast<float4*>(raw + (py * RPITCH + px) * RS);
+        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
       }
+      IMX_TS(1)
+      __syncthreads();
+      IMX_TS(2)
+    } else {
+      IMX_TS(1)
+      IMX_TS(2)
     }
-    IMX_LSTORE()
-    __syncthreads();
-    // ---- input transform  V = B^T d B : thread = (wtile w, channel c)
+    // ---- this chunk's B operands (U = G g G^T) straight from global/L2 into 64 registers: the layout
+    //      [pos][k-step][co-block][4 k][16 co] makes every wave load 256 contiguous bytes; they land
+    //      while the input transform runs, so the MFMA loop below touches no global memory except the
+    //      next raw patch.  U never goes through LDS.
+    const float* ub = ublk + (size_t)ch * USZ + cg * 128 + lane;
+    float bf[16][2][2];          // [position][k-step][column block]: the wave's whole B panel of this chunk
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf[q][s2][0] = ub[(q * 2 + s2) * 256];
+        bf[q][s2][1] = ub[(q * 2 + s2) * 256 + 64];
+      }
+    // ---- input transform  V = B^T d B  (LDS raw -> registers -> LDS V), thread = (channel tc, wtile tw)
     {
-      const int w = tid & 31, c = tid >> 5;
-      const int wr = w >> 3, wc = w & 7;
-      const float* rp = raw + ((2 * wr) * RPITCH + 2 * wc) * RS + c;
-      float d[4][4], tt[4][4];
+      const float* rp = raw + ((2 * twr) * RPITCH + 2 * twc) * RS + tc;
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) d[a][bb] = rp[(a * RPITCH + bb) * RS];
+        for (int bb = 0; bb < 4; ++bb) d[a * 4 + bb] = rp[(a * RPITCH + bb) * RS];
+      float tt[4][4];
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb) {       // rows: B^T d
-        tt[0][bb] = d[0][bb] - d[2][bb];
-        tt[1][bb] = d[1][bb] + d[2][bb];
-        tt[2][bb] = d[2][bb] - d[1][bb];
-        tt[3][bb] = d[1][bb] - d[3][bb];
+        tt[0][bb] = d[0 * 4 + bb] - d[2 * 4 + bb];
+        tt[1][bb] = d[1 * 4 + bb] + d[2 * 4 + bb];
+        tt[2][bb] = d[2 * 4 + bb] - d[1 * 4 + bb];
+        tt[3][bb] = d[1 * 4 + bb] - d[3 * 4 + bb];
       }
-      float* vp = V + ((c >> 1) * 32 + w) * 2 + (c & 1);
+      float* vp = V + (tc >> 1) * VK + tw * 2 + (tc & 1);
 #pragma unroll
       for (int xi = 0; xi < 4; ++xi) {       // columns: (B^T d) B ; position p = xi*4 + nu
-        vp[((xi * 4 + 0) * 4) * 64] = tt[xi][0] - tt[xi][2];
-        vp[((xi * 4 + 1) * 4) * 64] = tt[xi][1] + tt[xi][2];
-        vp[((xi * 4 + 2) * 4) * 64] = tt[xi][2] - tt[xi][1];
-        vp[((xi * 4 + 3) * 4) * 64] = tt[xi][1] - tt[xi][3];
+        vp[((xi * 4 + 0) * 4) * VK] = tt[xi][0] - tt[xi][2];
+        vp[((xi * 4 + 1) * 4) * VK] = tt[xi][1] + tt[xi][2];
+        vp[((xi * 4 + 2) * 4) * VK] = tt[xi][2] - tt[xi][1];
+        vp[((xi * 4 + 3) * 4) * VK] = tt[xi][1] - tt[xi][3];
       }
     }
+    IMX_TS(3)
     __syncthreads();
-    // prefetch the next chunk (branch-free: the last iteration re-fetches its own chunk, unused)
-    IMX_GLOAD(ch + 1 < nchunk ? ch + 1 : ch)
-    // ---- 16 positions x 2 k-steps x 2 column blocks of v_mfma_f32_16x16x4_f32, operands one step ahead
+    IMX_TS(4)
+    IMX_TS(5)
+    const int nch = ch + 1 < nchunk ? ch + 1 : ch;   // next chunk (branch-free: the last iteration re-fetches its own, unused)
+    // ---- 16 positions x 2 k-steps x 2 column blocks of v_mfma_f32_16x16x4_f32 in 8 groups of 4
+    //      positions (8 MFMAs = 256 cycles).  A operands (V) come from LDS one group ahead, B operands
+    //      are already in registers; the next chunk's raw patch load/store rides along.
     {
-      const float* va = V + (lane >> 5) * 64 + (ib * 16 + (lane & 15)) * 2 + ((lane >> 4) & 1);
-      const float* ub = U + (lane >> 5) * 128 + cg * 64 + ((lane >> 4) & 1) * 16 + (lane & 15);
-      float af[2], bf[2][2];
-      af[0] = va[0];
-      bf[0][0] = ub[0];
-      bf[0][1] = ub[32];
+      const float* va = V + (lane >> 5) * VK + (ib * 16 + (lane & 15)) * 2 + ((lane >> 4) & 1);
+      float af[2][4];
 #pragma unroll
-      for (int st = 0; st < 32; ++st) {
-        const int cur = st & 1, nxt = cur ^ 1;
-        const int q = st & 15;                  // position
-        if (st + 1 < 32) {
-          const int q1 = (st + 1) & 15, s1 = (st + 1) >> 4;
-          af[nxt] = va[(q1 * 4 + 2 * s1) * 64];
-          bf[nxt][0] = ub[(q1 * 4 + 2 * s1) * 128];
-          bf[nxt][1] = ub[(q1 * 4 + 2 * s1) * 128 + 32];
+      for (int i = 0; i < 4; ++i) af[0][i] = va[(i * 4) * VK];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int cur = g & 1, nxt = cur ^ 1;
+        if (g == 0) { IMX_GRAW(nch * CK) }
+        if (g == 6) { IMX_SRAW() }
+        if (g + 1 < 8) {
+          const int s1 = (g + 1) >> 2, qb = ((g + 1) & 3) * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[nxt][i] = va[((qb + i) * 4 + 2 * s1) * VK];
         }
         __builtin_amdgcn_sched_barrier(0);
-        acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur], bf[cur][0], acc[q][0], 0, 0, 0);
-        acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur], bf[cur][1], acc[q][1], 0, 0, 0);
+        const int q0 = (g & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[q0 + i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i], bf[q0 + i][g >> 2][0], acc[q0 + i][0], 0, 0, 0);
+          acc[q0 + i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i], bf[q0 + i][g >> 2][1], acc[q0 + i][1], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    IMX_TS(6)
   }
-#undef IMX_GR
-#undef IMX_SR
-#undef IMX_GU
-#undef IMX_SU
-#undef IMX_GLOAD
-#undef IMX_LSTORE
+  if constexpr (TRACE) {
+    if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 4096)
+      for (int i = 0; i < 7; ++i) trace[blockIdx.x * 8 + i] = tph[i];
+  }
+#undef IMX_TS
+#undef IMX_GRAW
+#undef IMX_SRAW
+
 
   // ---- output transform Y = A^T M A, bias, ReLU, (2x2 max-pool), store.
   //      acc[p][jb][r]: wtile ib*16 + 4*(lane>>4) + r, channel n0 + cg*32 + jb*16 + (lane&15).
@@ -252,9 +298,28 @@ template <bool POOL, bool RELU, bool FIRST>
 hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = (a.W + OW - 1) / OW, tiles_y = (a.H + OH - 1) / OH;
   dim3 grid((unsigned)(tiles_x * tiles_y * a.B), (unsigned)(a.Cout / NT));
-  size_t lds = (size_t)(RAW_PAD + VSZ + USZ + (FIRST ? IMG_H * IMG_W : 0)) * sizeof(float);
+  size_t lds = (size_t)(VSZ + RAW + (FIRST ? IMG_H * IMG_W + 9 * 64 + 64 : 0)) * sizeof(float);
+  if (getenv("IMX_WINO_TRACE")) {      // bring-up instrumentation: per-phase cycle counts of the first 4096 workgroups
+    static unsigned* dbuf = nullptr;
+    if (!dbuf) (void)hipMalloc(&dbuf, 4096 * 8 * sizeof(unsigned));
+    (void)hipMemsetAsync(dbuf, 0, 4096 * 8 * sizeof(unsigned), s);
+    auto kt = conv3x3_wino<POOL, RELU, FIRST, true>;
+    hipLaunchKernelGGL(kt, grid, dim3(256), lds, s, a, tiles_x, tiles_y, dbuf);
+    (void)hipStreamSynchronize(s);
+    static unsigned host[4096 * 8];
+    (void)hipMemcpy(host, dbuf, sizeof(host), hipMemcpyDeviceToHost);
+    const int n = grid.x < 4096 ? (int)grid.x : 4096;
+    double sum[7] = {0};
+    for (int i = 0; i < n; ++i) for (int j = 0; j < 7; ++j) sum[j] += host[i * 8 + j];
+    const int nchunk = a.Cin / CK;
+    fprintf(stderr, "[wino trace] H=%d W=%d Cin=%d Cout=%d pool=%d first=%d grid=%u | cycles/chunk: barrier1 %.0f  lstore %.0f  barrier2 %.0f  "
+                    "transform %.0f  barrier3 %.0f  gload %.0f  mfma %.0f\n", a.H, a.W, a.Cin, a.Cout, (int)POOL, (int)FIRST, grid.x,
+            sum[0] / n / nchunk, sum[1] / n / nchunk, sum[2] / n / nchunk, sum[3] / n / nchunk, sum[4] / n / nchunk,
+            sum[5] / n / nchunk, sum[6] / n / nchunk);
+    return hipGetLastError();
+  }
   auto k = conv3x3_wino<POOL, RELU, FIRST>;
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, tiles_x, tiles_y);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, tiles_x, tiles_y, (unsigned*)nullptr);
   return hipGetLastError();
 }
 }  // namespace

@@ -262,7 +262,8 @@ void put_conv3(const std::map<std::string, HostTensor>& raw, const std::string& 
 
 // Winograd F(2x2,3x3) weight transform U = G g G^T of folded direct-form weights w[tap][ci][co]
 // (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), laid out per (64-channel output group, 8-channel
-// input chunk) exactly as conv3x3_wino.hip stages it into LDS: [16 pos][ci>>1 (4)][co>>4 (4)][ci&1][16].
+// input chunk) as conv3x3_wino.hip's MFMA B fragments read it: [16 pos][ci>>2 (k-step)][co>>4][ci&3][16 co],
+// i.e. one wave load = 256 contiguous bytes.
 std::vector<float> wino_transform(const std::vector<float>& w, int cin, int cout) {
   const int nchunk = cin / 8, ncog = cout / 64;
   std::vector<float> u((size_t)ncog * nchunk * 8192, 0.f);
@@ -286,7 +287,7 @@ std::vector<float> wino_transform(const std::vector<float>& w, int cin, int cout
       const int cog = co / 64, col = co % 64, chunk = ci / 8, k = ci % 8;
       float* blk = u.data() + ((size_t)cog * nchunk + chunk) * 8192;
       for (int q = 0; q < 16; ++q)
-        blk[(((q * 4 + (k >> 1)) * 4 + (col >> 4)) * 2 + (k & 1)) * 16 + (col & 15)] = (float)uu[q / 4][q % 4];
+        blk[((((q * 2 + (k >> 2)) * 4 + (col >> 4)) * 4 + (k & 3)) * 16) + (col & 15)] = (float)uu[q / 4][q % 4];
     }
   return u;
 }

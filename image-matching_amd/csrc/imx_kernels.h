@@ -13,7 +13,7 @@ struct ConvArgs {
   const float* in2;
   int split;
   const float* w;     // [9][Cin][Cout]  (BN folded)
-  const float* wu;    // Winograd F(2x2,3x3) weights G g G^T: [Cout/64][Cin/8][16][4][4][2][16] (conv3x3_wino.hip)
+  const float* wu;    // Winograd F(2x2,3x3) weights G g G^T: [Cout/64][Cin/8][16 pos][2][4][4][16] (conv3x3_wino.hip)
   const float* bias;  // [Cout]
   const float* w1;    // FIRST mode: conv1a weights [9][64] and bias [64] (BN folded), Cin == 64
   const float* b1;
