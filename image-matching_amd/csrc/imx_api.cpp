@@ -34,6 +34,7 @@ struct DevBuf {
 struct ConvW {
   float* w = nullptr;    // direct form  [9][Cin][Cout]
   float* wu = nullptr;   // Winograd F(2x2,3x3) form (conv3x3_wino.hip layout)
+  float* wu4 = nullptr;  // Winograd F(2x2,3x3) form (conv3x3_wino4.hip layout)
   float* b = nullptr;
   int cin = 0, cout = 0;
 };
@@ -88,7 +89,7 @@ struct imx_handle_s {
   int det_B = 0, det_H = 0, det_W = 0, det_Hc = 0, det_Wc = 0, det_Ksel = 0;
   // debug / timing
   bool debug = false, timing = false;
-  bool use_wino = true;   // IMX_CONV=direct selects the direct-form 3x3 kernels (A/B, fallback)
+  int conv_mode = 1;      // 3x3 conv kernel: 0 direct (IMX_CONV=direct), 1 Winograd 16x16x4 (wino), 2 Winograd 32x32x2 pipelined (wino4)
   std::map<std::string, Tap> taps;
   std::vector<TimedEvent> events;
   std::vector<TimingRow> report;
@@ -264,7 +265,7 @@ void put_conv3(const std::map<std::string, HostTensor>& raw, const std::string& 
 // (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), laid out per (64-channel output group, 8-channel
 // input chunk) as conv3x3_wino.hip's MFMA B fragments read it: [16 pos][ci>>2 (k-step)][co>>4][ci&3][16 co],
 // i.e. one wave load = 256 contiguous bytes.
-std::vector<float> wino_transform(const std::vector<float>& w, int cin, int cout) {
+std::vector<float> wino_transform(const std::vector<float>& w, int cin, int cout, int layout = 0) {
   const int nchunk = cin / 8, ncog = cout / 64;
   std::vector<float> u((size_t)ncog * nchunk * 8192, 0.f);
   for (int co = 0; co < cout; ++co)
@@ -286,8 +287,11 @@ std::vector<float> wino_transform(const std::vector<float>& w, int cin, int cout
       }
       const int cog = co / 64, col = co % 64, chunk = ci / 8, k = ci % 8;
       float* blk = u.data() + ((size_t)cog * nchunk + chunk) * 8192;
-      for (int q = 0; q < 16; ++q)
-        blk[((((q * 2 + (k >> 2)) * 4 + (col >> 4)) * 4 + (k & 3)) * 16) + (col & 15)] = (float)uu[q / 4][q % 4];
+      for (int q = 0; q < 16; ++q) {
+        const size_t idx = layout == 0 ? (size_t)((((q * 2 + (k >> 2)) * 4 + (col >> 4)) * 4 + (k & 3)) * 16) + (col & 15)
+                                       : (size_t)(q * 8 + k) * 64 + col;     // conv3x3_wino4.hip: [pos][ci][co]
+        blk[idx] = (float)uu[q / 4][q % 4];
+      }
     }
   return u;
 }
@@ -298,6 +302,7 @@ int make_conv(imx_handle_t h, ConvW& out, const std::map<std::string, HostTensor
   put_conv3(raw, conv, bn, cin, cout, cout, 0, w, b);
   out.w = upload(h, w);
   out.wu = upload(h, wino_transform(w, cin, cout));
+  out.wu4 = upload(h, wino_transform(w, cin, cout, 1));
   out.b = upload(h, b);
   out.cin = cin;
   out.cout = cout;
@@ -360,6 +365,7 @@ int finalize_superpoint(imx_handle_t h) {
     put_conv3(raw, "convDa", bn ? "bnDa" : "", 128, 256, 512, 256, w, b);
     h->conv[7].w = upload(h, w);
     h->conv[7].wu = upload(h, wino_transform(w, 128, 512));
+    h->conv[7].wu4 = upload(h, wino_transform(w, 128, 512, 1));
     h->conv[7].b = upload(h, b);
     h->conv[7].cin = 128;
     h->conv[7].cout = 512;
@@ -480,9 +486,9 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   auto conv = [&](const char* name, const ConvW& w, const float* in, float* out, int hh, int ww, bool pool, bool first) -> int {
     ConvArgs a{};
     a.in = in; a.in2 = first ? img1 : nullptr; a.split = first ? split : 0;
-    a.w = w.w; a.wu = w.wu; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
+    a.w = w.w; a.wu = w.wu; a.wu4 = w.wu4; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
     a.B = B; a.H = hh; a.W = ww; a.Cin = w.cin; a.Cout = w.cout; a.relu = 1; a.pool = pool ? 1 : 0; a.first = first ? 1 : 0;
-    RUN(name, h->use_wino ? launch_conv3x3_wino(a, s) : launch_conv3x3(a, s));
+    RUN(name, h->conv_mode == 2 ? launch_conv3x3_wino4(a, s) : h->conv_mode == 1 ? launch_conv3x3_wino(a, s) : launch_conv3x3(a, s));
     return 0;
   };
   if (conv("conv1ab_pool", h->conv[0], img0, a1, H, W, true, true)) return -1;
@@ -674,7 +680,7 @@ int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
   imx_handle_s* h = new imx_handle_s();
   h->device = device_id;
   h->cfg = *cfg;
-  if (const char* e = getenv("IMX_CONV")) h->use_wino = std::string(e) != "direct";
+  if (const char* e = getenv("IMX_CONV")) h->conv_mode = std::string(e) == "direct" ? 0 : std::string(e) == "wino4" ? 2 : 1;
   build_expected(h);
   *out = h;
   return 0;
