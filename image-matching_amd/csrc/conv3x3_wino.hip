@@ -43,13 +43,15 @@ constexpr int VK = 72;                                    // V channel-pair stri
 constexpr int VSZ = 16 * 4 * VK;                          // 4608
 constexpr int USZ = 16 * 2 * 4 * 4 * 16;                  // 8192 = [16 pos][2 k-steps][4 co-blocks][4 k][16 co] per (64 co, 8 ci)
 constexpr int IMG_H = RH + 2, IMG_W = RW + 2;             // FIRST: image patch 12 x 20
+constexpr int RSF = 68;                                   // FIRST: conv1a patch [10*18 px][64 ch], pixel stride 68 (conflict-free)
+constexpr int RAWF = RH * RW * RSF;                       // 12240
 
 template <bool POOL, bool RELU, bool FIRST, bool TRACE = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, int tiles_y, unsigned* trace = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* V = smem;
   float* raw = V + VSZ;                 // raw input patch [10][18][12]
-  float* img = raw + RAW;               // FIRST only: image patch, conv1a weights + bias
+  float* img = raw + (FIRST ? RAWF : RAW);   // FIRST only: image patch, conv1a weights + bias
   float* w1s = img + IMG_H * IMG_W;
   float* b1s = w1s + 9 * 64;
 
@@ -74,6 +76,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
     }
     for (int e = tid; e < 9 * 64; e += 256) w1s[e] = p.w1[e];
     if (tid < 64) b1s[tid] = p.b1[tid];
+    __syncthreads();
+    // conv1a + folded BN + ReLU for ALL 64 channels of the 10x18 halo patch, once per workgroup
+    // (item = pixel x 16 channels; positions outside the image are conv1b's zero padding)
+    for (int e = tid; e < RH * RW * 4; e += 256) {
+      const int pix = e >> 2, cq = (e & 3) * 16;
+      const int py = pix / RW, px = pix % RW;
+      const int gy = y0 + py - 1, gx = x0 + px - 1;
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = 0.f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = b1s[cq + j];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+          const float iv = img[(py + tp / 3) * IMG_W + px + tp % 3];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[j] = fmaf(iv, w1s[tp * 64 + cq + j], v[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      float4* dst = reinterpret_cast<float4*>(raw + pix * RSF + cq);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    }
   }
 
   f32x4 acc[16][2];
@@ -136,40 +164,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
     __syncthreads();               // previous chunk's MFMA phase is done with raw / V / U
     IMX_TS(0)
     float d[16];
-    if constexpr (FIRST) {
-      // conv1a + folded BN + ReLU for channels [8ch, 8ch+8) at the 10x18 halo pixels (weights from
-      // LDS, broadcast reads); positions outside the image are conv1b's zero padding.
-      if (tid < RH * RW) {
-        const int py = tid / RW, px = tid % RW;
-        const int gy = y0 + py - 1, gx = x0 + px - 1;
-        const int cb = ch * CK;
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-          float im9[9];
-#pragma unroll
-          for (int tp = 0; tp < 9; ++tp) im9[tp] = img[(py + tp / 3) * IMG_W + px + tp % 3];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = b1s[cb + j];
-#pragma unroll
-          for (int tp = 0; tp < 9; ++tp)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaf(im9[tp], w1s[tp * 64 + cb + j], v[j]);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        float4* dst = reinterpret_cast<float4*>(raw + (py * RPITCH + px) * RS);
-        dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-        dst[1] = make_float4(v[4], v[5], v[6], v[7]);
-      }
-      IMX_TS(1)
-      __syncthreads();
-      IMX_TS(2)
-    } else {
-      IMX_TS(1)
-      IMX_TS(2)
-    }
+    IMX_TS(1)
+    IMX_TS(2)
     // ---- this chunk's B operands (U = G g G^T) straight from global/L2 into 64 registers: the layout
     //      [pos][k-step][co-block][4 k][16 co] makes every wave load 256 contiguous bytes; they land
     //      while the input transform runs, so the MFMA loop below touches no global memory except the
@@ -185,11 +181,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
       }
     // ---- input transform  V = B^T d B  (LDS raw -> registers -> LDS V), thread = (channel tc, wtile tw)
     {
-      const float* rp = raw + ((2 * twr) * RPITCH + 2 * twc) * RS + tc;
+      constexpr int RSX = FIRST ? RSF : RS;
+      const float* rp = raw + ((2 * twr) * RPITCH + 2 * twc) * RSX + tc + (FIRST ? ch * CK : 0);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) d[a * 4 + bb] = rp[(a * RPITCH + bb) * RS];
+        for (int bb = 0; bb < 4; ++bb) d[a * 4 + bb] = rp[(a * RPITCH + bb) * RSX];
       float tt[4][4];
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb) {       // rows: B^T d
@@ -253,10 +250,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
 
   // ---- output transform Y = A^T M A, bias, ReLU, (2x2 max-pool), store.
   //      acc[p][jb][r]: wtile ib*16 + 4*(lane>>4) + r, channel n0 + cg*32 + jb*16 + (lane&15).
+  //      The full-resolution tile goes through LDS (free after the loop) so HBM sees whole 256-byte
+  //      channel rows written as float4: per-lane dword stores at a pixel stride are store-issue bound
+  //      (measured on the wino4 variant: 19k -> 7k cycles).  The pooled tile is 4x smaller: direct stores.
+  constexpr int OS = NT + 4;
+  float* Ot = smem;
+  if constexpr (!POOL) __syncthreads();          // every wave is done with V / raw
 #pragma unroll
   for (int jb = 0; jb < 2; ++jb) {
-    const int co = n0 + cg * 32 + jb * 16 + (lane & 15);
-    const float bs = p.bias[co];
+    const int col = cg * 32 + jb * 16 + (lane & 15);
+    const float bs = p.bias[n0 + col];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int w = ib * 16 + 4 * (lane >> 4) + r;
@@ -277,19 +280,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
         const int Ho = H >> 1, Wo = W >> 1;
         const int oy = (y0 >> 1) + wr, ox = (x0 >> 1) + wc;
         if (oy < Ho && ox < Wo)
-          p.out[((size_t)(b * Ho + oy) * Wo + ox) * Cout + co] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
+          p.out[((size_t)(b * Ho + oy) * Wo + ox) * Cout + n0 + col] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
       } else {
-        const int oy = y0 + 2 * wr, ox = x0 + 2 * wc;
-        float* o = p.out + ((size_t)(b * H + oy) * W + ox) * Cout + co;
-        if (oy < H) {
-          if (ox < W) o[0] = y00;
-          if (ox + 1 < W) o[Cout] = y01;
-        }
-        if (oy + 1 < H) {
-          if (ox < W) o[(size_t)W * Cout] = y10;
-          if (ox + 1 < W) o[(size_t)W * Cout + Cout] = y11;
-        }
+        float* o = Ot + ((2 * wr) * OW + 2 * wc) * OS + col;
+        o[0] = y00;
+        o[OS] = y01;
+        o[OW * OS] = y10;
+        o[OW * OS + OS] = y11;
       }
+    }
+  }
+  if constexpr (!POOL) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < OH * OW * (NT / 4) / 256; ++it) {
+      const int e = tid + it * 256;
+      const int pix = e / (NT / 4), v4 = e % (NT / 4);
+      const int oy = y0 + pix / OW, ox = x0 + pix % OW;
+      if (oy < H && ox < W)
+        *reinterpret_cast<float4*>(p.out + ((size_t)(b * H + oy) * W + ox) * Cout + n0 + 4 * v4) =
+            *reinterpret_cast<const float4*>(Ot + pix * OS + 4 * v4);
     }
   }
 }
@@ -298,7 +308,8 @@ template <bool POOL, bool RELU, bool FIRST>
 hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = (a.W + OW - 1) / OW, tiles_y = (a.H + OH - 1) / OH;
   dim3 grid((unsigned)(tiles_x * tiles_y * a.B), (unsigned)(a.Cout / NT));
-  size_t lds = (size_t)(VSZ + RAW + (FIRST ? IMG_H * IMG_W + 9 * 64 + 64 : 0)) * sizeof(float);
+  size_t lds = (size_t)(VSZ + (FIRST ? RAWF + IMG_H * IMG_W + 9 * 64 + 64 : RAW)) * sizeof(float);
+  if (!POOL && lds < (size_t)OH * OW * (NT + 4) * sizeof(float)) lds = (size_t)OH * OW * (NT + 4) * sizeof(float);   // epilogue staging tile
   if (getenv("IMX_WINO_TRACE")) {      // bring-up instrumentation: per-phase cycle counts of the first 4096 workgroups
     static unsigned* dbuf = nullptr;
     if (!dbuf) (void)hipMalloc(&dbuf, 4096 * 8 * sizeof(unsigned));
