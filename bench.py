@@ -51,6 +51,8 @@ def algorithmic_work(B, H, W, d, K, kenc, iters, n_layers=18):
     H2, W2, H4, W4, Hc, Wc = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
     R = 2 * B * K
     w = {
+        # algorithmic = the reference's direct-convolution FLOPs; the Winograd F(2x2,3x3)
+        # kernels execute 2.25x fewer multiplies, so "achieved" can exceed the executed-FLOP rate
         "conv1ab_pool": ("mfma", 2.0 * I * H * W * (9 * 64 + 576 * 64)),
         "conv2a": ("mfma", 2.0 * I * H2 * W2 * 576 * 64),
         "conv2b_pool": ("mfma", 2.0 * I * H2 * W2 * 576 * 64),
@@ -235,8 +237,16 @@ def main():
             achieved, peak, unit = units / avg_s / 1e12, PEAK_MFMA_F32_TFLOPS, "TFLOP/s"
         else:
             achieved, peak, unit = units / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
+        traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (offline; profiles/r01_pmc_traffic.json)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            if pmc.get("pairs_per_gpu") == B and args.workload == "c3" and name in pmc["kernels"]:
+                traffic = pmc["kernels"][name]["traffic_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
         line["roofline"] = {"bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-                            "frac": round(achieved / peak, 4), "traffic": None, "kernel": name,
+                            "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": name,
                             "avg_launch_ms": round(ms / launches, 4), "share_of_gpu_time": round(ms / tot_ms, 4)}
         # whole-pair view: algorithmic dense FLOPs of the step / measured step time vs the fp32 MFMA peak
         per_step = {r[0]: r[1] / args.steps for r in rows}          # launches per step
