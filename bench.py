@@ -38,6 +38,7 @@ from image_matching_amd.superglue.models.matching_test import Matching         #
 WORKLOADS = {
     "c3": dict(H=480, W=640, d=128, K=1024, name="C3 SuperPoint+SuperGlue 640x480 d=128 1024 kpts 30 Sinkhorn iters"),
     "c5": dict(H=960, W=1280, d=256, K=2048, name="C5 SuperPoint+SuperGlue 1280x960 d=256 2048 kpts 100 Sinkhorn iters"),
+    "c2": dict(H=480, W=640, d=128, K=1024, name="C2 SuperPoint-only 640x480 d=128 NMS + top-1024 keypoints"),
 }
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
@@ -163,7 +164,14 @@ def main():
     img0 = torch.from_numpy(np.stack([p[0] for p in ims]))[:, None].to(device)
     img1 = torch.from_numpy(np.stack([p[1] for p in ims]))[:, None].to(device)
 
+    sp_only = args.workload == "c2"
+    img01 = torch.cat([img0, img1]) if sp_only else None
+
     def step():
+        if sp_only:                                  # C2: SuperPoint on 2B images, no SuperGlue / gather
+            eng = matching._shared.get_engine([0])
+            kp, sc, ds, cnt = eng.superpoint_batch(img01)
+            return {"counts0": cnt[:B], "counts1": cnt[B:], "matches0": cnt.new_zeros(1) + 1}, torch.zeros(world * B, 1)
         out = matching.match_batch(img0, img1)
         rec = shard.pack_records(pair_ids, out)
         return out, shard.gather_records(rec)
@@ -198,17 +206,19 @@ def main():
     # harness checks: every image yields exactly K keypoints; the gather holds every pair once
     c0, c1 = out["counts0"].cpu().numpy(), out["counts1"].cpu().numpy()
     assert (c0 == K).all() and (c1 == K).all(), f"keypoint counts != {K}: {c0} {c1}"
-    assert rec.shape == (world * B, shard.record_width(K))
-    assert sorted(rec[:, 0].long().cpu().tolist()) == list(range(world * B))
+    if not sp_only:
+        assert rec.shape == (world * B, shard.record_width(K))
+        assert sorted(rec[:, 0].long().cpu().tolist()) == list(range(world * B))
     n_matches = int((out["matches0"] > -1).sum().item())
     assert n_matches > 0
 
     total_pairs = world * B * args.steps
-    value = total_pairs / dt
+    value = (2 * total_pairs if sp_only else total_pairs) / dt
     line = {
-        "metric": "image-pairs/sec (640x480, 1024 kpts, 30 Sinkhorn iters)" if args.workload == "c3"
-                  else "image-pairs/sec (1280x960, 2048 kpts, 100 Sinkhorn iters)",
-        "value": round(value, 3), "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": {"c3": "image-pairs/sec (640x480, 1024 kpts, 30 Sinkhorn iters)",
+                   "c5": "image-pairs/sec (1280x960, 2048 kpts, 100 Sinkhorn iters)",
+                   "c2": "images/sec (SuperPoint-only, 640x480, NMS + top-1024 kpts)"}[args.workload],
+        "value": round(value, 3), "unit": "images/s" if sp_only else "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B,
@@ -225,7 +235,7 @@ def main():
         eng.timing_reset()
         eng.set_timing(True)
         for _ in range(args.steps):
-            matching.match_batch(img0, img1)
+            step()
         rows = eng.timing_report()
         eng.set_timing(False)
         eng.timing_reset()
@@ -255,7 +265,7 @@ def main():
         line["roofline"]["kernels"] = {r[0]: {"launches": r[1], "ms_per_step": round(r[2] / args.steps, 4)} for r in rows}
     if world > 1:
         barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not sp_only:
         log("cpu baseline (oracle on host cores)")
         line["cpu_baseline"] = cpu_baseline(wl, cfg, sd_sp, sd_sg)
     if rank == 0:

@@ -463,7 +463,7 @@ int gemm(imx_handle_t h, hipStream_t s, const char* name, const GemmW& W, const 
 
 // ----------------------------------------------------------------------------- SuperPoint
 int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, int B, int H, int W, int32_t* counts_out,
-              hipStream_t s) {
+              hipStream_t s, bool dense_only = false) {
   if (!h->finalized[IMX_NET_SUPERPOINT]) return fail(h, "SuperPoint weights not finalized");
   if (B <= 0 || H < 8 || W < 8) return fail(h, "bad image batch shape B=%d H=%d W=%d", B, H, W);
   const imx_config_t& c = h->cfg;
@@ -502,6 +502,8 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   const int rows = B * Hc * Wc;
   if (gemm(h, s, "convPb", h->pb, hd, 512, 256, nullptr, 0, 0, nullptr, 0, semi, 65, rows, false)) return -1;
   if (gemm(h, s, "convDb", h->db, hd + 256, 512, 256, nullptr, 0, 0, nullptr, 0, dense, d, rows, false)) return -1;
+  h->det_Hc = Hc; h->det_Wc = Wc;
+  if (dense_only) { h->det_B = 0; return 0; }     // network only (imx_superpoint_dense)
   RUN("softmax_shuffle", launch_softmax_shuffle(semi, 65, smap, B, Hc, Wc, s));
   RUN("nms", launch_nms(smap, nms, B, H8, W8, c.nms_radius, s));
 
@@ -744,6 +746,17 @@ int imx_superpoint_detect(imx_handle_t h, const float* img_dev, int B, int H, in
   return sp_detect(h, img_dev, nullptr, B, B, H, W, counts_dev, as_stream(stream));
 }
 
+int imx_superpoint_dense(imx_handle_t h, const float* img_dev, int B, int H, int W, float* semi_dev, float* desc_dev, void* stream) {
+  if (!h) return -1;
+  HIP_OK(h, hipSetDevice(h->device));
+  hipStream_t s = as_stream(stream);
+  if (sp_detect(h, img_dev, nullptr, B, B, H, W, nullptr, s, true)) return -1;
+  RUN("dense_export", launch_dense_export(static_cast<const float*>(h->bufs["sp.semi"].p), 65,
+                                          static_cast<const float*>(h->bufs["sp.dense"].p), h->cfg.descriptor_dim, semi_dev,
+                                          desc_dev, B, h->det_Hc, h->det_Wc, h->cfg.sp_variant == IMX_SP_VARIANT_OFFICIAL, s));
+  return 0;
+}
+
 int imx_superpoint_describe(imx_handle_t h, int B, int Kcap, float* kpts_dev, float* scores_dev, float* desc_dev, void* stream) {
   if (!h) return -1;
   HIP_OK(h, hipSetDevice(h->device));
@@ -793,6 +806,19 @@ int imx_op_nms(imx_handle_t h, const float* scores_dev, float* out_dev, int B, i
   HIP_OK(h, hipSetDevice(h->device));
   hipStream_t s = as_stream(stream);
   RUN("nms", launch_nms(scores_dev, out_dev, B, H, W, radius, s));
+  return 0;
+}
+
+int imx_estimate_affine_partial(imx_handle_t h, const float* kpts0_dev, const float* kpts1_dev, const int64_t* matches0_dev,
+                                const int32_t* counts0_dev, int B, int K, float ransac_threshold, int hypotheses, uint32_t seed,
+                                float* M_dev, uint8_t* inlier_dev, int32_t* n_inliers_dev, void* stream) {
+  if (!h) return -1;
+  HIP_OK(h, hipSetDevice(h->device));
+  hipStream_t s = as_stream(stream);
+  if (B <= 0 || K <= 0 || K > 8192) return fail(h, "imx_estimate_affine_partial: bad shape B=%d K=%d (K <= 8192)", B, K);
+  RansacArgs a{kpts0_dev, kpts1_dev, reinterpret_cast<const long long*>(matches0_dev), counts0_dev, B, K, ransac_threshold,
+               hypotheses, seed, M_dev, inlier_dev, n_inliers_dev};
+  RUN("ransac", launch_ransac(a, s));
   return 0;
 }
 

@@ -55,6 +55,9 @@ hipError_t launch_score_gemm(const ScoreArgs& a, hipStream_t s);
 // ---------------------------------------------------------------- SuperPoint tail
 // softmax over 65 channels + drop dustbin + 8x8 pixel shuffle.  semi: (B,Hc,Wc,ld) -> scores (B,8Hc,8Wc)
 hipError_t launch_softmax_shuffle(const float* semi, int ld, float* scores, int B, int Hc, int Wc, hipStream_t s);
+// channels-last semi / raw descriptors -> reference (B,C,Hc,Wc) tensors, descriptors divided by their channel norm
+hipError_t launch_dense_export(const float* semi, int ld, const float* dense, int d, float* semi_out, float* desc_out,
+                               int B, int Hc, int Wc, int eps_mode, hipStream_t s);
 // simple_nms (3 rounds, radius r<=8) fused; out = where(max_mask, scores, 0)
 hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int radius, hipStream_t s);
 // threshold + border removal + row-major compaction, then top-k (score desc, index asc on ties).
@@ -130,5 +133,19 @@ struct MatchArgs {
   int64_t* matches0; int64_t* matches1; float* ms0; float* ms1;  // (B,N0) / (B,N1)
 };
 hipError_t launch_matches(const MatchArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- registration post-step
+// RANSAC 4-DoF similarity ("partial affine") on the matched keypoints of each pair.
+struct RansacArgs {
+  const float* kpts0; const float* kpts1;   // (B,K,2) (x,y)
+  const long long* matches0;                // (B,K) index into kpts1 or -1
+  const int* counts0;                       // (B) valid keypoints per pair, may be null
+  int B, K;
+  float threshold; int hypotheses; unsigned seed;
+  float* M;                                 // (B,2,3)
+  unsigned char* inlier;                    // (B,K) 1 = matched and inlier of the RANSAC model
+  int* n_inliers;                           // (B) 0 = no fit (fewer than 4 matches)
+};
+hipError_t launch_ransac(const RansacArgs& a, hipStream_t s);
 
 }  // namespace imx

@@ -1,0 +1,174 @@
+// registration.hip — RANSAC partial-affine (4-DoF similarity) fit on matched keypoints, one
+// workgroup per image pair.  GPU counterpart of the post-step inside the reference's timed region,
+// cv2.estimateAffinePartial2D(mkpts0, mkpts1, method=cv2.RANSAC, ransacReprojThreshold=7)
+// (superpoint_glue_test.py:86-92; superpoint_flann_test.py:84-90) — SURVEY §8(f) rank 1.
+// OpenCV's arithmetic (its RNG, LMedS/LM refinement) is third-party and absent from the reference
+// tree: parity is against oracle/ransac_ref.py, which uses the same counter-based hypothesis
+// sequence, so inlier masks are comparable bit for bit; parity vs OpenCV itself is unpinned.
+#include "imx_kernels.h"
+
+namespace imx {
+namespace {
+
+__device__ __forceinline__ unsigned mix32(unsigned x) {     // murmur3 finaliser
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+
+// block-wide sum of a double over 256 threads (LDS scratch of 4 doubles)
+__device__ double block_sum(double v, double* scratch) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+__global__ __launch_bounds__(256) void ransac_similarity_kernel(RansacArgs a) {
+  extern __shared__ float sm[];
+  float* sx = sm;               // matched source / destination coordinates
+  float* sy = sx + a.K;
+  float* dx = sy + a.K;
+  float* dy = dx + a.K;
+  __shared__ int s_n, s_best_cnt;
+  __shared__ int wcnt[4], wh[4];
+  __shared__ float s_model[4];
+  __shared__ double dscr[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* k0 = a.kpts0 + (size_t)b * a.K * 2;
+  const float* k1 = a.kpts1 + (size_t)b * a.K * 2;
+  const long long* m0 = a.matches0 + (size_t)b * a.K;
+  const int cnt0 = a.counts0 ? a.counts0[b] : a.K;
+
+  // ---- 1. ordered compaction of the matched pairs (index order, as kpts0[valid] in the reference)
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < a.K; i0 += 256) {
+    const int i = i0 + tid;
+    const long long j = (i < cnt0) ? m0[i] : -1;
+    const bool v = j >= 0;
+    const unsigned long long bal = __ballot(v);
+    if (lane == 0) wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_n;
+    for (int w = 0; w < wave; ++w) off += wcnt[w];
+    if (v) {
+      const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+      sx[pos] = k0[2 * i]; sy[pos] = k0[2 * i + 1];
+      dx[pos] = k1[2 * j]; dy[pos] = k1[2 * j + 1];
+    }
+    __syncthreads();
+    if (tid == 0) s_n += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+  const int n = s_n;
+  float* M = a.M + (size_t)b * 6;
+  if (n <= 3) {                 // the reference only fits when len(mkpts0) > 3 (:86)
+    if (tid < 6) M[tid] = 0.f;
+    if (tid == 0) a.n_inliers[b] = 0;
+    for (int i = tid; i < a.K; i += 256) a.inlier[(size_t)b * a.K + i] = 0;
+    return;
+  }
+  const float thr2 = a.threshold * a.threshold;
+
+  // ---- 2. hypotheses: similarity through two matches, inlier count over all matches
+  int best_cnt = -1, best_h = 0x7fffffff;
+  for (int h = tid; h < a.hypotheses; h += 256) {
+    const unsigned r = mix32(a.seed ^ (0x9E3779B9u * (unsigned)(b + 1)) ^ (0x85EBCA6Bu * (unsigned)(h + 1)));
+    const int i = (int)(r % (unsigned)n);
+    int j = (int)(mix32(r + 0x27D4EB2Fu) % (unsigned)(n - 1));
+    if (j >= i) ++j;
+    const float px = sx[j] - sx[i], py = sy[j] - sy[i];
+    const float qx = dx[j] - dx[i], qy = dy[j] - dy[i];
+    const float den = px * px + py * py;
+    int cnt = -1;
+    if (den > 1e-12f) {
+      const float ca = (qx * px + qy * py) / den, cb = (qy * px - qx * py) / den;   // (q2-q1)/(p2-p1) as complex
+      const float tx = dx[i] - (ca * sx[i] - cb * sy[i]), ty = dy[i] - (cb * sx[i] + ca * sy[i]);
+      cnt = 0;
+      for (int k = 0; k < n; ++k) {
+        const float ex = ca * sx[k] - cb * sy[k] + tx - dx[k], ey = cb * sx[k] + ca * sy[k] + ty - dy[k];
+        cnt += (ex * ex + ey * ey < thr2) ? 1 : 0;
+      }
+    }
+    if (cnt > best_cnt) { best_cnt = cnt; best_h = h; }      // ascending h per thread: first best kept
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int oc = __shfl_xor(best_cnt, o), oh = __shfl_xor(best_h, o);
+    if (oc > best_cnt || (oc == best_cnt && oh < best_h)) { best_cnt = oc; best_h = oh; }
+  }
+  if (lane == 0) { wcnt[wave] = best_cnt; wh[wave] = best_h; }
+  __syncthreads();
+  if (tid == 0) {
+    int bc = wcnt[0], bh = wh[0];
+    for (int w = 1; w < 4; ++w)
+      if (wcnt[w] > bc || (wcnt[w] == bc && wh[w] < bh)) { bc = wcnt[w]; bh = wh[w]; }
+    s_best_cnt = bc;
+    // recompute the winning model
+    const unsigned r = mix32(a.seed ^ (0x9E3779B9u * (unsigned)(b + 1)) ^ (0x85EBCA6Bu * (unsigned)(bh + 1)));
+    const int i = (int)(r % (unsigned)n);
+    int j = (int)(mix32(r + 0x27D4EB2Fu) % (unsigned)(n - 1));
+    if (j >= i) ++j;
+    const float px = sx[j] - sx[i], py = sy[j] - sy[i], qx = dx[j] - dx[i], qy = dy[j] - dy[i];
+    const float den = px * px + py * py;
+    const float ca = (qx * px + qy * py) / den, cb = (qy * px - qx * py) / den;
+    s_model[0] = ca; s_model[1] = cb;
+    s_model[2] = dx[i] - (ca * sx[i] - cb * sy[i]);
+    s_model[3] = dy[i] - (cb * sx[i] + ca * sy[i]);
+  }
+  __syncthreads();
+  if (s_best_cnt < 2) {
+    if (tid < 6) M[tid] = 0.f;
+    if (tid == 0) a.n_inliers[b] = 0;
+    for (int i = tid; i < a.K; i += 256) a.inlier[(size_t)b * a.K + i] = 0;
+    return;
+  }
+  // ---- 3. least-squares similarity on the inliers of the best hypothesis (double accumulation)
+  const float ca = s_model[0], cb = s_model[1], tx = s_model[2], ty = s_model[3];
+  double c = 0, spx = 0, spy = 0, sqx = 0, sqy = 0;
+  for (int k = tid; k < n; k += 256) {
+    const float ex = ca * sx[k] - cb * sy[k] + tx - dx[k], ey = cb * sx[k] + ca * sy[k] + ty - dy[k];
+    if (ex * ex + ey * ey < thr2) { c += 1; spx += sx[k]; spy += sy[k]; sqx += dx[k]; sqy += dy[k]; }
+  }
+  c = block_sum(c, dscr); spx = block_sum(spx, dscr); spy = block_sum(spy, dscr);
+  sqx = block_sum(sqx, dscr); sqy = block_sum(sqy, dscr);
+  const double mpx = spx / c, mpy = spy / c, mqx = sqx / c, mqy = sqy / c;
+  double den = 0, dot = 0, crs = 0;
+  for (int k = tid; k < n; k += 256) {
+    const float ex = ca * sx[k] - cb * sy[k] + tx - dx[k], ey = cb * sx[k] + ca * sy[k] + ty - dy[k];
+    if (ex * ex + ey * ey < thr2) {
+      const double ux = sx[k] - mpx, uy = sy[k] - mpy, vx = dx[k] - mqx, vy = dy[k] - mqy;
+      den += ux * ux + uy * uy; dot += ux * vx + uy * vy; crs += ux * vy - uy * vx;
+    }
+  }
+  den = block_sum(den, dscr); dot = block_sum(dot, dscr); crs = block_sum(crs, dscr);
+  if (tid == 0) {
+    const double fa = den > 1e-12 ? dot / den : ca, fb = den > 1e-12 ? crs / den : cb;
+    M[0] = (float)fa; M[1] = (float)(-fb); M[2] = (float)(mqx - (fa * mpx - fb * mpy));
+    M[3] = (float)fb; M[4] = (float)fa;    M[5] = (float)(mqy - (fb * mpx + fa * mpy));
+    a.n_inliers[b] = (int)c;
+  }
+  // ---- 4. inlier mask in keypoint0 index space (mask of the RANSAC model, as OpenCV reports it)
+  for (int i = tid; i < a.K; i += 256) {
+    const long long j = (i < cnt0) ? m0[i] : -1;
+    unsigned char v = 0;
+    if (j >= 0) {
+      const float x = k0[2 * i], y = k0[2 * i + 1];
+      const float ex = ca * x - cb * y + tx - k1[2 * j], ey = cb * x + ca * y + ty - k1[2 * j + 1];
+      v = (ex * ex + ey * ey < thr2) ? 1 : 0;
+    }
+    a.inlier[(size_t)b * a.K + i] = v;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_ransac(const RansacArgs& a, hipStream_t s) {
+  if (a.K <= 0 || a.B <= 0 || a.hypotheses <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ransac_similarity_kernel, dim3((unsigned)a.B), dim3(256), (size_t)a.K * 4 * sizeof(float), s, a);
+  return hipGetLastError();
+}
+
+}  // namespace imx

@@ -40,6 +40,27 @@ __global__ __launch_bounds__(256) void softmax_shuffle_kernel(const float* __res
   scores[((size_t)b * Hc * 8 + (size_t)y * 8 + (lane >> 3)) * W8 + x * 8 + (lane & 7)] = e / sum;
 }
 
+// ------------------------------------------------------------------ dense export (label-export / training forward)
+// One wave per 8x8 cell: channels-last semi (B,Hc,Wc,ld) and raw descriptors (B,Hc,Wc,d) ->
+// reference layout semi (B,65,Hc,Wc), desc (B,d,Hc,Wc) divided by its channel norm
+// (superpoint/models/superpoint_train.py:46-55; same arithmetic as superpoint_test.py:119-126).
+__global__ __launch_bounds__(256) void dense_export_kernel(const float* __restrict__ semi, int ld, const float* __restrict__ dense,
+                                                           int d, float* __restrict__ semi_out, float* __restrict__ desc_out,
+                                                           int B, int Hc, int Wc, int eps_mode) {
+  const int lane = threadIdx.x & 63;
+  const long cell = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long total = (long)B * Hc * Wc;
+  if (cell >= total) return;
+  const long hw = (long)Hc * Wc;
+  const long b = cell / hw, yx = cell % hw;
+  for (int c = lane; c < 65; c += 64) semi_out[(b * 65 + c) * hw + yx] = semi[cell * ld + c];
+  float s2 = 0.f;
+  for (int c = lane; c < d; c += 64) { const float v = dense[cell * d + c]; s2 += v * v; }
+  float dn = sqrtf(wave_sum(s2));
+  if (eps_mode) dn = fmaxf(dn, 1e-12f);
+  for (int c = lane; c < d; c += 64) desc_out[(b * d + c) * hw + yx] = dense[cell * d + c] / dn;
+}
+
 // ------------------------------------------------------------------ simple_nms
 // Output tile T x T, halo 5r (five dependent radius-r max-pools).  Separable row/column maxima
 // are exact, so the result is bit-identical to the reference given the same score map.
@@ -523,6 +544,14 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
 }
 
 }  // namespace
+
+hipError_t launch_dense_export(const float* semi, int ld, const float* dense, int d, float* semi_out, float* desc_out,
+                               int B, int Hc, int Wc, int eps_mode, hipStream_t s) {
+  long cells = (long)B * Hc * Wc;
+  hipLaunchKernelGGL(dense_export_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, semi, ld, dense, d, semi_out,
+                     desc_out, B, Hc, Wc, eps_mode);
+  return hipGetLastError();
+}
 
 hipError_t launch_softmax_shuffle(const float* semi, int ld, float* scores, int B, int Hc, int Wc, hipStream_t s) {
   long cells = (long)B * Hc * Wc;

@@ -123,6 +123,33 @@ class Engine:
             self._check(self.lib.imx_superpoint_describe(self.handle, B, K, _ptr(kpts), _ptr(scores), _ptr(desc), st))
         return kpts, scores, desc, n
 
+    def superpoint_dense(self, x):
+        """Dense forward (superpoint_train.py:31-57): semi (B,65,H/8,W/8), desc (B,d,H/8,W/8) unit-norm."""
+        x = self._image(x)
+        B, _, H, W = x.shape
+        Hc, Wc = H // 2 // 2 // 2, W // 2 // 2 // 2
+        semi = torch.empty(B, 65, Hc, Wc, dtype=torch.float32, device=self.device)
+        desc = torch.empty(B, self.d, Hc, Wc, dtype=torch.float32, device=self.device)
+        self._check(self.lib.imx_superpoint_dense(self.handle, _ptr(x), B, H, W, _ptr(semi), _ptr(desc), _stream(self.device)))
+        return semi, desc
+
+    def superpoint_batch(self, x):
+        """Throughput path: SuperPoint with fixed max_keypoints = K > 0, no host sync.  Returns padded
+        (kpts (B,K,2), scores (B,K), desc (B,K,d), counts (B) int32); rows >= count are zero."""
+        x = self._image(x)
+        B, _, H, W = x.shape
+        K = self.max_keypoints
+        if K <= 0:
+            raise ImxError("superpoint_batch needs max_keypoints > 0")
+        counts = torch.empty(B, dtype=torch.int32, device=self.device)
+        kpts = torch.empty(B, K, 2, dtype=torch.float32, device=self.device)
+        scores = torch.empty(B, K, dtype=torch.float32, device=self.device)
+        desc = torch.empty(B, K, self.d, dtype=torch.float32, device=self.device)
+        st = _stream(self.device)
+        self._check(self.lib.imx_superpoint_detect(self.handle, _ptr(x), B, H, W, _ptr(counts), st))
+        self._check(self.lib.imx_superpoint_describe(self.handle, B, K, _ptr(kpts), _ptr(scores), _ptr(desc), st))
+        return kpts, scores, desc, counts
+
     def _image(self, x):
         if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 1:
             raise ImxError(f"expected an image tensor of shape (B,1,H,W), got {getattr(x, 'shape', type(x))}")
@@ -186,6 +213,28 @@ class Engine:
             _ptr(out["matches0"]), _ptr(out["matches1"]),
             _ptr(out["matching_scores0"]), _ptr(out["matching_scores1"]), _stream(dev)))
         return out
+
+    def estimate_affine_partial(self, kpts0, kpts1, matches0, counts0=None, ransac_thresh=7.0, hypotheses=512, seed=0):
+        """Batched RANSAC partial-affine fit (superpoint_glue_test.py:86-92) on the GPU.
+        kpts{0,1} (B,K,2), matches0 (B,K) int64.  Returns M (B,2,3), inlier mask (B,K) uint8, n_inliers (B) int32."""
+        dev = self.device
+        kpts0 = kpts0.to(dev, torch.float32).contiguous()
+        kpts1 = kpts1.to(dev, torch.float32).contiguous()
+        matches0 = matches0.to(dev, torch.int64).contiguous()
+        B, K0 = matches0.shape
+        K = max(K0, kpts1.shape[1])
+        if K0 < K:                        # pad side 0 (unmatched) so both sides share K; indices stay valid
+            kpts0 = torch.cat([kpts0, kpts0.new_zeros(B, K - K0, 2)], 1)
+            matches0 = torch.cat([matches0, matches0.new_full((B, K - K0), -1)], 1)
+        if kpts1.shape[1] < K:
+            kpts1 = torch.cat([kpts1, kpts1.new_zeros(B, K - kpts1.shape[1], 2)], 1)
+        M = torch.empty(B, 2, 3, dtype=torch.float32, device=dev)
+        inl = torch.empty(B, K, dtype=torch.uint8, device=dev)
+        ninl = torch.empty(B, dtype=torch.int32, device=dev)
+        self._check(self.lib.imx_estimate_affine_partial(self.handle, _ptr(kpts0), _ptr(kpts1), _ptr(matches0), _ptr(counts0),
+                                                         B, K, float(ransac_thresh), int(hypotheses), int(seed) & 0xFFFFFFFF,
+                                                         _ptr(M), _ptr(inl), _ptr(ninl), _stream(dev)))
+        return M, inl[:, :K0], ninl
 
     def op_nms(self, scores, radius):
         """simple_nms on a (B,H,W) score map (single-stage entry point, used by parity tests)."""

@@ -92,6 +92,12 @@ int imx_superpoint_detect(imx_handle_t h, const float* img_dev, int B, int H, in
 int imx_superpoint_describe(imx_handle_t h, int B, int Kcap, float* kpts_dev, float* scores_dev,
                             float* desc_dev, void* stream);
 
+/* Dense SuperPoint forward used by training / pseudo-label export (superpoint/models/superpoint_train.py:31-57):
+ * semi_dev (B,65,H/8,W/8) and desc_dev (B,d,H/8,W/8) in the reference's channel-major layout, descriptors divided
+ * by their channel norm (:53-54). */
+int imx_superpoint_dense(imx_handle_t h, const float* img_dev, int B, int H, int W,
+                         float* semi_dev, float* desc_dev, void* stream);
+
 /* SuperGlue.forward (superglue_test.py:230-285) on B pairs.
  *   kpts{0,1}_dev (B,N{0,1},2) (x,y) px;  scores{0,1}_dev (B,N{0,1});
  *   desc{0,1}_dev: element (b, c, i) at  b*desc_stride_b + c*desc_stride_c + i*desc_stride_n
@@ -119,6 +125,17 @@ int imx_match_pairs(imx_handle_t h, const float* img0_dev, const float* img1_dev
                     int32_t* counts0_dev, int32_t* counts1_dev, float* desc0_dev, float* desc1_dev,
                     int64_t* matches0_dev, int64_t* matches1_dev,
                     float* mscores0_dev, float* mscores1_dev, void* stream);
+
+/* Registration post-step inside the reference's timed region: RANSAC partial-affine (4-DoF similarity) fit
+ * of kpts0[valid] -> kpts1[matches0[valid]], replacing cv2.estimateAffinePartial2D(..., cv2.RANSAC,
+ * ransacReprojThreshold) at superpoint_glue_test.py:86-92.  Per pair: `hypotheses`
+ * two-point models from a counter-based RNG (`seed`), best inlier count wins (ties: lowest hypothesis id),
+ * closed-form least-squares refit on its inliers.  M_dev (B,2,3); inlier_dev (B,K) uint8 in keypoints0 index
+ * space; n_inliers_dev (B) = 0 when the pair has <= 3 matches (no fit, M = 0).  counts0_dev may be NULL. */
+int imx_estimate_affine_partial(imx_handle_t h, const float* kpts0_dev, const float* kpts1_dev,
+                                const int64_t* matches0_dev, const int32_t* counts0_dev, int B, int K,
+                                float ransac_threshold, int hypotheses, uint32_t seed,
+                                float* M_dev, uint8_t* inlier_dev, int32_t* n_inliers_dev, void* stream);
 
 /* Single-stage entry point: simple_nms (superpoint_test.py:7-22) on a caller-supplied score map
  * (B,H,W) -> out (B,H,W).  Compare-only arithmetic: bit-exact given identical input. */

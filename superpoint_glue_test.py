@@ -45,6 +45,8 @@ def build_parser():
     p.add_argument('--match_threshold', type=float, default=0.1, help='SuperGlue match threshold')
     # not in the reference
     p.add_argument('--synthetic', type=int, default=0, help='write this many synthetic pairs under --img_dir first')
+    p.add_argument('--ransac', choices=['gpu', 'host'], default='gpu',
+                   help="partial-affine RANSAC: 'gpu' = libimx kernel (imx_estimate_affine_partial), 'host' = OpenCV/numpy")
     return p
 
 
@@ -121,6 +123,11 @@ def main(argv=None):
         template_tensor = torch.from_numpy(template_image)[None].float().to(device)
         start = time.perf_counter()
         pred = matching({'image0': source_tensor, 'image1': template_tensor})
+        M_gpu = None
+        if opt.ransac == 'gpu' and pred['keypoints0'][0].shape[0] and pred['keypoints1'][0].shape[0]:
+            eng = matching._shared.engine          # RANSAC runs on the GPU before anything is copied back
+            M_gpu, inl_gpu, ninl_gpu = eng.estimate_affine_partial(pred['keypoints0'][0][None], pred['keypoints1'][0][None],
+                                                                   pred['matches0'].long(), ransac_thresh=7)
         kpts0 = pred['keypoints0'][0].cpu().numpy()
         kpts1 = pred['keypoints1'][0].cpu().numpy()
         matches = pred['matches0'][0].cpu().numpy()
@@ -128,7 +135,11 @@ def main(argv=None):
         valid = matches > -1
         mkpts0, mkpts1 = kpts0[valid], kpts1[matches[valid]]
         if len(mkpts0) > 3:
-            M, mask = hostops.estimate_affine_partial_2d(mkpts0, mkpts1, ransac_thresh=7)
+            if M_gpu is not None:
+                M = M_gpu[0].cpu().numpy() if int(ninl_gpu[0]) > 0 else None
+                mask = inl_gpu[0].cpu().numpy()[valid][:, None]
+            else:
+                M, mask = hostops.estimate_affine_partial_2d(mkpts0, mkpts1, ransac_thresh=7)
             if M is not None:       # the reference crashes on a failed fit; we keep the last matrix
                 Matrix = np.array(M, dtype=np.float64)
                 if opt.resize_scale is not None:

@@ -1,0 +1,63 @@
+"""RANSAC partial-affine post-step: libimx kernel vs its host restatement
+(oracle/ransac_ref.py, same hypothesis sequence) and vs the ground-truth transform.  Needs an MI355X.
+Parity vs cv2.estimateAffinePartial2D itself is unpinned (OpenCV is not in the reference tree)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed, K, theta, scale, t, frac_unmatched=3, outlier_every=7):
+    rng = np.random.RandomState(seed)
+    k0 = (rng.rand(K, 2) * 600).astype(np.float32)
+    R = np.array([[np.cos(theta), -np.sin(theta)], [np.sin(theta), np.cos(theta)]]) * scale
+    perm = rng.permutation(K)
+    k1 = np.zeros((K, 2), np.float32)
+    k1[perm] = (k0 @ R.T + t + rng.randn(K, 2) * 0.05).astype(np.float32)      # inliers: 0.05 px noise
+    m = perm.astype(np.int64).copy()
+    m[::frac_unmatched] = -1
+    bad = np.arange(1, K, outlier_every)
+    k1[perm[bad]] += (rng.rand(len(bad), 2) * 100 + 30).astype(np.float32)      # outliers: >= 30 px off
+    return k0, k1, m, np.concatenate([R, np.array(t, float)[:, None]], 1)
+
+
+def test_ransac_recovers_transform_and_matches_host_restatement():
+    from image_matching_amd.engine import Engine
+    from oracle import ransac_ref
+    eng = Engine(util.sp_config(128, 1024), util.sg_config(128), "cuda")
+    cases = [_case(0, 1024, 0.05, 0.95, (12, -7)), _case(1, 1024, -0.3, 1.2, (-40, 25)), _case(2, 1024, 1.0, 1.0, (300, 10))]
+    k0 = torch.from_numpy(np.stack([c[0] for c in cases])).cuda()
+    k1 = torch.from_numpy(np.stack([c[1] for c in cases])).cuda()
+    m = torch.from_numpy(np.stack([c[2] for c in cases])).cuda()
+    M, inl, ninl = eng.estimate_affine_partial(k0, k1, m, ransac_thresh=7.0, hypotheses=256, seed=5)
+    M, inl, ninl = M.cpu().numpy(), inl.cpu().numpy(), ninl.cpu().numpy()
+    for b, (c0, c1, cm, Mtrue) in enumerate(cases):
+        Mr, maskr, nr = ransac_ref.estimate_affine_partial(c0, c1, cm, b=b, thresh=7.0, hypotheses=256, seed=5)
+        assert np.array_equal(inl[b], maskr), f"pair {b}: inlier mask differs from the host restatement"
+        assert ninl[b] == nr
+        np.testing.assert_allclose(M[b], Mr, atol=2e-4, rtol=1e-5)
+        np.testing.assert_allclose(M[b][:, :2], Mtrue[:, :2], atol=2e-3)                 # ground truth
+        np.testing.assert_allclose(M[b][:, 2], Mtrue[:, 2], atol=0.5)
+        matched = cm >= 0
+        bad = np.zeros(len(cm), bool); bad[np.arange(1, len(cm), 7)] = True
+        assert inl[b][matched & ~bad].all() and not inl[b][matched & bad].any() and not inl[b][~matched].any()
+
+
+def test_ransac_too_few_matches_and_counts():
+    from image_matching_amd.engine import Engine
+    eng = Engine(util.sp_config(128, 64), util.sg_config(128), "cuda")
+    k0, k1, m, _ = _case(3, 64, 0.1, 1.0, (5, 5), frac_unmatched=1)      # everything unmatched
+    m[:3] = [0, 1, 2]
+    k1[:3] = k0[:3]
+    M, inl, ninl = eng.estimate_affine_partial(torch.from_numpy(k0)[None], torch.from_numpy(k1)[None], torch.from_numpy(m)[None])
+    assert int(ninl[0]) == 0 and not inl.any() and (M == 0).all()          # <= 3 matches: no fit (reference :86)
+    # ragged: K0 != K1
+    k0b, k1b, mb, Mt = _case(4, 200, 0.2, 1.1, (3, 4), frac_unmatched=5)
+    keep = 150
+    mb2 = mb[:keep].copy()
+    M2, inl2, n2 = eng.estimate_affine_partial(torch.from_numpy(k0b[:keep])[None], torch.from_numpy(k1b)[None], torch.from_numpy(mb2)[None])
+    assert inl2.shape == (1, keep) and int(n2[0]) > 50
+    np.testing.assert_allclose(M2[0].cpu().numpy()[:, :2], Mt[:, :2], atol=2e-3)

@@ -157,3 +157,17 @@ def test_empty_result_when_threshold_is_high():
     eng.load_state_dict(L.NET_SUPERPOINT, util.sp_sd(128))
     kpts, scores, desc, n = eng.superpoint(util.pair(1, 64, 64)[0].cuda())
     assert n == [0] and kpts.shape == (1, 0, 2) and desc.shape == (1, 0, 128)
+
+
+def test_dense_forward_for_label_export_vs_reference_golden():
+    """superpoint/models/superpoint_train.py:31-57: {'semi','desc'} dense tensors in the reference layout."""
+    from image_matching_amd.superpoint.models.superpoint_train import SuperPoint as DenseSuperPoint
+    g = util.golden("sp_small.npz")
+    H, W, seed = int(g["H"]), int(g["W"]), int(g["seed"])
+    net = DenseSuperPoint(descriptor_length=128).eval().to("cuda")
+    net.load_state_dict(util.sp_sd(128))
+    out = net(torch.cat(util.pair(seed, H, W)).cuda())
+    assert set(out) == {"semi", "desc"} and net.output is out
+    assert out["semi"].shape == g["semi"].shape and out["desc"].shape == g["desc"].shape
+    util.assert_close(out["semi"], g["semi"], "semi")
+    util.assert_close(out["desc"], g["desc"], "desc")
