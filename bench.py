@@ -72,8 +72,8 @@ def algorithmic_work(B, H, W, d, K, kenc, iters, n_layers=18):
         "kenc0": ("hbm", 4.0 * R * (3 + kenc[0])),
         "qkv_proj": ("mfma", 2.0 * R * d * 3 * d),
         "attention": ("mfma", 2.0 * 2 * B * 2 * K * K * d),
-        "attn_merge": ("mfma", 2.0 * R * d * d),
-        "gnn_mlp1": ("mfma", 2.0 * R * 2 * d * 2 * d),
+        # attn.merge (d->d) is folded into mlp.0's weights at load; its reference FLOPs stay in the count
+        "gnn_mlp1": ("mfma", 2.0 * R * (2 * d * 2 * d + d * d)),
         "gnn_mlp2": ("mfma", 2.0 * R * 2 * d * d),
         "final_proj": ("mfma", 2.0 * R * d * d),
         "score_gemm": ("mfma", 2.0 * B * K * K * d),

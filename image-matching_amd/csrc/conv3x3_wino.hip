@@ -48,6 +48,8 @@ constexpr int RAWF = RH * RW * RSF;                       // 12240
 
 template <bool POOL, bool RELU, bool FIRST, bool TRACE = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, int tiles_y, unsigned* trace = nullptr) {
+  unsigned long long t_start = 0, t_loop = 0, t_epi = 0;
+  if constexpr (TRACE) t_start = __builtin_readcyclecounter();
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* V = smem;
   float* raw = V + VSZ;                 // raw input patch [10][18][12]
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
   }
   IMX_GRAW(0)
   IMX_SRAW()
-  if constexpr (TRACE) tprev = __builtin_readcyclecounter();
+  if constexpr (TRACE) { tprev = __builtin_readcyclecounter(); t_loop = tprev; }
   for (int ch = 0; ch < nchunk; ++ch) {
     __syncthreads();               // previous chunk's MFMA phase is done with raw / V / U
     IMX_TS(0)
@@ -239,10 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
     }
     IMX_TS(6)
   }
-  if constexpr (TRACE) {
-    if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 4096)
-      for (int i = 0; i < 7; ++i) trace[blockIdx.x * 8 + i] = tph[i];
-  }
+  if constexpr (TRACE) t_epi = __builtin_readcyclecounter();
 #undef IMX_TS
 #undef IMX_GRAW
 #undef IMX_SRAW
@@ -302,6 +301,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
             *reinterpret_cast<const float4*>(Ot + pix * OS + 4 * v4);
     }
   }
+  if constexpr (TRACE) {
+    const unsigned long long t_end = __builtin_readcyclecounter();
+    if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 4096) {
+      for (int i = 0; i < 4; ++i) trace[blockIdx.x * 8 + i] = tph[i * 2] + (i < 3 ? tph[i * 2 + 1] : 0);
+      trace[blockIdx.x * 8 + 4] = (unsigned)(t_loop - t_start);
+      trace[blockIdx.x * 8 + 5] = (unsigned)(t_epi - t_loop);
+      trace[blockIdx.x * 8 + 6] = (unsigned)(t_end - t_epi);
+    }
+  }
 }
 
 template <bool POOL, bool RELU, bool FIRST>
@@ -323,10 +331,10 @@ hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
     double sum[7] = {0};
     for (int i = 0; i < n; ++i) for (int j = 0; j < 7; ++j) sum[j] += host[i * 8 + j];
     const int nchunk = a.Cin / CK;
-    fprintf(stderr, "[wino trace] H=%d W=%d Cin=%d Cout=%d pool=%d first=%d grid=%u | cycles/chunk: barrier1 %.0f  lstore %.0f  barrier2 %.0f  "
-                    "transform %.0f  barrier3 %.0f  gload %.0f  mfma %.0f\n", a.H, a.W, a.Cin, a.Cout, (int)POOL, (int)FIRST, grid.x,
-            sum[0] / n / nchunk, sum[1] / n / nchunk, sum[2] / n / nchunk, sum[3] / n / nchunk, sum[4] / n / nchunk,
-            sum[5] / n / nchunk, sum[6] / n / nchunk);
+    fprintf(stderr, "[wino trace] H=%d W=%d Cin=%d Cout=%d pool=%d first=%d grid=%u | prologue %.0f  loop %.0f (%.0f / chunk: barrier+ %.0f  "
+                    "transform+B %.0f  barrier %.0f  mfma %.0f)  epilogue %.0f cycles\n", a.H, a.W, a.Cin, a.Cout, (int)POOL, (int)FIRST, grid.x,
+            sum[4] / n, sum[5] / n, sum[5] / n / nchunk, sum[0] / n / nchunk, sum[1] / n / nchunk, sum[2] / n / nchunk,
+            sum[3] / n / nchunk, sum[6] / n);
     return hipGetLastError();
   }
   auto k = conv3x3_wino<POOL, RELU, FIRST>;

@@ -310,13 +310,14 @@ int make_conv(imx_handle_t h, ConvW& out, const std::map<std::string, HostTensor
 }
 
 // linear weight (N,K[,1[,1]]) -> W[k_perm(k)][n_perm(n)] padded to Npad columns, folded BN
-int make_gemm(imx_handle_t h, GemmW& out, const std::map<std::string, HostTensor>& raw, const std::string& conv,
-              const std::string& bn, int K, int N, const std::vector<int>* kperm = nullptr) {
-  const int Npad = ((N + 63) / 64) * 64;
+void build_gemm_host(const std::map<std::string, HostTensor>& raw, const std::string& conv, const std::string& bn, int K,
+                     int N, const std::vector<int>* kperm, std::vector<float>& w, std::vector<float>& b, int& Npad) {
+  Npad = ((N + 63) / 64) * 64;
   std::vector<double> s, t;
   fold_bn(raw, conv, bn, N, s, t);
   const std::vector<float>& src = raw.at(conv + ".weight").data;
-  std::vector<float> w((size_t)K * Npad, 0.f), b(Npad, 0.f);
+  w.assign((size_t)K * Npad, 0.f);
+  b.assign(Npad, 0.f);
   for (int n = 0; n < N; ++n) {
     for (int k = 0; k < K; ++k) {
       const int kk = kperm ? (*kperm)[k] : k;   // kk = position of reference input channel k in OUR layout
@@ -324,12 +325,24 @@ int make_gemm(imx_handle_t h, GemmW& out, const std::map<std::string, HostTensor
     }
     b[n] = (float)t[n];
   }
+}
+
+int upload_gemm(imx_handle_t h, GemmW& out, const std::vector<float>& w, const std::vector<float>& b, int K, int N, int Npad,
+                const char* what) {
   out.w = upload(h, w);
   out.b = upload(h, b);
   out.K = K;
   out.N = N;
   out.Npad = Npad;
-  return (out.w && out.b) ? 0 : fail(h, "weight upload failed (%s)", conv.c_str());
+  return (out.w && out.b) ? 0 : fail(h, "weight upload failed (%s)", what);
+}
+
+int make_gemm(imx_handle_t h, GemmW& out, const std::map<std::string, HostTensor>& raw, const std::string& conv,
+              const std::string& bn, int K, int N, const std::vector<int>* kperm = nullptr) {
+  std::vector<float> w, b;
+  int Npad = 0;
+  build_gemm_host(raw, conv, bn, K, N, kperm, w, b, Npad);
+  return upload_gemm(h, out, w, b, K, N, Npad, conv.c_str());
 }
 
 int finalize_superpoint(imx_handle_t h) {
@@ -441,8 +454,31 @@ int finalize_superglue(imx_handle_t h) {
       L.qkv.Npad = N;
       if (!L.qkv.w || !L.qkv.b) return fail(h, "weight upload failed (%s qkv)", p.c_str());
     }
-    if (make_gemm(h, L.merge, raw, p + ".attn.merge", "", d, d, &perm)) return -1;
-    if (make_gemm(h, L.mlp1, raw, p + ".mlp.0", p + ".mlp.1", 2 * d, 2 * d)) return -1;
+    // attn.merge is linear and feeds only mlp.0's second input half (superglue_test.py:107,119):
+    //   mlp.0([x ; Wm a + bm]) = W1x x + (W1m Wm) a + (W1m bm + b1)
+    // so the merge GEMM is folded into the (BN-folded) mlp.0 weights once, in double, and the kernel
+    // chain per layer is qkv -> attention -> mlp1([x | a]) -> mlp2 (+residual).
+    {
+      std::vector<float> wm, bm, w1, b1;
+      int npm = 0, np1 = 0;
+      build_gemm_host(raw, p + ".attn.merge", "", d, d, &perm, wm, bm, npm);      // wm[a_ch (ours)][c], bm[c]
+      build_gemm_host(raw, p + ".mlp.0", p + ".mlp.1", 2 * d, 2 * d, nullptr, w1, b1, np1);
+      std::vector<float> wf((size_t)2 * d * np1, 0.f), bf(b1);
+      for (int k = 0; k < d; ++k)
+        for (int n = 0; n < 2 * d; ++n) wf[(size_t)k * np1 + n] = w1[(size_t)k * np1 + n];
+      for (int n = 0; n < 2 * d; ++n) {
+        double accb = b1[n];
+        for (int cch = 0; cch < d; ++cch) accb += (double)bm[cch] * (double)w1[(size_t)(d + cch) * np1 + n];
+        bf[n] = (float)accb;
+      }
+      for (int kk = 0; kk < d; ++kk)
+        for (int n = 0; n < 2 * d; ++n) {
+          double acc = 0.0;
+          for (int cch = 0; cch < d; ++cch) acc += (double)wm[(size_t)kk * npm + cch] * (double)w1[(size_t)(d + cch) * np1 + n];
+          wf[(size_t)(d + kk) * np1 + n] = (float)acc;
+        }
+      if (upload_gemm(h, L.mlp1, wf, bf, 2 * d, 2 * d, np1, (p + ".mlp.0 (+merge)").c_str())) return -1;
+    }
     if (make_gemm(h, L.mlp2, raw, p + ".mlp.3", "", 2 * d, d)) return -1;
     h->layers.push_back(L);
   }
@@ -580,7 +616,6 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   WS(tb, float, "sg.tb", (size_t)R * maxw * f);
   WS(qkv, float, "sg.qkv", (size_t)R * 3 * d * f);
   WS(att, float, "sg.att", (size_t)R * d * f);
-  WS(msg, float, "sg.msg", (size_t)R * d * f);
   WS(hid, float, "sg.hid", (size_t)R * 2 * d * f);
   WS(mdesc, float, "sg.mdesc", (size_t)R * d * f);
   WS(S, float, "sg.S", (size_t)B * N0p * N1p * f);
@@ -634,8 +669,7 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     a.qkv = qkv; a.out = att; a.B = B; a.N0p = N0p; a.N1p = N1p; a.d = d; a.heads = HEADS;
     a.n0 = sd[0].n; a.n1 = sd[1].n; a.N0 = N0; a.N1 = N1; a.cross = c.gnn_layer_is_cross[l];
     RUN("attention", launch_attention(a, s));
-    if (gemm(h, s, "attn_merge", L.merge, att, d, d, nullptr, 0, 0, nullptr, 0, msg, d, R, false)) return -1;
-    if (gemm(h, s, "gnn_mlp1", L.mlp1, x, d, d, msg, d, d, nullptr, 0, hid, 2 * d, R, true)) return -1;
+    if (gemm(h, s, "gnn_mlp1", L.mlp1, x, d, d, att, d, d, nullptr, 0, hid, 2 * d, R, true)) return -1;   // merge folded in
     if (gemm(h, s, "gnn_mlp2", L.mlp2, hid, 2 * d, 2 * d, nullptr, 0, 0, x, d, x, d, R, false)) return -1;
     if (h->debug) {
       std::string nm = "gnn" + std::to_string(l);

@@ -107,3 +107,23 @@ def test_cli_end_to_end_on_synthetic_dataset(tmp_path):
     import os
     assert sorted(os.listdir(os.path.join(res_dir, "t", "Match"))) == ["src_000.png", "src_001.png"]
     assert sorted(os.listdir(os.path.join(res_dir, "t", "Transform"))) == ["trans_src_000.png", "trans_src_001.png"]
+
+
+def test_pair_sharding_is_order_independent():
+    """C4 shape in miniature: 8 pairs processed as two round-robin shards (what 2 ranks would do) and
+    collected through pack/gather/sort give exactly the records of one 8-pair batch."""
+    from image_matching_amd import shard
+    d, K, H, W = 128, 1024, 480, 640
+    m = _matching(d, K)
+    n_pairs, world = 8, 2
+    pairs = [util.pair(100 + i, H, W) for i in range(n_pairs)]
+
+    def run(ids):
+        i0 = torch.cat([pairs[i][0] for i in ids]).cuda()
+        i1 = torch.cat([pairs[i][1] for i in ids]).cuda()
+        return shard.pack_records(ids, m.match_batch(i0, i1))
+    whole = shard.sort_by_pair_id(run(list(range(n_pairs))))
+    parts = torch.cat([run(shard.shard_indices(n_pairs, r, world)) for r in range(world)])
+    assert torch.equal(shard.sort_by_pair_id(parts), whole)
+    rec = shard.unpack_records(whole)
+    assert rec["pair_id"].tolist() == list(range(n_pairs)) and (rec["counts0"] == K).all()

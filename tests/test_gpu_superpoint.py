@@ -61,7 +61,7 @@ def test_dense_stages_and_keypoints_vs_reference_golden(name):
     assert np.array_equal(eng.fetch("nms") > 0, g["nms"] > 0)
 
 
-@pytest.mark.parametrize("name", ["c3_pair_s59.npz", "c3_pair_s55.npz"])
+@pytest.mark.parametrize("name", ["c3_pair_s59.npz", "c3_pair_s55.npz", "c5_pair_s19.npz"])
 def test_c3_full_size_vs_reference_golden(name):
     g = util.golden(name)
     H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))

@@ -156,3 +156,19 @@ def test_hostops_similarity_ransac_and_warp():
     img = rng.rand(40, 60) * 255
     w = hostops.warp_affine(img, np.array([[1, 0, 3], [0, 1, 2.0]]), (60, 40))
     np.testing.assert_allclose(w[5, 10], img[3, 7])
+
+
+def test_superglue_checkpoint_formats(tmp_path):
+    """superglue_test.py:221-227: {'net': state_dict} for self-trained checkpoints, a bare state dict when
+    the path contains 'indoor'/'outdoor'; the user's (not the merged) config is indexed for the path."""
+    from image_matching_amd.superglue.models.superglue_test import SuperGlue
+    sd = util.sg_sd(128)
+    p_net, p_ind = tmp_path / "SuperGlue_allss.pth", tmp_path / "superglue_indoor.pth"
+    torch.save({"epoch": 3, "net": sd}, p_net)
+    torch.save(sd, p_ind)
+    for path in (p_net, p_ind):
+        sg = SuperGlue(util.sg_config(128, weights=str(path)))
+        got = sg.state_dict()
+        assert all(torch.equal(got[k], sd[k]) for k in sd)
+    with pytest.raises(KeyError):       # default 'weights': 'indoor' is truthy but the user's dict has no key (:222)
+        SuperGlue({"descriptor_dim": 128, "keypoint_encoder": [32, 64, 128]})
