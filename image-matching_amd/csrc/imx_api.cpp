@@ -681,7 +681,12 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   if (gemm(h, s, "final_proj", h->final_proj, x, d, d, nullptr, 0, 0, nullptr, 0, mdesc, d, R, false)) return -1;
   ScoreArgs sc{mdesc, mdesc + off1 * d, S, B, N0p, N1p, d, (float)(1.0 / std::sqrt((double)d))};
   RUN("score_gemm", launch_score_gemm(sc, s));
-  SinkhornArgs sk{S, u, v, B, N0p, N1p, sd[0].n, sd[1].n, N0, N1, h->bin_score, c.sinkhorn_iterations};
+  float* part = nullptr;
+  if (const int Rs = sinkhorn_slab_rows(N1p)) {
+    WS(pt, float, "sg.part", (size_t)B * (N0p / Rs + 1) * (N1p + 1) * 2 * f);
+    part = pt;
+  }
+  SinkhornArgs sk{S, u, v, B, N0p, N1p, sd[0].n, sd[1].n, N0, N1, h->bin_score, c.sinkhorn_iterations, part};
   RUN("sinkhorn", launch_sinkhorn(sk, s));
   MatchArgs ma{S, u, v, B, N0p, N1p, sd[0].n, sd[1].n, N0, N1, h->bin_score, c.match_threshold,
                max0, idx0, max1, idx1, m0, m1, ms0, ms1};

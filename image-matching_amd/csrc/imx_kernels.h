@@ -122,7 +122,9 @@ struct SinkhornArgs {
   const int* n0; const int* n1; int N0, N1;
   float alpha;               // bin_score
   int iters;
+  float* part;               // scratch (B, N0p/R + 1, N1p + 1, 2) for the slab form, R = sinkhorn_slab_rows(N1p); may be null
 };
+int sinkhorn_slab_rows(int N1p);
 hipError_t launch_sinkhorn(const SinkhornArgs& a, hipStream_t s);
 
 struct MatchArgs {

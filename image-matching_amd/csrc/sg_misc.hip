@@ -139,6 +139,92 @@ __global__ __launch_bounds__(1024) void sinkhorn_cols(SinkhornArgs a) {
   }
 }
 
+// Slab form of one Sinkhorn iteration: a workgroup (16 waves) keeps R rows of S in LDS, computes their
+// u (row pass, :145) and immediately the partial column log-sum-exps of (Z + u) over those rows
+// (:146), so S is read from HBM/L2 once per iteration instead of twice.  A second, small kernel merges
+// the per-slab partials into v.  Slab `m / R` also owns the dustbin row i = m.
+template <int R>
+__global__ __launch_bounds__(1024) void sinkhorn_slab(SinkhornArgs a, float* __restrict__ part, int nslab_max) {
+  extern __shared__ float sm[];
+  float* tile = sm;                       // [R][N1p]
+  float* vs = tile + R * a.N1p;           // [N1p + 1]
+  __shared__ float uu[R];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, slab = blockIdx.x, i0 = slab * R;
+  int m, n;
+  counts(a, b, m, n);
+  if (m == 0 || n == 0 || i0 > m) return;
+  const float* v = a.v + (size_t)b * (a.N1p + 1);
+  for (int j = tid; j <= n; j += 1024) vs[j] = v[j];
+  __syncthreads();
+  const float norm = -logf((float)(m + n));
+  for (int r = wave; r < R; r += 16) {          // 16 waves: one row each when R = 16
+    const int i = i0 + r;
+    if (i > m) break;
+    LSE acc{-INFINITY, 0.f};
+    if (i < m) {
+      const float* Srow = a.S + ((size_t)b * a.N0p + i) * a.N1p;
+      float* trow = tile + r * a.N1p;
+      for (int j = lane; j < n; j += 64) {
+        const float sv = Srow[j];
+        trow[j] = sv;
+        lse_add(acc, sv + vs[j]);
+      }
+    } else {
+      for (int j = lane; j < n; j += 64) lse_add(acc, a.alpha + vs[j]);
+    }
+    if (lane == 0) lse_add(acc, a.alpha + vs[n]);
+    acc = wave_lse(acc);
+    if (lane == 0) {
+      const float log_mu = i < m ? norm : logf((float)n) + norm;
+      const float ui = log_mu - lse_value(acc);
+      uu[r] = ui;
+      a.u[(size_t)b * (a.N0p + 1) + i] = ui;
+    }
+  }
+  __syncthreads();
+  const int rows = min(R, m + 1 - i0);      // rows of this slab, the last may be the dustbin row
+  float2* pb = reinterpret_cast<float2*>(part + ((size_t)b * nslab_max + slab) * (a.N1p + 1) * 2);
+  for (int j = tid; j <= n; j += 1024) {
+    LSE acc{-INFINITY, 0.f};
+    for (int r = 0; r < rows; ++r) {
+      const bool real = (i0 + r < m) && (j < n);
+      lse_add(acc, (real ? tile[r * a.N1p + j] : a.alpha) + uu[r]);
+    }
+    pb[j] = make_float2(acc.m, acc.s);
+  }
+}
+
+// v[j] = log_nu[j] - logsumexp over the slabs' partial (max, sum) pairs.  64 columns x 4 slab groups
+// per workgroup so the (few dozen) partial loads of a column are spread over 4 threads.
+__global__ __launch_bounds__(256) void sinkhorn_vmerge(SinkhornArgs a, const float* __restrict__ part, int nslab_max, int R) {
+  __shared__ float pm[4][64], ps[4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int b = blockIdx.y, j = blockIdx.x * 64 + c;
+  int m, n;
+  counts(a, b, m, n);
+  if (m == 0 || n == 0) return;
+  const int nslab = m / R + 1;
+  LSE t{-INFINITY, 0.f};
+  if (j <= n) {
+    const float2* pb = reinterpret_cast<const float2*>(part + (size_t)b * nslab_max * (a.N1p + 1) * 2) + j;
+    for (int sl = g; sl < nslab; sl += 4) {
+      const float2 q = pb[(size_t)sl * (a.N1p + 1)];
+      t = lse_merge(t, LSE{q.x, q.y});
+    }
+  }
+  pm[g][c] = t.m;
+  ps[g][c] = t.s;
+  __syncthreads();
+  if (g == 0 && j <= n) {
+#pragma unroll
+    for (int k = 1; k < 4; ++k) t = lse_merge(t, LSE{pm[k][c], ps[k][c]});
+    const float norm = -logf((float)(m + n));
+    const float log_nu = j < n ? norm : logf((float)m) + norm;
+    a.v[(size_t)b * (a.N1p + 1) + j] = log_nu - lse_value(t);
+  }
+}
+
 // ------------------------------------------------------------------ matches
 // Z'[i][j] = ((S[i][j] + u[i]) + v[j]) - norm   (:147, :169) — same operation order as the reference.
 __device__ __forceinline__ void mcounts(const MatchArgs& a, int b, int& m, int& n) {
@@ -245,6 +331,9 @@ __global__ __launch_bounds__(256) void match_finalize(MatchArgs a) {
 
 }  // namespace
 
+// rows per LDS slab (R * N1p floats <= 64 KB); 0 = use the two-pass kernels
+int sinkhorn_slab_rows(int N1p) { return N1p <= 1024 ? 16 : N1p <= 2048 ? 8 : N1p <= 4096 ? 4 : 0; }
+
 hipError_t launch_kenc0(const Kenc0Args& a, hipStream_t s) {
   long total = (long)a.B * a.Np * a.C1;
   hipLaunchKernelGGL(kenc0_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, a.scaling);
@@ -259,11 +348,33 @@ hipError_t launch_gather_desc(const float* src, int64_t sb, int64_t sc, int64_t 
   return hipGetLastError();
 }
 
+template <int R>
+static void launch_slab_iter(const SinkhornArgs& a, int nslab_max, hipStream_t s) {
+  const size_t lds = ((size_t)R * a.N1p + a.N1p + 1) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_slab<R>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(sinkhorn_slab<R>, dim3((unsigned)nslab_max, (unsigned)a.B), dim3(1024), lds, s, a, a.part, nslab_max);
+  hipLaunchKernelGGL(sinkhorn_vmerge, dim3((unsigned)((a.N1p + 1 + 63) / 64), (unsigned)a.B), dim3(256), 0, s, a, a.part, nslab_max, R);
+}
+
 hipError_t launch_sinkhorn(const SinkhornArgs& a, hipStream_t s) {
   hipError_t e = hipMemsetAsync(a.v, 0, (size_t)a.B * (a.N1p + 1) * sizeof(float), s);   // v = 0 (:143)
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(a.u, 0, (size_t)a.B * (a.N0p + 1) * sizeof(float), s);
   if (e != hipSuccess) return e;
+  const int R = sinkhorn_slab_rows(a.N1p);
+  if (R > 0 && a.part) {
+    const int nslab_max = a.N0p / R + 1;
+    for (int it = 0; it < a.iters; ++it) {
+      if (R == 16) launch_slab_iter<16>(a, nslab_max, s);
+      else if (R == 8) launch_slab_iter<8>(a, nslab_max, s);
+      else launch_slab_iter<4>(a, nslab_max, s);
+    }
+    return hipGetLastError();
+  }
   dim3 gr((unsigned)((a.N0p + 1 + 3) / 4), (unsigned)a.B);
   dim3 gc((unsigned)((a.N1p + 1 + 63) / 64), (unsigned)a.B);
   for (int it = 0; it < a.iters; ++it) {
