@@ -9,8 +9,8 @@
 // so the result differs from the direct form by fp32 rounding only (measured in the parity tests).
 //
 // Workgroup = 256 threads (4 waves) -> 4x8 wtiles (8x16 output pixels) x 64 output channels.
-//   wave: i-block ib (16 wtiles) x co-group cg (32 channels = 2 MFMA column blocks) x all 16
-//   positions -> 32 accumulators of 4 VGPRs.  The 16x16 MFMA's D layout gives each lane one output
+//   wave: one 16-channel column block x both 16-wtile row blocks x all 16 positions -> 32 accumulators
+//   of 4 VGPRs (B fragments shared by the two row blocks: half the L1 traffic of a 16x32 wave tile).  The 16x16 MFMA's D layout gives each lane one output
 //   channel and 4 wtiles with all 16 positions: the output transform, bias, ReLU and the 2x2
 //   max-pool (one wtile = one pooled pixel) are in-lane, no LDS exchange.
 // K loop, 8 input channels per chunk, two barriers per chunk:
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
   float* b1s = w1s + 9 * 64;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ib = wave & 1, cg = wave >> 1;
+  const int cb = wave;          // wave = one 16-channel column block x BOTH 16-wtile row blocks (halves the B traffic)
   int t = blockIdx.x;
   const int tx = t % tiles_x; t /= tiles_x;
   const int ty = t % tiles_y;
@@ -172,15 +172,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
     //      [pos][k-step][co-block][4 k][16 co] makes every wave load 256 contiguous bytes; they land
     //      while the input transform runs, so the MFMA loop below touches no global memory except the
     //      next raw patch.  U never goes through LDS.
-    const float* ub = ublk + (size_t)ch * USZ + cg * 128 + lane;
-    float bf[16][2][2];          // [position][k-step][column block]: the wave's whole B panel of this chunk
+    const float* ub = ublk + (size_t)ch * USZ + cb * 64 + lane;
+    float bf[16][2];             // [position][k-step]: the wave's whole B panel of this chunk (32 registers)
 #pragma unroll
     for (int q = 0; q < 16; ++q)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        bf[q][s2][0] = ub[(q * 2 + s2) * 256];
-        bf[q][s2][1] = ub[(q * 2 + s2) * 256 + 64];
-      }
+      for (int s2 = 0; s2 < 2; ++s2) bf[q][s2] = ub[(q * 2 + s2) * 256];
     // ---- input transform  V = B^T d B  (LDS raw -> registers -> LDS V), thread = (channel tc, wtile tw)
     {
       constexpr int RSX = FIRST ? RSF : RS;
@@ -215,10 +212,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
     //      positions (8 MFMAs = 256 cycles).  A operands (V) come from LDS one group ahead, B operands
     //      are already in registers; the next chunk's raw patch load/store rides along.
     {
-      const float* va = V + (lane >> 5) * VK + (ib * 16 + (lane & 15)) * 2 + ((lane >> 4) & 1);
-      float af[2][4];
+      const float* va = V + (lane >> 5) * VK + (lane & 15) * 2 + ((lane >> 4) & 1);     // row block 1 is +32 floats
+      float af[2][4][2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[0][i] = va[(i * 4) * VK];
+      for (int i = 0; i < 4; ++i) {
+        af[0][i][0] = va[(i * 4) * VK];
+        af[0][i][1] = va[(i * 4) * VK + 32];
+      }
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const int cur = g & 1, nxt = cur ^ 1;
@@ -227,14 +227,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
         if (g + 1 < 8) {
           const int s1 = (g + 1) >> 2, qb = ((g + 1) & 3) * 4;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) af[nxt][i] = va[((qb + i) * 4 + 2 * s1) * VK];
+          for (int i = 0; i < 4; ++i) {
+            af[nxt][i][0] = va[((qb + i) * 4 + 2 * s1) * VK];
+            af[nxt][i][1] = va[((qb + i) * 4 + 2 * s1) * VK + 32];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         const int q0 = (g & 3) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          acc[q0 + i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i], bf[q0 + i][g >> 2][0], acc[q0 + i][0], 0, 0, 0);
-          acc[q0 + i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i], bf[q0 + i][g >> 2][1], acc[q0 + i][1], 0, 0, 0);
+          acc[q0 + i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][0], bf[q0 + i][g >> 2], acc[q0 + i][0], 0, 0, 0);
+          acc[q0 + i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][1], bf[q0 + i][g >> 2], acc[q0 + i][1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
 
 
   // ---- output transform Y = A^T M A, bias, ReLU, (2x2 max-pool), store.
-  //      acc[p][jb][r]: wtile ib*16 + 4*(lane>>4) + r, channel n0 + cg*32 + jb*16 + (lane&15).
+  //      acc[p][ibx][r]: wtile ibx*16 + 4*(lane>>4) + r, channel n0 + cb*16 + (lane&15).
   //      The full-resolution tile goes through LDS (free after the loop) so HBM sees whole 256-byte
   //      channel rows written as float4: per-lane dword stores at a pixel stride are store-issue bound
   //      (measured on the wino4 variant: 19k -> 7k cycles).  The pooled tile is 4x smaller: direct stores.
@@ -256,12 +259,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
   float* Ot = smem;
   if constexpr (!POOL) __syncthreads();          // every wave is done with V / raw
 #pragma unroll
-  for (int jb = 0; jb < 2; ++jb) {
-    const int col = cg * 32 + jb * 16 + (lane & 15);
+  for (int jb = 0; jb < 2; ++jb) {          // jb = wtile row block
+    const int col = cb * 16 + (lane & 15);
     const float bs = p.bias[n0 + col];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int w = ib * 16 + 4 * (lane >> 4) + r;
+      const int w = jb * 16 + 4 * (lane >> 4) + r;
       const int wr = w >> 3, wc = w & 7;
       float m[16];
 #pragma unroll
