@@ -10,6 +10,7 @@
 // K in chunks of 32: A tile [128][33] (odd stride: conflict-free 32-lane column reads),
 // W tile [32][NT] (row reads, conflict free).
 #include "imx_kernels.h"
+#include <algorithm>
 
 namespace imx {
 
@@ -116,20 +117,42 @@ __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
 #undef IMX_GW
 #undef IMX_SA
 
+  // ---- epilogue through LDS (the operand buffers are free after the loop's last barrier): the
+  //      accumulator layout gives a lane one column of 16 scattered rows, and per-lane dword stores
+  //      at a row stride are store-issue bound (~250 cycles per wave store measured); staged, the tile
+  //      leaves as float4 row segments with bias / ReLU / residual applied on whole rows.
+  constexpr int OS = NT + 4;
   const int hi = lane >> 5;
 #pragma unroll
   for (int n = 0; n < NB; ++n) {
-    const int col = n0 + n * 32 + (lane & 31);
-    if (col >= p.N) continue;
-    const float bs = p.bias ? p.bias[col] : 0.f;
+    const int col = n * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = r0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (row >= p.M) continue;
-      float v = acc[n][r] + bs;
-      if (p.relu) v = fmaxf(v, 0.f);
-      if (p.res) v = p.res[(size_t)row * p.ldr + col] + v;
-      p.out[(size_t)row * p.ldo + col] = v;
+    for (int r = 0; r < 16; ++r) smem[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hi) * OS + col] = acc[n][r];
+  }
+  __syncthreads();
+  const bool vec_ok = (p.ldo & 3) == 0 && (!p.res || (p.ldr & 3) == 0);
+#pragma unroll
+  for (int it = 0; it < BM * (NT / 4) / 256; ++it) {
+    const int e = tid + it * 256;
+    const int row = e / (NT / 4), c4 = (e % (NT / 4)) * 4;
+    const int grow = r0 + row, gcol = n0 + c4;
+    if (grow >= p.M || gcol >= p.N) continue;
+    float4 v = *reinterpret_cast<const float4*>(smem + row * OS + c4);
+    if (p.bias) {
+      const float4 bsv = *reinterpret_cast<const float4*>(p.bias + gcol);
+      v.x += bsv.x; v.y += bsv.y; v.z += bsv.z; v.w += bsv.w;
+    }
+    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (vec_ok && gcol + 3 < p.N) {
+      if (p.res) {
+        const float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)grow * p.ldr + gcol);
+        v.x = rv.x + v.x; v.y = rv.y + v.y; v.z = rv.z + v.z; v.w = rv.w + v.w;
+      }
+      *reinterpret_cast<float4*>(p.out + (size_t)grow * p.ldo + gcol) = v;
+    } else {                                // ragged N (e.g. 65) or unaligned leading dimension
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      for (int j = 0; j < 4 && gcol + j < p.N; ++j)
+        p.out[(size_t)grow * p.ldo + gcol + j] = (p.res ? p.res[(size_t)grow * p.ldr + gcol + j] : 0.f) + vv[j];
     }
   }
 }
@@ -205,9 +228,11 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.K0 % CK || a.K1 % CK || a.Npad % 64 || a.M <= 0) return hipErrorInvalidValue;
   const unsigned gm = (unsigned)((a.M + BM - 1) / BM);
   if (a.Npad % 128 == 0) {
-    hipLaunchKernelGGL(gemm_mfma<128>, dim3(gm, a.Npad / 128), dim3(256), 2 * (BM * SA + CK * 128) * sizeof(float), s, a);
+    hipLaunchKernelGGL(gemm_mfma<128>, dim3(gm, a.Npad / 128), dim3(256),
+                       std::max<size_t>(2 * (BM * SA + CK * 128), BM * (128 + 4)) * sizeof(float), s, a);
   } else {
-    hipLaunchKernelGGL(gemm_mfma<64>, dim3(gm, a.Npad / 64), dim3(256), 2 * (BM * SA + CK * 64) * sizeof(float), s, a);
+    hipLaunchKernelGGL(gemm_mfma<64>, dim3(gm, a.Npad / 64), dim3(256),
+                       std::max<size_t>(2 * (BM * SA + CK * 64), BM * (64 + 4)) * sizeof(float), s, a);
   }
   return hipGetLastError();
 }
