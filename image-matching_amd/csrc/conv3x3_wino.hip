@@ -163,14 +163,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
   IMX_SRAW()
   if constexpr (TRACE) { tprev = __builtin_readcyclecounter(); t_loop = tprev; }
   for (int ch = 0; ch < nchunk; ++ch) {
-    __syncthreads();               // previous chunk's MFMA phase is done with raw / V / U
-    IMX_TS(0)
-    float d[16];
-    IMX_TS(1)
-    IMX_TS(2)
     // ---- this chunk's B operands (U = G g G^T) straight from global/L2 into 64 registers: the layout
-    //      [pos][k-step][co-block][4 k][16 co] makes every wave load 256 contiguous bytes; they land
-    //      while the input transform runs, so the MFMA loop below touches no global memory except the
+    //      [pos][k-step][co-block][4 k][16 co] makes every wave load 256 contiguous bytes; they are issued BEFORE the
+    //      barrier (the registers are dead once the wave leaves its MFMA loop) and land while the wave waits and the
+    //      input transform runs, so the MFMA loop below touches no global memory except the
     //      next raw patch.  U never goes through LDS.
     const float* ub = ublk + (size_t)ch * USZ + cb * 64 + lane;
     float bf[16][2];             // [position][k-step]: the wave's whole B panel of this chunk (32 registers)
@@ -178,6 +174,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
     for (int q = 0; q < 16; ++q)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) bf[q][s2] = ub[(q * 2 + s2) * 256];
+    __syncthreads();               // previous chunk's MFMA phase is done with raw / V
+    IMX_TS(0)
+    float d[16];
+    IMX_TS(1)
+    IMX_TS(2)
     // ---- input transform  V = B^T d B  (LDS raw -> registers -> LDS V), thread = (channel tc, wtile tw)
     {
       constexpr int RSX = FIRST ? RSF : RS;
