@@ -861,6 +861,32 @@ int imx_estimate_affine_partial(imx_handle_t h, const float* kpts0_dev, const fl
   return 0;
 }
 
+int imx_knn_ratio_match(imx_handle_t h, int B, const float* desc0_dev, int64_t s0b, int64_t s0c, int64_t s0n, const int32_t* n0_dev,
+                        int N0, const float* desc1_dev, int64_t s1b, int64_t s1c, int64_t s1n, const int32_t* n1_dev, int N1,
+                        float ratio, int64_t* matches_dev, float* dist1_dev, float* dist2_dev, void* stream) {
+  if (!h) return -1;
+  HIP_OK(h, hipSetDevice(h->device));
+  hipStream_t s = as_stream(stream);
+  const int d = h->cfg.descriptor_dim;
+  if (B <= 0 || N0 <= 0 || N1 < 0) return fail(h, "imx_knn_ratio_match: bad shape B=%d N0=%d N1=%d", B, N0, N1);
+  const int N0p = pad32(N0), N1p = pad32(std::max(N1, 1));
+  const size_t f = sizeof(float);
+  WS(r0, float, "knn.rows0", (size_t)B * N0p * d * f);
+  WS(r1, float, "knn.rows1", (size_t)B * N1p * d * f);
+  WS(nr0, float, "knn.norm0", (size_t)B * N0p * f);
+  WS(nr1, float, "knn.norm1", (size_t)B * N1p * f);
+  WS(dots, float, "knn.dots", (size_t)B * N0p * N1p * f);
+  RUN("gather_desc", launch_gather_desc(desc0_dev, s0b, s0c, s0n, B, N0, N0p, d, r0, s));
+  RUN("gather_desc", launch_gather_desc(desc1_dev, s1b, s1c, s1n, B, N1, N1p, d, r1, s));
+  RUN("rownorm2", launch_rownorm2(r0, d, (long)B * N0p, nr0, s));
+  RUN("rownorm2", launch_rownorm2(r1, d, (long)B * N1p, nr1, s));
+  ScoreArgs sc{r0, r1, dots, B, N0p, N1p, d, 1.0f};
+  RUN("knn_dots", launch_score_gemm(sc, s));
+  KnnArgs k{dots, nr0, nr1, B, N0, N1, N0p, N1p, n0_dev, n1_dev, ratio, reinterpret_cast<long long*>(matches_dev), dist1_dev, dist2_dev};
+  RUN("knn2", launch_knn2(k, s));
+  return 0;
+}
+
 int imx_set_debug(imx_handle_t h, int enable) {
   if (!h) return -1;
   h->debug = enable != 0;

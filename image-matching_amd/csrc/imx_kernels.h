@@ -150,4 +150,17 @@ struct RansacArgs {
 };
 hipError_t launch_ransac(const RansacArgs& a, hipStream_t s);
 
+// exact 2-NN + ratio test on descriptor rows (dots from launch_score_gemm with scale 1)
+struct KnnArgs {
+  const float* dots;                 // (B,N0p,N1p)
+  const float* norm0; const float* norm1;   // squared row norms (B,N0p) / (B,N1p)
+  int B, N0, N1, N0p, N1p;
+  const int* n0; const int* n1;      // valid counts per pair, may be null
+  float ratio;
+  long long* matches;                // (B,N0) nearest index if dist1 < ratio*dist2 else -1
+  float* dist1; float* dist2;        // (B,N0)
+};
+hipError_t launch_rownorm2(const float* x, int d, long rows, float* out, hipStream_t s);
+hipError_t launch_knn2(const KnnArgs& a, hipStream_t s);
+
 }  // namespace imx

@@ -163,7 +163,68 @@ __global__ __launch_bounds__(256) void ransac_similarity_kernel(RansacArgs a) {
   }
 }
 
+// ---- exact 2-nearest-neighbour search + ratio test on descriptor rows: GPU replacement of
+//      cv2.FlannBasedMatcher(KDTree).knnMatch(Desc1, Desc2, k=2) + `m.distance < 0.7*n.distance`
+//      (superpoint_flann_test.py:66-74).  FLANN is approximate: the exact search is
+//      its ideal; parity vs FLANN is unpinned, vs the brute-force oracle exact.
+//      dots (B,N0p,N1p) = D0 . D1^T from score_mfma; dist^2(i,j) = |a_i|^2 + |b_j|^2 - 2 dot.
+__global__ __launch_bounds__(256) void rownorm2_kernel(const float* __restrict__ x, int d, long rows, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) { const float v = x[r * d + c]; s += v * v; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[r] = s;
+}
+
+__global__ __launch_bounds__(256) void knn2_kernel(KnnArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (i >= a.N0) return;
+  const int m = a.n0 ? a.n0[b] : a.N0, n = a.n1 ? a.n1[b] : a.N1;
+  const size_t o = (size_t)b * a.N0 + i;
+  if (i >= m || n < 2) {            // knnMatch needs two neighbours; padded rows stay unmatched
+    if (lane == 0) { a.matches[o] = -1; a.dist1[o] = 0.f; a.dist2[o] = 0.f; }
+    return;
+  }
+  const float* dots = a.dots + ((size_t)b * a.N0p + i) * a.N1p;
+  const float* nb2 = a.norm1 + (size_t)b * a.N1p;
+  float k1 = INFINITY, k2 = INFINITY;
+  int j1 = 0x7fffffff;
+  for (int j = lane; j < n; j += 64) {
+    const float k = nb2[j] - 2.0f * dots[j];
+    if (k < k1) { k2 = k1; k1 = k; j1 = j; } else if (k < k2) { k2 = k; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ok1 = __shfl_xor(k1, off), ok2 = __shfl_xor(k2, off);
+    const int oj1 = __shfl_xor(j1, off);
+    if (ok1 < k1 || (ok1 == k1 && oj1 < j1)) { k2 = fminf(k1, ok2); k1 = ok1; j1 = oj1; }
+    else { k2 = fminf(k2, ok1); }
+  }
+  if (lane == 0) {
+    const float na2 = a.norm0[(size_t)b * a.N0p + i];
+    const float d1 = sqrtf(fmaxf(na2 + k1, 0.f)), d2 = sqrtf(fmaxf(na2 + k2, 0.f));
+    a.matches[o] = (d1 < a.ratio * d2) ? (long long)j1 : -1;
+    a.dist1[o] = d1;
+    a.dist2[o] = d2;
+  }
+}
+
 }  // namespace
+
+hipError_t launch_rownorm2(const float* x, int d, long rows, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(rownorm2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, d, rows, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_knn2(const KnnArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(knn2_kernel, dim3((unsigned)((a.N0 + 3) / 4), (unsigned)a.B), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
 
 hipError_t launch_ransac(const RansacArgs& a, hipStream_t s) {
   if (a.K <= 0 || a.B <= 0 || a.hypotheses <= 0) return hipErrorInvalidValue;

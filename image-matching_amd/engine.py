@@ -236,6 +236,24 @@ class Engine:
                                                          _ptr(M), _ptr(inl), _ptr(ninl), _stream(dev)))
         return M, inl[:, :K0], ninl
 
+    def knn_ratio_match(self, desc0, desc1, ratio=0.7, n0=None, n1=None):
+        """Exact 2-NN + ratio test (superpoint_flann_test.py:66-74 without FLANN's approximation).
+        desc{0,1}: (B,d,N) tensors, any strides.  Returns matches (B,N0) int64 (-1 = rejected), dist1, dist2 (B,N0)."""
+        dev = self.device
+        desc0, desc1 = desc0.to(dev, torch.float32), desc1.to(dev, torch.float32)
+        B, _, N0 = desc0.shape
+        N1 = desc1.shape[2]
+        m = torch.empty(B, N0, dtype=torch.int64, device=dev)
+        d1 = torch.empty(B, N0, dtype=torch.float32, device=dev)
+        d2 = torch.empty(B, N0, dtype=torch.float32, device=dev)
+        if N0 == 0:
+            return m, d1, d2
+        s0, s1 = desc0.stride(), desc1.stride()
+        self._check(self.lib.imx_knn_ratio_match(self.handle, B, _ptr(desc0), s0[0], s0[1], s0[2], _ptr(n0), N0,
+                                                 _ptr(desc1), s1[0], s1[1], s1[2], _ptr(n1), N1, float(ratio),
+                                                 _ptr(m), _ptr(d1), _ptr(d2), _stream(dev)))
+        return m, d1, d2
+
     def op_nms(self, scores, radius):
         """simple_nms on a (B,H,W) score map (single-stage entry point, used by parity tests)."""
         scores = scores.to(self.device, torch.float32).contiguous()

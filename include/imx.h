@@ -137,6 +137,18 @@ int imx_estimate_affine_partial(imx_handle_t h, const float* kpts0_dev, const fl
                                 float ransac_threshold, int hypotheses, uint32_t seed,
                                 float* M_dev, uint8_t* inlier_dev, int32_t* n_inliers_dev, void* stream);
 
+/* SuperPoint + nearest-neighbour matcher: exact 2-NN over descriptor rows and the ratio test
+ * `m.distance < ratio * n.distance`, replacing cv2.FlannBasedMatcher(...).knnMatch(Desc1, Desc2, k=2) and the loop at
+ * superpoint_flann_test.py:66-74 (FLANN's KD-tree search is approximate; this is the exact search it approximates).
+ * desc{0,1}_dev addressed like imx_superglue_forward's descriptors; n{0,1}_dev optional valid counts.
+ * matches_dev (B,N0) int64 nearest index in side 1 or -1; dist{1,2}_dev (B,N0) L2 distances to the two neighbours. */
+int imx_knn_ratio_match(imx_handle_t h, int B,
+                        const float* desc0_dev, int64_t desc0_stride_b, int64_t desc0_stride_c, int64_t desc0_stride_n,
+                        const int32_t* n0_dev, int N0,
+                        const float* desc1_dev, int64_t desc1_stride_b, int64_t desc1_stride_c, int64_t desc1_stride_n,
+                        const int32_t* n1_dev, int N1, float ratio,
+                        int64_t* matches_dev, float* dist1_dev, float* dist2_dev, void* stream);
+
 /* Single-stage entry point: simple_nms (superpoint_test.py:7-22) on a caller-supplied score map
  * (B,H,W) -> out (B,H,W).  Compare-only arithmetic: bit-exact given identical input. */
 int imx_op_nms(imx_handle_t h, const float* scores_dev, float* out_dev, int B, int H, int W,

@@ -61,3 +61,47 @@ def test_ransac_too_few_matches_and_counts():
     M2, inl2, n2 = eng.estimate_affine_partial(torch.from_numpy(k0b[:keep])[None], torch.from_numpy(k1b)[None], torch.from_numpy(mb2)[None])
     assert inl2.shape == (1, keep) and int(n2[0]) > 50
     np.testing.assert_allclose(M2[0].cpu().numpy()[:, :2], Mt[:, :2], atol=2e-3)
+
+
+def test_knn_ratio_matcher_vs_brute_force():
+    """SuperPoint + nearest-neighbour matcher (superpoint_flann_test.py:66-74): exact 2-NN + ratio test on the GPU
+    against numpy brute force on real SuperPoint descriptors of a synthetic pair (FLANN itself is approximate and
+    absent: parity vs cv2 unpinned)."""
+    from image_matching_amd.engine import Engine
+    from image_matching_amd import _lib as L
+    eng = Engine(util.sp_config(128, 600), util.sg_config(128), "cuda")
+    eng.load_state_dict(L.NET_SUPERPOINT, util.sp_sd(128))
+    x0, x1 = util.pair(12, 240, 320)
+    kp, sc, ds, n = eng.superpoint(torch.cat([x0, x1]).cuda())
+    d0, d1 = ds[0, :n[0]].t()[None], ds[1, :n[1] - 37].t()[None]          # (1,d,N0), (1,d,N1), N0 != N1, strided views
+    m, dist1, dist2 = eng.knn_ratio_match(d0, d1, ratio=0.7)
+    a, b = d0[0].t().double().cpu().numpy(), d1[0].t().double().cpu().numpy()
+    D = np.sqrt(np.maximum((a * a).sum(1)[:, None] + (b * b).sum(1)[None] - 2 * a @ b.T, 0))
+    order = np.argsort(D, axis=1)
+    nn1, nn2 = order[:, 0], order[:, 1]
+    r1, r2 = D[np.arange(len(a)), nn1], D[np.arange(len(a)), nn2]
+    np.testing.assert_allclose(dist1[0].cpu().numpy(), r1, atol=2e-4)
+    np.testing.assert_allclose(dist2[0].cpu().numpy(), r2, atol=2e-4)
+    decided = np.abs(r1 - 0.7 * r2) > 1e-3                                 # away from the ratio boundary
+    expect = np.where(r1 < 0.7 * r2, nn1, -1)
+    got = m[0].cpu().numpy()
+    assert np.array_equal(got[decided], expect[decided])
+    clear = (r2 - r1) > 1e-3
+    assert np.array_equal(got[(got >= 0) & clear], nn1[(got >= 0) & clear])
+
+
+def test_flann_cli_end_to_end_on_synthetic_dataset(tmp_path):
+    """superpoint_flann_test.py:42-127 contract: reads <img_dir>/source1/*, <img_dir>/template1/<one>, writes
+    <Result_dir>/transformed/trans_* and <Result_dir>/Match/match_*; the synthetic sources are translations of the
+    template, so the fitted partial affine must be that translation."""
+    import os
+    import superpoint_flann_test as cli
+    img_dir, res_dir = str(tmp_path / "data") + "/", str(tmp_path / "out") + "/"
+    res = cli.main(["--img_dir", img_dir, "--Result_dir", res_dir, "--synthetic", "2", "--resize_scale", "0.5"])
+    assert sorted(os.listdir(os.path.join(res_dir, "Match"))) == ["match_src_000.png", "match_src_001.png"]
+    assert sorted(os.listdir(os.path.join(res_dir, "transformed"))) == ["trans_src_000.png", "trans_src_001.png"]
+    for i, (name, n_good, n_inl, M) in enumerate(res):
+        assert n_good > 50 and n_inl > 0.5 * n_good, (name, n_good, n_inl)
+        # source = roll(template, (16(i+1) rows, 32(i+1) cols)) at full size -> template = source shifted back
+        np.testing.assert_allclose(M[:, :2], np.eye(2), atol=0.02)
+        np.testing.assert_allclose(M[:, 2], [-32 * (i + 1), -16 * (i + 1)], atol=1.5)

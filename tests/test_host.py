@@ -142,6 +142,21 @@ def test_cli_flags_match_reference_and_kenc_string_parsing():
     assert cfg["superpoint"]["weights"] is None            # LFS-pointer / absent checkpoint -> synthetic weights
 
 
+def test_flann_cli_flags_match_reference():
+    """superpoint_flann_test.py:16-26: every reference flag exists with the same default."""
+    import superpoint_flann_test as cli
+    opt = cli.build_parser().parse_args([])
+    ref_defaults = {"img_dir": "datasets/Amazon/", "Result_dir": "Results/Camera/superpoint_allss_descriptor_128",
+                    "resize_scale": 0.25, "match_viz": True,
+                    "weights_path": "superpoint/models/weights/superPointNet_allss_descriptor_128.pth.tar",
+                    "descriptor_dim": 128, "max_keypoints": 1200, "keypoint_threshold": 0.005, "nms_radius": 4}
+    for k, v in ref_defaults.items():
+        assert getattr(opt, k) == v, k
+    assert cli.MIN_MATCH_COUNT == 4 and cli.RATIO == 0.7
+    c = cli.match_colors(np.array([0.0, 0.5, 1.0], np.float32), 128)       # dist <= 1 -> worst = 1
+    assert c.shape == (3, 4) and np.all((c >= 0) & (c <= 1))
+
+
 def test_hostops_similarity_ransac_and_warp():
     from image_matching_amd import hostops
     rng = np.random.RandomState(1)
