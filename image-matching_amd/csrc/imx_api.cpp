@@ -887,6 +887,35 @@ int imx_knn_ratio_match(imx_handle_t h, int B, const float* desc0_dev, int64_t s
   return 0;
 }
 
+int imx_ingest_resize_u8(imx_handle_t h, const uint8_t* src_dev, int B, int Hs, int Ws, int64_t src_stride_b, float* dst_dev, int H,
+                         int W, void* stream) {
+  if (!h) return -1;
+  HIP_OK(h, hipSetDevice(h->device));
+  if (B <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0) return fail(h, "imx_ingest_resize_u8: bad shape %dx%dx%d -> %dx%d", B, Hs, Ws, H, W);
+  hipStream_t s = as_stream(stream);
+  RUN("ingest_resize", launch_resize_u8_unit(src_dev, (long)src_stride_b, B, Hs, Ws, dst_dev, H, W, s));
+  return 0;
+}
+
+int imx_warp_affine_u8(imx_handle_t h, const uint8_t* src_dev, int Hs, int Ws, const double* M_host, uint8_t* dst_dev, int H, int W,
+                       void* stream) {
+  if (!h) return -1;
+  HIP_OK(h, hipSetDevice(h->device));
+  if (Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0 || !M_host) return fail(h, "imx_warp_affine_u8: bad arguments");
+  // cv2.warpAffine without WARP_INVERSE_MAP inverts the 2x3 matrix in double precision (imgwarp.cpp invertAffineTransform path)
+  const double* M = M_host;
+  double D = M[0] * M[4] - M[1] * M[3];
+  D = D != 0.0 ? 1.0 / D : 0.0;
+  const double A11 = M[4] * D, A22 = M[0] * D;
+  double inv[6];
+  inv[0] = A11; inv[1] = M[1] * (-D); inv[3] = M[3] * (-D); inv[4] = A22;
+  inv[2] = -inv[0] * M[2] - inv[1] * M[5];
+  inv[5] = -inv[3] * M[2] - inv[4] * M[5];
+  hipStream_t s = as_stream(stream);
+  RUN("warp_affine", launch_warp_affine_u8(src_dev, Hs, Ws, dst_dev, H, W, inv, s));
+  return 0;
+}
+
 int imx_set_debug(imx_handle_t h, int enable) {
   if (!h) return -1;
   h->debug = enable != 0;

@@ -150,6 +150,10 @@ struct RansacArgs {
 };
 hipError_t launch_ransac(const RansacArgs& a, hipStream_t s);
 
+// ingest / warp byte kernels (ingest.hip)
+hipError_t launch_resize_u8_unit(const uint8_t* src, long sstride, int B, int Hs, int Ws, float* dst, int H, int W, hipStream_t s);
+hipError_t launch_warp_affine_u8(const uint8_t* src, int Hs, int Ws, uint8_t* dst, int H, int W, const double* Minv, hipStream_t s);
+
 // exact 2-NN + ratio test on descriptor rows (dots from launch_score_gemm with scale 1)
 struct KnnArgs {
   const float* dots;                 // (B,N0p,N1p)

@@ -254,6 +254,34 @@ class Engine:
                                                  _ptr(m), _ptr(d1), _ptr(d2), _stream(dev)))
         return m, d1, d2
 
+    def ingest(self, img_u8, size_hw=None, out=None):
+        """cv2.resize + /255 of datasets/SSHIDataset.py:19-27 on the GPU.  img_u8: (B,Hs,Ws) or (Hs,Ws) uint8 tensor
+        (moved to the device if needed); size_hw None = no resize.  Returns (B,1,H,W) float32 in [0,1]."""
+        if img_u8.dtype != torch.uint8:
+            raise TypeError("ingest expects uint8 gray images")
+        src = img_u8.to(self.device, non_blocking=True)
+        if src.dim() == 2:
+            src = src[None]
+        src = src.contiguous()
+        B, Hs, Ws = src.shape
+        H, W = (Hs, Ws) if size_hw is None else size_hw
+        dst = out if out is not None else torch.empty(B, 1, H, W, dtype=torch.float32, device=self.device)
+        self._check(self.lib.imx_ingest_resize_u8(self.handle, _ptr(src), B, Hs, Ws, Hs * Ws, _ptr(dst), H, W, _stream(self.device)))
+        return dst
+
+    def warp_affine_u8(self, src_u8, M, size_hw=None):
+        """cv2.warpAffine(source_original*255, M, (W,H)) as cv2.imwrite stores it (superpoint_glue_test.py:101-113).
+        src_u8 (Hs,Ws) uint8 tensor; M forward 2x3 (array-like, host).  Returns (H,W) uint8 on the device."""
+        src = src_u8.to(self.device).contiguous()
+        Hs, Ws = src.shape
+        H, W = (Hs, Ws) if size_hw is None else size_hw
+        import numpy as np
+        Mh = np.ascontiguousarray(np.asarray(M, np.float64).reshape(6))
+        dst = torch.empty(H, W, dtype=torch.uint8, device=self.device)
+        self._check(self.lib.imx_warp_affine_u8(self.handle, _ptr(src), Hs, Ws, Mh.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                _ptr(dst), H, W, _stream(self.device)))
+        return dst
+
     def op_nms(self, scores, radius):
         """simple_nms on a (B,H,W) score map (single-stage entry point, used by parity tests)."""
         scores = scores.to(self.device, torch.float32).contiguous()

@@ -20,15 +20,48 @@ def imread_gray(path):
     return np.asarray(Image.open(path).convert("L"))
 
 
+def _lin_coef(n_dst, n_src, clamp_weight):
+    """OpenCV's 8U INTER_LINEAR tap table for one axis: source index and the two 11-bit weights."""
+    scale = 1.0 / (n_dst / n_src)
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    if clamp_weight:
+        lo, hi = s < 0, s >= n_src - 1
+        f = np.where(lo | hi, np.float32(0), f)
+        s = np.where(lo, 0, np.where(hi, n_src - 1, s))
+    a0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+    a1 = np.rint(f * np.float32(2048)).astype(np.int64)
+    return s, a0, a1
+
+
+def resize_linear_u8(img, size_wh):
+    """cv2.resize(uint8, size, INTER_LINEAR) restated in numpy (fixed-point, 11-bit weights); the GPU kernel
+    resize_u8_unit (csrc/ingest.hip) is bit-exact against this."""
+    img = np.asarray(img, np.uint8)
+    W, H = size_wh
+    Hs, Ws = img.shape
+    cx, a0, a1 = _lin_coef(W, Ws, True)
+    cy, b0, b1 = _lin_coef(H, Hs, False)
+    y0, y1 = np.clip(cy, 0, Hs - 1), np.clip(cy + 1, 0, Hs - 1)
+    x1 = np.minimum(cx + 1, Ws - 1)
+    im = img.astype(np.int64)
+    r0 = im[y0][:, cx] * a0 + im[y0][:, x1] * a1
+    r1 = im[y1][:, cx] * a0 + im[y1][:, x1] * a1
+    v = (((b0[:, None] * (r0 >> 4)) >> 16) + ((b1[:, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
 def resize(img, size_wh):
     if cv2 is not None:
         return cv2.resize(img, size_wh)
-    from PIL import Image
-    return np.asarray(Image.fromarray(img).resize(size_wh, Image.BILINEAR))
+    return resize_linear_u8(img, size_wh)
 
 
 def imwrite(path, img):
-    img = np.clip(np.asarray(img), 0, 255).astype(np.uint8)
+    img = np.asarray(img)
+    if img.dtype != np.uint8:               # cv2.imwrite converts with round-half-even + saturation
+        img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
     if cv2 is not None:
         return cv2.imwrite(path, img)
     from PIL import Image
@@ -82,23 +115,44 @@ def estimate_affine_partial_2d(src, dst, ransac_thresh=7.0, max_iters=2000, conf
     return M, best.astype(np.uint8)[:, None]
 
 
+def invert_affine(M):
+    """The double-precision 2x3 inversion cv2.warpAffine applies to a forward matrix."""
+    M = np.asarray(M, np.float64).reshape(2, 3)
+    D = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    inv = np.empty((2, 3))
+    inv[0, 0], inv[0, 1], inv[1, 0], inv[1, 1] = M[1, 1] * D, M[0, 1] * (-D), M[1, 0] * (-D), M[0, 0] * D
+    inv[0, 2] = -inv[0, 0] * M[0, 2] - inv[0, 1] * M[1, 2]
+    inv[1, 2] = -inv[1, 0] * M[0, 2] - inv[1, 1] * M[1, 2]
+    return inv
+
+
+def _sat_int(v):
+    return np.rint(np.clip(v, -2147483648.0, 2147483647.0)).astype(np.int64)
+
+
 def warp_affine(img, M, size_wh):
+    """cv2.warpAffine(img, M, size) for a float image, INTER_LINEAR, constant border 0: 10+5-bit fixed-point source
+    coordinates, float32 table weights, float64 accumulation (restated; bit-exact twin of csrc/ingest.hip)."""
     if cv2 is not None:
         return cv2.warpAffine(img, M, size_wh)
     W, H = size_wh
-    A = np.vstack([M, [0, 0, 1]])
-    Ai = np.linalg.inv(A)
-    ys, xs = np.mgrid[0:H, 0:W]
-    sx = Ai[0, 0] * xs + Ai[0, 1] * ys + Ai[0, 2]
-    sy = Ai[1, 0] * xs + Ai[1, 1] * ys + Ai[1, 2]
-    x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
-    fx, fy = sx - x0, sy - y0
+    m = invert_affine(M).ravel()
+    xs, ys = np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64)
+    X = ((_sat_int((m[1] * ys + m[2]) * 1024.0) + 16)[:, None] + _sat_int(m[0] * xs * 1024.0)[None]) >> 5
+    Y = ((_sat_int((m[4] * ys + m[5]) * 1024.0) + 16)[:, None] + _sat_int(m[3] * xs * 1024.0)[None]) >> 5
+    ix, iy = X >> 5, Y >> 5
+    fx, fy = (X & 31).astype(np.float32) / np.float32(32), (Y & 31).astype(np.float32) / np.float32(32)
+    one = np.float32(1)
     img = np.asarray(img, np.float64)
+    Hs, Ws = img.shape
     out = np.zeros((H, W), np.float64)
-    for dy, dx, w in ((0, 0, (1 - fx) * (1 - fy)), (0, 1, fx * (1 - fy)), (1, 0, (1 - fx) * fy), (1, 1, fx * fy)):
-        xx, yy = x0 + dx, y0 + dy
-        ok = (xx >= 0) & (xx < img.shape[1]) & (yy >= 0) & (yy < img.shape[0])
-        out[ok] += w[ok] * img[yy[ok], xx[ok]]
+    for dy, dx, w in ((0, 0, (one - fy) * (one - fx)), (0, 1, (one - fy) * fx), (1, 0, fy * (one - fx)), (1, 1, fy * fx)):
+        xx, yy = ix + dx, iy + dy
+        ok = (xx >= 0) & (xx < Ws) & (yy >= 0) & (yy < Hs)
+        tap = np.zeros((H, W), np.float64)
+        tap[ok] = img[yy[ok], xx[ok]]
+        out = out + tap * w.astype(np.float64)
     return out
 
 

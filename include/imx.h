@@ -149,6 +149,19 @@ int imx_knn_ratio_match(imx_handle_t h, int B,
                         const int32_t* n1_dev, int N1, float ratio,
                         int64_t* matches_dev, float* dist1_dev, float* dist2_dev, void* stream);
 
+/* Image ingest: cv2.resize(uint8 gray, (W,H)) [INTER_LINEAR] followed by `/255`
+ * (datasets/SSHIDataset.py:19-27) on the GPU: src_dev (B,Hs,Ws) uint8 (batch stride src_stride_b bytes) ->
+ * dst_dev (B,H,W) float32 in [0,1], ready for imx_superpoint_detect / imx_match_pairs.  H==Hs, W==Ws is the
+ * `resize_scale is None` path (plain /255). */
+int imx_ingest_resize_u8(imx_handle_t h, const uint8_t* src_dev, int B, int Hs, int Ws, int64_t src_stride_b,
+                         float* dst_dev, int H, int W, void* stream);
+
+/* Warp post-step: cv2.warpAffine(source_original*255, Matrix, (W,H)) as written by cv2.imwrite
+ * (superpoint_glue_test.py:101-113, superpoint_flann_test.py:88-92).  M_host: forward 2x3 matrix, 6 doubles on
+ * the host (row-major).  src_dev (Hs,Ws) uint8 -> dst_dev (H,W) uint8. */
+int imx_warp_affine_u8(imx_handle_t h, const uint8_t* src_dev, int Hs, int Ws, const double* M_host,
+                       uint8_t* dst_dev, int H, int W, void* stream);
+
 /* Single-stage entry point: simple_nms (superpoint_test.py:7-22) on a caller-supplied score map
  * (B,H,W) -> out (B,H,W).  Compare-only arithmetic: bit-exact given identical input. */
 int imx_op_nms(imx_handle_t h, const float* scores_dev, float* out_dev, int B, int H, int W,

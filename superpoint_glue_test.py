@@ -103,10 +103,6 @@ def main(argv=None):
     config = make_config(opt)
     if opt.synthetic > 0:
         write_synthetic_dataset(opt.img_dir, opt.synthetic, opt.resize_scale or 1.0)
-    source_dir = opt.img_dir + 'source1/'
-    template_dir = opt.img_dir + 'template1/'
-    template_img_path = template_dir + os.listdir(template_dir)[0]
-
     matching = Matching(config).eval().to(device)
     if config['superpoint']['weights'] is None and opt.descriptor_dim in (128, 256):
         matching.superpoint.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in
@@ -115,7 +111,15 @@ def main(argv=None):
             and list(config['superglue']['keypoint_encoder']) == synth.SG_CONFIGS[opt.descriptor_dim][0]:
         matching.superglue.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in
                                             synth.make_superglue_state_dict(opt.descriptor_dim).items()})
+    return run_registration(opt, matching, device)
 
+
+def run_registration(opt, matching, device):
+    """The per-pair loop shared by superpoint_glue_test.py:72-140 and superpoint_glue_official_test.py:66-137."""
+    source_dir = opt.img_dir + 'source1/'
+    template_dir = opt.img_dir + 'template1/'
+    template_img_path = template_dir + os.listdir(template_dir)[0]
+    results = []
     Matrix = None
     for filename in sorted(os.listdir(source_dir)):
         source_original, source_image, template_image = load_pair(source_dir + filename, template_img_path, opt.resize_scale)
@@ -147,6 +151,7 @@ def main(argv=None):
                 flag = (mask > 0).ravel().tolist()
                 mkpts0, mkpts1 = mkpts0[flag], mkpts1[flag]
         print("Time used:", time.perf_counter() - start)
+        results.append((filename, len(kpts0), len(kpts1), int(valid.sum()), len(mkpts0), None if Matrix is None else Matrix.copy()))
 
         src255 = source_original.squeeze() * 255
         if Matrix is not None:
@@ -167,6 +172,7 @@ def main(argv=None):
             hostops.make_matching_plot_fast(source_image.squeeze() * 255, template_image.squeeze() * 255, kpts0, kpts1,
                                             mkpts0, mkpts1, color, text, path=out_file,
                                             show_keypoints=opt.show_keypoints, small_text=small_text)
+    return results
 
 
 if __name__ == '__main__':

@@ -109,6 +109,17 @@ def test_cli_end_to_end_on_synthetic_dataset(tmp_path):
     assert sorted(os.listdir(os.path.join(res_dir, "t", "Transform"))) == ["trans_src_000.png", "trans_src_001.png"]
 
 
+def test_official_cli_end_to_end_on_synthetic_dataset(tmp_path):
+    """superpoint_glue_official_test.py:53-137: official (no-BN, d=256) SuperPoint + SuperGlue through the same loop."""
+    import os
+    import superpoint_glue_official_test as cli
+    img_dir, res_dir = str(tmp_path / "data") + "/", str(tmp_path / "out") + "/"
+    res = cli.main(["--img_dir", img_dir, "--Result_dir", res_dir, "--synthetic", "2", "--resize_scale", "0.5",
+                    "--max_keypoints", "512", "--exper_name", "o"])
+    assert sorted(os.listdir(os.path.join(res_dir, "o", "Match"))) == ["src_000.png", "src_001.png"]
+    assert [r[0] for r in res] == ["src_000.png", "src_001.png"] and all(r[1] == 512 and r[2] == 512 for r in res)
+
+
 def test_pair_sharding_is_order_independent():
     """C4 shape in miniature: 8 pairs processed as two round-robin shards (what 2 ranks would do) and
     collected through pack/gather/sort give exactly the records of one 8-pair batch."""

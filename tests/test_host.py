@@ -18,7 +18,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 def test_library_exports_every_declared_symbol():
     lib = _lib.load_library()
     header = open(os.path.join(ROOT, "include", "imx.h")).read()
-    declared = set(re.findall(r"\b(imx_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(imx_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     for name in declared:
         assert hasattr(lib, name), f"libimx.so does not export {name}"
@@ -140,6 +140,23 @@ def test_cli_flags_match_reference_and_kenc_string_parsing():
     cfg = cli.make_config(opt)
     assert cfg["superglue"]["keypoint_encoder"] == [32, 64] and cfg["superpoint"]["max_keypoints"] == 100
     assert cfg["superpoint"]["weights"] is None            # LFS-pointer / absent checkpoint -> synthetic weights
+
+
+def test_official_cli_flags_match_reference():
+    """superpoint_glue_official_test.py:16-33: every reference flag exists with the same default (typo included)."""
+    import superpoint_glue_official_test as cli
+    opt = cli.build_parser().parse_args([])
+    ref_defaults = {"exper_name": "superpoint_glue_official", "img_dir": "datasets/Camera/", "Result_dir": "Results/Camera/",
+                    "resize_scale": 0.125, "match_viz": True, "show_keypoints": True, "descriptor_dim": 256,
+                    "superpoint_weights": "supeeglue/models/weights/superpoint_v1.pth",
+                    "superglue_weights": "superglue/models/weights/superglue_indoor.pth",
+                    "sinkhorn_iterations": 30, "match_threshold": 0.1, "keypoint_threshold": 0.005, "nms_radius": 4,
+                    "max_keypoints": -1}
+    for k, v in ref_defaults.items():
+        assert getattr(opt, k) == v, k
+    cfg = cli.make_config(opt)
+    assert cfg["superpoint"]["weights_path"] is None and cfg["superglue"]["weights"] is None
+    assert "keypoint_encoder" not in cfg["superglue"]          # the official CLI leaves the d=256 default encoder
 
 
 def test_flann_cli_flags_match_reference():
