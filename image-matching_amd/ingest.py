@@ -24,20 +24,32 @@ class IngestPipeline:
         } for _ in range(depth)]
         self.next = 0
 
-    def submit(self, images):
-        """images: sequence of <= batch uint8 (Hs,Ws) numpy arrays / tensors.  Returns a ticket for `take`."""
+    def staging(self):
+        """The next slot's pinned (batch,Hs,Ws) uint8 buffer as a numpy view, so a decoder can write frames straight
+        into page-locked memory (then call `submit_staged(n)`); blocks until that slot's previous batch was consumed."""
         slot = self.slots[self.next]
-        self.next = (self.next + 1) % len(self.slots)
         if slot["used"]:
             slot["free"].synchronize()             # the consumer of this slot's previous batch has finished
+        return slot["pinned"].numpy()
+
+    def submit(self, images):
+        """images: sequence of <= batch uint8 (Hs,Ws) numpy arrays / tensors.  Returns a ticket for `take`."""
         n = len(images)
         if n > self.B:
             raise ValueError(f"{n} images for a batch of {self.B}")
+        self.staging()
+        pinned = self.slots[self.next]["pinned"]
         for i, im in enumerate(images):
             t = im if torch.is_tensor(im) else torch.from_numpy(im)
             if tuple(t.shape) != self.src_hw or t.dtype != torch.uint8:
                 raise ValueError(f"image {i}: expected uint8 {self.src_hw}, got {t.dtype} {tuple(t.shape)}")
-            slot["pinned"][i].copy_(t)
+            pinned[i].copy_(t)
+        return self.submit_staged(n)
+
+    def submit_staged(self, n):
+        """Ship the first n frames of the buffer `staging()` returned."""
+        slot = self.slots[self.next]
+        self.next = (self.next + 1) % len(self.slots)
         with torch.cuda.stream(self.copy_stream):
             slot["dev_u8"][:n].copy_(slot["pinned"][:n], non_blocking=True)
             self.engine.ingest(slot["dev_u8"][:n], self.dst_hw, out=slot["out"][:n])

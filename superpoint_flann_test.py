@@ -110,7 +110,10 @@ def main(argv=None):
             if opt.resize_scale is not None:
                 Matrix[:, 2] = Matrix[:, 2] / opt.resize_scale
             src255 = source_original.squeeze() * 255
-            Transform = hostops.warp_affine(src255, Matrix, (src255.shape[1], src255.shape[0]))
+            if opt.ransac == 'gpu':
+                Transform = eng.warp_affine_u8(torch.from_numpy(np.rint(src255).astype(np.uint8)), Matrix).cpu().numpy()
+            else:
+                Transform = hostops.warp_affine(src255, Matrix, (src255.shape[1], src255.shape[0]))
             Transform_dir = os.path.join(opt.Result_dir, 'transformed/')
             os.makedirs(Transform_dir, exist_ok=True)
             hostops.imwrite(Transform_dir + 'trans_{}'.format(filename), Transform)

@@ -155,7 +155,11 @@ def run_registration(opt, matching, device):
 
         src255 = source_original.squeeze() * 255
         if Matrix is not None:
-            Transform = hostops.warp_affine(src255, Matrix, (src255.shape[1], src255.shape[0]))
+            if opt.ransac == 'gpu':        # warp on the GPU too (imx_warp_affine_u8): same fixed-point arithmetic as cv2.warpAffine
+                src_u8 = torch.from_numpy(np.rint(src255).astype(np.uint8))
+                Transform = matching._shared.engine.warp_affine_u8(src_u8, Matrix).cpu().numpy()
+            else:
+                Transform = hostops.warp_affine(src255, Matrix, (src255.shape[1], src255.shape[0]))
             Transform_dir = os.path.join(opt.Result_dir, opt.exper_name, 'Transform/')
             os.makedirs(Transform_dir, exist_ok=True)
             hostops.imwrite(Transform_dir + 'trans_{}'.format(filename), Transform)

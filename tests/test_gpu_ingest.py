@@ -72,13 +72,13 @@ def test_ingest_pipeline_feeds_matching_identically():
     pipe0 = IngestPipeline(eng, 2, (960, 1280), (480, 640))
     pipe1 = IngestPipeline(eng, 2, (960, 1280), (480, 640))
     outs = []
-    tickets = [(pipe0.submit([f[0] for f in frames[0:2]]), pipe1.submit([f[1] for f in frames[0:2]]))]
+    ship = lambda k: (pipe0.submit([f[0] for f in frames[2 * k:2 * k + 2]]), pipe1.submit([f[1] for f in frames[2 * k:2 * k + 2]]))
+    t = ship(0)
     for k in range(3):
+        outs.append(m.match_batch(pipe0.take(t[0]), pipe1.take(t[1])))
+        pipe0.release(t[0]), pipe1.release(t[1])
         if k + 1 < 3:
-            tickets.append((pipe0.submit([f[0] for f in frames[2 * k + 2:2 * k + 4]]), pipe1.submit([f[1] for f in frames[2 * k + 2:2 * k + 4]])))
-        t0, t1 = tickets[k]
-        outs.append(m.match_batch(pipe0.take(t0), pipe1.take(t1)))
-        pipe0.release(t0), pipe1.release(t1)
+            t = ship(k + 1)
     torch.cuda.synchronize()
     for k in range(3):
         host0 = torch.stack([torch.from_numpy(hostops.resize_linear_u8(f[0], (640, 480)) / 255).float()[None] for f in frames[2 * k:2 * k + 2]]).cuda()
