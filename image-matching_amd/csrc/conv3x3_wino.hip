@@ -28,6 +28,7 @@
 #include "imx_kernels.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace imx {
 
@@ -53,9 +54,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* V = smem;
   float* raw = V + VSZ;                 // raw input patch [10][18][12]
-  float* img = raw + (FIRST ? RAWF : RAW);   // FIRST only: image patch, conv1a weights + bias
-  float* w1s = img + IMG_H * IMG_W;
-  float* b1s = w1s + 9 * 64;
+  float* img = raw + (FIRST ? RAWF : RAW);   // FIRST only: image patch 12 x 20
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cb = wave;          // wave = one 16-channel column block x BOTH 16-wtile row blocks (halves the B traffic)
@@ -71,38 +70,52 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
 
   if constexpr (FIRST) {
     const float* im = (b < p.split) ? p.in + (size_t)b * H * W : p.in2 + (size_t)(b - p.split) * H * W;
+    float wr[9];                       // issued together with the image patch loads: one latency, not two
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) wr[tp] = p.w1[tp * 64 + lane];
+    const float bias = p.b1[lane];
     for (int e = tid; e < IMG_H * IMG_W; e += 256) {
       const int py = e / IMG_W, px = e % IMG_W;
       const int gy = y0 + py - 2, gx = x0 + px - 2;
       img[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.f;
     }
-    for (int e = tid; e < 9 * 64; e += 256) w1s[e] = p.w1[e];
-    if (tid < 64) b1s[tid] = p.b1[tid];
     __syncthreads();
-    // conv1a + folded BN + ReLU for ALL 64 channels of the 10x18 halo patch, once per workgroup
-    // (item = pixel x 16 channels; positions outside the image are conv1b's zero padding)
-    for (int e = tid; e < RH * RW * 4; e += 256) {
-      const int pix = e >> 2, cq = (e & 3) * 16;
-      const int py = pix / RW, px = pix % RW;
-      const int gy = y0 + py - 1, gx = x0 + px - 1;
-      float v[16];
+    // conv1a + folded BN + ReLU for ALL 64 channels of the 10x18 halo patch, once per workgroup.  lane = channel
+    // (its 9 weights + bias live in registers), wave = 5 half-rows of 9 pixels; the image taps are wave-uniform
+    // float4 broadcasts from LDS (9 reads per half-row), so the phase is FMA-bound instead of LDS-bound.
+    // Positions outside the image are conv1b's zero padding.
+    {
+      auto half_row = [&](int hr, auto odd_c) {
+        constexpr int ODD = decltype(odd_c)::value;        // odd half-rows start at pixel 9: taps 9..19 sit in floats 8..19
+        const int py = hr >> 1, xo = ODD * 9, xb = ODD * 8;
+        float tap[3][12];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = 0.f;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = b1s[cq + j];
+          for (int q4 = 0; q4 < 3; ++q4) {
+            const float4 tv = *reinterpret_cast<const float4*>(img + (py + dy) * IMG_W + xb + 4 * q4);
+            tap[dy][4 * q4] = tv.x; tap[dy][4 * q4 + 1] = tv.y; tap[dy][4 * q4 + 2] = tv.z; tap[dy][4 * q4 + 3] = tv.w;
+          }
+        const int gy = y0 + py - 1;
+        const float rowmask = (gy >= 0 && gy < H) ? 1.f : 0.f;      // masks as multiplies: no per-pixel scalar branches
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) {
-          const float iv = img[(py + tp / 3) * IMG_W + px + tp % 3];
+        for (int px = 0; px < 9; ++px) {
+          float v = bias;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) v[j] = fmaf(iv, w1s[tp * 64 + cq + j], v[j]);
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) v = fmaf(tap[dy][px + dx + ODD], wr[dy * 3 + dx], v);
+          const int gx = x0 + xo + px - 1;
+          const float mask = (gx >= 0 && gx < W) ? rowmask : 0.f;
+          raw[(py * RW + xo + px) * RSF + lane] = fmaxf(v, 0.f) * mask;
         }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
+      };
+#pragma unroll 1
+      for (int k = 0; k < 5; ++k) {
+        const int hr = __builtin_amdgcn_readfirstlane(wave * 5 + k);
+        if (hr & 1) half_row(hr, std::integral_constant<int, 1>{});
+        else half_row(hr, std::integral_constant<int, 0>{});
       }
-      float4* dst = reinterpret_cast<float4*>(raw + pix * RSF + cq);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dst[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
     }
   }
 
@@ -320,7 +333,7 @@ template <bool POOL, bool RELU, bool FIRST>
 hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = (a.W + OW - 1) / OW, tiles_y = (a.H + OH - 1) / OH;
   dim3 grid((unsigned)(tiles_x * tiles_y * a.B), (unsigned)(a.Cout / NT));
-  size_t lds = (size_t)(VSZ + (FIRST ? RAWF + IMG_H * IMG_W + 9 * 64 + 64 : RAW)) * sizeof(float);
+  size_t lds = (size_t)(VSZ + (FIRST ? RAWF + IMG_H * IMG_W : RAW)) * sizeof(float);
   if (!POOL && lds < (size_t)OH * OW * (NT + 4) * sizeof(float)) lds = (size_t)OH * OW * (NT + 4) * sizeof(float);   // epilogue staging tile
   if (getenv("IMX_WINO_TRACE")) {      // bring-up instrumentation: per-phase cycle counts of the first 4096 workgroups
     static unsigned* dbuf = nullptr;

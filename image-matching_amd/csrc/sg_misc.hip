@@ -163,12 +163,29 @@ __global__ __launch_bounds__(1024) void sinkhorn_slab(SinkhornArgs a, float* __r
     if (i > m) break;
     LSE acc{-INFINITY, 0.f};
     if (i < m) {
+      // a row is N1p (multiple of 32) floats, 16-byte aligned: four float4 loads per lane are issued before any of
+      // them is consumed, so the wave keeps 4 KB in flight (a scalar loop serialised one 256 B load per latency)
       const float* Srow = a.S + ((size_t)b * a.N0p + i) * a.N1p;
       float* trow = tile + r * a.N1p;
-      for (int j = lane; j < n; j += 64) {
-        const float sv = Srow[j];
-        trow[j] = sv;
-        lse_add(acc, sv + vs[j]);
+      for (int j0 = 0; j0 < n; j0 += 1024) {
+        float4 x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int j = j0 + k * 256 + lane * 4;
+          x[k] = j < a.N1p ? *reinterpret_cast<const float4*>(Srow + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int j = j0 + k * 256 + lane * 4;
+          if (j < a.N1p) {
+            *reinterpret_cast<float4*>(trow + j) = x[k];
+            const float4 vv = *reinterpret_cast<const float4*>(vs + j);
+            if (j + 0 < n) lse_add(acc, x[k].x + vv.x);
+            if (j + 1 < n) lse_add(acc, x[k].y + vv.y);
+            if (j + 2 < n) lse_add(acc, x[k].z + vv.z);
+            if (j + 3 < n) lse_add(acc, x[k].w + vv.w);
+          }
+        }
       }
     } else {
       for (int j = lane; j < n; j += 64) lse_add(acc, a.alpha + vs[j]);
@@ -187,18 +204,24 @@ __global__ __launch_bounds__(1024) void sinkhorn_slab(SinkhornArgs a, float* __r
   float2* pb = reinterpret_cast<float2*>(part + ((size_t)b * nslab_max + slab) * (a.N1p + 1) * 2);
   for (int j = tid; j <= n; j += 1024) {
     LSE acc{-INFINITY, 0.f};
-    for (int r = 0; r < rows; ++r) {
-      const bool real = (i0 + r < m) && (j < n);
-      lse_add(acc, (real ? tile[r * a.N1p + j] : a.alpha) + uu[r]);
+    float t[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) t[r] = tile[r * a.N1p + j];          // rows beyond `rows` hold stale data, unused
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r < rows) {
+        const bool real = (i0 + r < m) && (j < n);
+        lse_add(acc, (real ? t[r] : a.alpha) + uu[r]);
+      }
     }
     pb[j] = make_float2(acc.m, acc.s);
   }
 }
 
-// v[j] = log_nu[j] - logsumexp over the slabs' partial (max, sum) pairs.  64 columns x 4 slab groups
-// per workgroup so the (few dozen) partial loads of a column are spread over 4 threads.
-__global__ __launch_bounds__(256) void sinkhorn_vmerge(SinkhornArgs a, const float* __restrict__ part, int nslab_max, int R) {
-  __shared__ float pm[4][64], ps[4][64];
+// v[j] = log_nu[j] - logsumexp over the slabs' partial (max, sum) pairs.  64 columns x 16 slab groups per
+// workgroup; each thread loads its (up to 4 at a time) partials before merging them, so the loads overlap.
+__global__ __launch_bounds__(1024) void sinkhorn_vmerge(SinkhornArgs a, const float* __restrict__ part, int nslab_max, int R) {
+  __shared__ float pm[16][64], ps[16][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int b = blockIdx.y, j = blockIdx.x * 64 + c;
   int m, n;
@@ -208,9 +231,15 @@ __global__ __launch_bounds__(256) void sinkhorn_vmerge(SinkhornArgs a, const flo
   LSE t{-INFINITY, 0.f};
   if (j <= n) {
     const float2* pb = reinterpret_cast<const float2*>(part + (size_t)b * nslab_max * (a.N1p + 1) * 2) + j;
-    for (int sl = g; sl < nslab; sl += 4) {
-      const float2 q = pb[(size_t)sl * (a.N1p + 1)];
-      t = lse_merge(t, LSE{q.x, q.y});
+    for (int s0 = g; s0 < nslab; s0 += 64) {
+      float2 q[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sl = s0 + 16 * k;
+        q[k] = sl < nslab ? pb[(size_t)sl * (a.N1p + 1)] : make_float2(-INFINITY, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t = lse_merge(t, LSE{q[k].x, q[k].y});
     }
   }
   pm[g][c] = t.m;
@@ -218,7 +247,7 @@ __global__ __launch_bounds__(256) void sinkhorn_vmerge(SinkhornArgs a, const flo
   __syncthreads();
   if (g == 0 && j <= n) {
 #pragma unroll
-    for (int k = 1; k < 4; ++k) t = lse_merge(t, LSE{pm[k][c], ps[k][c]});
+    for (int k = 1; k < 16; ++k) t = lse_merge(t, LSE{pm[k][c], ps[k][c]});
     const float norm = -logf((float)(m + n));
     const float log_nu = j < n ? norm : logf((float)m) + norm;
     a.v[(size_t)b * (a.N1p + 1) + j] = log_nu - lse_value(t);
@@ -357,7 +386,7 @@ static void launch_slab_iter(const SinkhornArgs& a, int nslab_max, hipStream_t s
     attr = true;
   }
   hipLaunchKernelGGL(sinkhorn_slab<R>, dim3((unsigned)nslab_max, (unsigned)a.B), dim3(1024), lds, s, a, a.part, nslab_max);
-  hipLaunchKernelGGL(sinkhorn_vmerge, dim3((unsigned)((a.N1p + 1 + 63) / 64), (unsigned)a.B), dim3(256), 0, s, a, a.part, nslab_max, R);
+  hipLaunchKernelGGL(sinkhorn_vmerge, dim3((unsigned)((a.N1p + 1 + 63) / 64), (unsigned)a.B), dim3(1024), 0, s, a, a.part, nslab_max, R);
 }
 
 hipError_t launch_sinkhorn(const SinkhornArgs& a, hipStream_t s) {
