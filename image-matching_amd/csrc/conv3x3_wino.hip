@@ -246,12 +246,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
             af[nxt][i][1] = va[((qb + i) * 4 + 2 * s1) * VK + 32];
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
         const int q0 = (g & 3) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           acc[q0 + i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][0], bf[q0 + i][g >> 2], acc[q0 + i][0], 0, 0, 0);
           acc[q0 + i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][1], bf[q0 + i][g >> 2], acc[q0 + i][1], 0, 0, 0);
+        }
+        // one MFMA, then one LDS read (next group's A operand) / one other instruction in its shadow
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+          __builtin_amdgcn_sched_group_barrier(0x026, 1, 0);     // VALU / SALU / VMEM read (raw patch fetch, addressing)
         }
         __builtin_amdgcn_sched_barrier(0);
       }
