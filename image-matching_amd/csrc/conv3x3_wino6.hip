@@ -1,0 +1,504 @@
+// 3x3 convolution (pad 1) + folded BatchNorm + ReLU (+ fused 2x2 max-pool, + fused conv1a) as Winograd F(2x2,3x3)
+// on the fp32 matrix cores -- persistent, wave-specialised form for gfx950 (MI355X).
+//
+// Replaces double_conv / inconv / down (superpoint/models/unet_parts.py:10-48) and convPa/convDa
+// (superpoint_test.py:76-84); same arithmetic as conv3x3_wino.hip (U = G g G^T precomputed at weight load,
+// V = B^T d B per tile, Y = A^T M A in-lane), different execution shape:
+//
+//   * one workgroup of 8 waves per CU, persistent over a list of (tile, 64-channel block) work items;
+//   * waves 0-3 are CONSUMERS: nothing but v_mfma_f32_16x16x4_f32 (64 per 8-channel chunk), their A operands from
+//     LDS (V) and B operands (U) from L2 into a double-buffered register panel, and the in-lane output transform;
+//   * waves 4-7 are PRODUCERS: they fetch the next raw 10x18x8 input patches (or compute them: FIRST mode fuses
+//     conv1a), run the input transform into the other V buffer, and write finished output tiles from an LDS
+//     staging tile to HBM as whole 256-byte channel rows;
+//   * ONE barrier per chunk.  Prologue, input transform, epilogue stores and index arithmetic all run in the shadow
+//     of the consumers' MFMA stream instead of in series with it (conv3x3_wino.hip measured 2.05k MFMA cycles inside
+//     a 5.1-6.0k-cycle chunk period plus a 13-17 % prologue/epilogue share).
+//
+// Tile = 4x8 Winograd tiles (8x16 output pixels) x 64 output channels; consumer wave cb owns channels cb*16..+16 for
+// all 32 wtiles: acc[16 positions][2 row blocks] (128 accumulator registers).  LDS: V[2] 36 KB, raw[2] 17 KB,
+// output staging 34 KB (+ 2 image patches in FIRST mode) = 89 KB.  XCD-aware: the work list is cut into 8
+// contiguous ranges (workgroup g runs on XCD g % 8), so the 32 workgroups of an XCD walk neighbouring tiles and share
+// halos / weights in that XCD's L2.
+#include "imx_kernels.h"
+#include <type_traits>
+#include <cstdio>
+
+namespace imx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+#ifndef EXP_NOB
+#define EXP_NOB 0
+#endif
+#ifndef EXP_NOT
+#define EXP_NOT 0
+#endif
+#ifndef W6_TRACE
+#define W6_TRACE 0
+#endif
+#if W6_TRACE
+__device__ unsigned long long w6_trace[8];
+#define W6_T(var) const unsigned long long var = __builtin_readcyclecounter();
+#else
+#define W6_T(var)
+#endif
+constexpr int TR = 4, TC = 8, OH = 2 * TR, OW = 2 * TC;
+constexpr int RH = OH + 2, RW = OW + 2, RS = 12;
+constexpr int CK = 8, NT = 64;
+constexpr int RAW = RH * RW * RS;        // 2160
+constexpr int VK = 72, VSZ = 16 * 4 * VK; // 4608
+constexpr int USZ = 16 * 2 * 4 * 4 * 16;  // 8192
+constexpr int IMG_H = RH + 2, IMG_W = RW + 2, IMG = IMG_H * IMG_W;   // 12 x 20
+constexpr int OS = NT + 4;
+constexpr int OTSZ = OH * OW * OS;        // 8704
+constexpr int NXCD = 8;
+
+struct Item { int b, y0, x0, cob; };
+
+struct Sched {
+  int tiles_x, tiles_y, ncob, total, per_xcd, first, limit, stride, count;
+  __device__ __forceinline__ void init(const ConvArgs& p, int g, int G) {
+    tiles_x = (p.W + OW - 1) / OW;
+    tiles_y = (p.H + OH - 1) / OH;
+    ncob = p.Cout / NT;
+    total = tiles_x * tiles_y * p.B * ncob;
+    per_xcd = (total + NXCD - 1) / NXCD;
+    const int xcd = g % NXCD;
+    stride = G / NXCD;
+    first = xcd * per_xcd + g / NXCD;
+    limit = min(total, (xcd + 1) * per_xcd);
+    count = first < limit ? (limit - first + stride - 1) / stride : 0;
+  }
+  __device__ __forceinline__ Item item(int k) const {
+    int w = first + k * stride;
+    Item it;
+    it.cob = w % ncob; w /= ncob;
+    it.x0 = (w % tiles_x) * OW; w /= tiles_x;
+    it.y0 = (w % tiles_y) * OH;
+    it.b = w / tiles_y;
+    return it;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ consumer side
+// B operands (U) come straight from L2 into ONE 32-register panel that is refilled in place with the next chunk's
+// values, four registers at a time, right behind the MFMAs that read them (the refill sits in the NEXT scheduling
+// region so it cannot be hoisted above those MFMAs; a second panel does not fit next to 128 accumulators).  Row (pos, k-step) of a wave's panel is 256 contiguous bytes: [pos][k-step][co-block][4 k][16 co].
+// Buffer loads: descriptor + block offset live in SGPRs, the only VGPR is the lane offset.  U layout (wu6):
+// [k-step][pos group][co-block][lane][4 pos] -- the four B registers of one MFMA group are ONE dwordx4 per lane, so a
+// chunk's panel is 8 vector-memory instructions instead of 32 (their issue cost sits in the MFMA stream).
+__device__ __forceinline__ f32x4 u_load(__amdgpu_buffer_rsrc_t ur, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, soff, 0));
+}
+__device__ __forceinline__ void load_b_panel(f32x4 (&bf)[8], __amdgpu_buffer_rsrc_t ur, int uoff, int voff) {
+#pragma unroll
+  for (int g = 0; g < 8; ++g) bf[g] = u_load(ur, voff, uoff + g * 4096);
+}
+
+// 16 positions x 2 k-steps x 2 row blocks of v_mfma_f32_16x16x4_f32 in 8 groups of 8 (group g = k-step g>>2, positions
+// 4(g&3)..+3); A operands from LDS one group ahead; bf[g] = group g's four B registers, refilled in place with the next
+// chunk's right behind the MFMAs that read them (the refill sits in the NEXT scheduling region so it cannot be hoisted
+// above those MFMAs; a second panel does not fit next to 128 accumulators).
+template <bool ZERO>      // ZERO: first chunk of a tile, the accumulators start from 0 (no clearing pass after the epilogue)
+__device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[16][2], const float* Vb, f32x4 (&bf)[8], __amdgpu_buffer_rsrc_t ur, int uoff,
+                                           int voff, int lane) {
+  const float* va = Vb + (lane >> 5) * VK + (lane & 15) * 2 + ((lane >> 4) & 1);
+  float af[2][4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    af[0][i][0] = va[(i * 4) * VK];
+    af[0][i][1] = va[(i * 4) * VK + 32];
+  }
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int cur = g & 1, nxt = cur ^ 1;
+    if (g + 1 < 8) {
+      const int s1 = (g + 1) >> 2, qb = ((g + 1) & 3) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[nxt][i][0] = va[((qb + i) * 4 + 2 * s1) * VK];
+        af[nxt][i][1] = va[((qb + i) * 4 + 2 * s1) * VK + 32];
+      }
+    }
+    const int q0 = (g & 3) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      const bool fresh = ZERO && g < 4;       // k-step 0 touches every accumulator once
+      acc[q0 + i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][0], bf[g][i], fresh ? zero : acc[q0 + i][0], 0, 0, 0);
+      acc[q0 + i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][1], bf[g][i], fresh ? zero : acc[q0 + i][1], 0, 0, 0);
+    }
+    if (g > 0) bf[g - 1] = u_load(ur, voff, uoff + (g - 1) * 4096);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read (next group's A)
+      __builtin_amdgcn_sched_group_barrier(0x026, 1, 0);     // VALU / SALU / VMEM read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  bf[7] = u_load(ur, voff, uoff + 7 * 4096);
+}
+
+// Y = A^T M A in-lane, bias, ReLU, (2x2 max-pool) -> LDS staging tile Ot[pixel][OS].
+template <bool POOL, bool RELU>
+__device__ __forceinline__ void output_transform(f32x4 (&acc)[16][2], float* Ot, const float* bias, int n0, int cb, int lane) {
+  asm volatile("" : "+v"(lane));      // opaque: keeps the staging addresses from being hoisted out of the chunk loop (they would
+                                       // sit in ~16 registers next to 128 accumulators + two B panels and force spills)
+  const int col = cb * 16 + (lane & 15);
+  const float bs = bias[n0 + col];
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int w = jb * 16 + 4 * (lane >> 4) + r;
+      const int wr = w >> 3, wc = w & 7;
+      float m[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { m[q] = acc[q][jb][r]; acc[q][jb][r] = 0.f; }
+      float t0[4], t1[4];
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        t0[nu] = m[0 * 4 + nu] + m[1 * 4 + nu] + m[2 * 4 + nu];
+        t1[nu] = m[1 * 4 + nu] - m[2 * 4 + nu] - m[3 * 4 + nu];
+      }
+      float y00 = t0[0] + t0[1] + t0[2] + bs, y01 = t0[1] - t0[2] - t0[3] + bs;
+      float y10 = t1[0] + t1[1] + t1[2] + bs, y11 = t1[1] - t1[2] - t1[3] + bs;
+      if (RELU) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
+      if constexpr (POOL) {
+        Ot[(wr * TC + wc) * OS + col] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
+      } else {
+        float* o = Ot + ((2 * wr) * OW + 2 * wc) * OS + col;
+        o[0] = y00;
+        o[OS] = y01;
+        o[OW * OS] = y10;
+        o[OW * OS + OS] = y11;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ producer side
+__device__ __forceinline__ f32x4 nt_load4(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+
+// input transform V = B^T d B: thread = (channel tc, wtile tw); raw pixel stride 12 keeps the reads conflict free
+__device__ __forceinline__ void input_transform(const float* raw, float* V, int ptid) {
+  const int tc = ptid & 7, tw = ptid >> 3, twr = tw >> 3, twc = tw & 7;
+  const float* rp = raw + ((2 * twr) * RW + 2 * twc) * RS + tc;
+  float d[16];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) d[a * 4 + bb] = rp[(a * RW + bb) * RS];
+  float tt[4][4];
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb) {
+    tt[0][bb] = d[0 * 4 + bb] - d[2 * 4 + bb];
+    tt[1][bb] = d[1 * 4 + bb] + d[2 * 4 + bb];
+    tt[2][bb] = d[2 * 4 + bb] - d[1 * 4 + bb];
+    tt[3][bb] = d[1 * 4 + bb] - d[3 * 4 + bb];
+  }
+  float* vp = V + (tc >> 1) * VK + tw * 2 + (tc & 1);
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi) {
+    vp[((xi * 4 + 0) * 4) * VK] = tt[xi][0] - tt[xi][2];
+    vp[((xi * 4 + 1) * 4) * VK] = tt[xi][1] + tt[xi][2];
+    vp[((xi * 4 + 2) * 4) * VK] = tt[xi][2] - tt[xi][1];
+    vp[((xi * 4 + 3) * 4) * VK] = tt[xi][1] - tt[xi][3];
+  }
+}
+
+// staged output tile -> HBM, whole channel rows as float4.  All LDS reads are issued before the first store (one LDS
+// round trip per tile, not one per row).
+template <bool POOL>
+__device__ __forceinline__ void store_tile(const ConvArgs& p, const Item& it, const float* Ot, int ptid) {
+  constexpr int PW = POOL ? TC : OW, PH = POOL ? TR : OH;
+  constexpr int N = PH * PW * (NT / 4) / 256;
+  const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
+  const int oy0 = POOL ? it.y0 >> 1 : it.y0, ox0 = POOL ? it.x0 >> 1 : it.x0;
+  f32x4 v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int e = ptid + i * 256;
+    v[i] = *reinterpret_cast<const f32x4*>(Ot + (e / (NT / 4)) * OS + 4 * (e % (NT / 4)));
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int e = ptid + i * 256;
+    const int pix = e / (NT / 4), v4 = e % (NT / 4);
+    const int oy = oy0 + pix / PW, ox = ox0 + pix % PW;
+    if (oy < Ho && ox < Wo)
+      __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4*>(p.out + ((size_t)(it.b * Ho + oy) * Wo + ox) * p.Cout + it.cob * NT + 4 * v4));
+  }
+}
+
+template <bool POOL, bool RELU, bool FIRST>
+__global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* V = smem;                    // [2][VSZ]
+  float* raw = V + 2 * VSZ;           // [2][RAW]
+  float* Ot = raw + 2 * RAW;          // [OTSZ]
+  float* img = Ot + OTSZ;             // FIRST: [2][IMG] + conv1a weights
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: the role branch below is wave-uniform
+  Sched sc;
+  sc.init(p, blockIdx.x, gridDim.x);
+  if (sc.count == 0) return;
+  const int nchunk = p.Cin / CK;
+  const int S = sc.count * nchunk;
+  const int H = p.H, W = p.W, Cin = p.Cin;
+
+  if (wave < 4) {
+    // ======================================================================================== consumers
+    const int cb = wave;
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][j][r] = 0.f;
+#if W6_TRACE
+    unsigned long long tr_work = 0, tr_bar = 0, tr_epi = 0;
+#endif
+    f32x4 bf[8];
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.wu6, 0, (p.Cout / NT) * nchunk * USZ * 4, 0x00020000);
+    const int voff = (cb * 64 + lane) * 16;
+    auto ustep = [&](int k, int c) __attribute__((always_inline)) -> int {      // byte offset of a step's U chunk (scalar)
+      if (c >= nchunk) { c -= nchunk; ++k; }
+      if (k >= sc.count) { k = sc.count - 1; c = nchunk - 1; }
+      return __builtin_amdgcn_readfirstlane((sc.item(k).cob * nchunk + c) * (USZ * 4));
+    };
+    load_b_panel(bf, ur, ustep(0, 0), voff);
+    if constexpr (FIRST) __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    for (int k = 0; k < sc.count; ++k) {
+      const Item it = sc.item(k);
+      for (int c = 0; c < nchunk; c += 2) {
+        W6_T(t0)
+        mfma_chunk<false>(acc, V, bf, ur, ustep(k, c + 1), voff, lane);
+        W6_T(t1)
+        __syncthreads();
+        W6_T(t2)
+        mfma_chunk<false>(acc, V + VSZ, bf, ur, ustep(k, c + 2), voff, lane);
+        W6_T(t3)
+        if (c + 2 == nchunk) output_transform<POOL, RELU>(acc, Ot, p.bias, it.cob * NT, cb, lane);
+        W6_T(t4)
+        __syncthreads();
+#if W6_TRACE
+        const unsigned long long t5 = __builtin_readcyclecounter();
+        tr_work += (t1 - t0) + (t3 - t2); tr_bar += (t2 - t1) + (t5 - t4); tr_epi += t4 - t3;
+#endif
+      }
+    }
+#if W6_TRACE
+    if (tid == 0) { atomicAdd(&w6_trace[0], tr_work); atomicAdd(&w6_trace[1], tr_bar); atomicAdd(&w6_trace[2], tr_epi); atomicAdd(&w6_trace[3], (unsigned long long)S); }
+#endif
+    return;
+  }
+
+  // ========================================================================================== producers
+  const int ptid = tid - 256;
+
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+  if constexpr (!FIRST) {
+    // this thread's two raw-patch items: e < 360: pixel e>>1, channel half e&1.  Threads without a second item repeat
+    // their first one; out-of-image pixels load from a clamped address and are zeroed at the LDS write -- so every
+    // load and store below is unconditional and the compiler can count the fetches in flight.
+    const int e0 = ptid, e1 = ptid + 256 < RH * RW * 2 ? ptid + 256 : ptid;
+    const int rpy0 = (e0 >> 1) / RW, rpx0 = (e0 >> 1) % RW, rh0 = e0 & 1;
+    const int rpy1 = (e1 >> 1) / RW, rpx1 = (e1 >> 1) % RW, rh1 = e1 & 1;
+    const int rdst0 = (rpy0 * RW + rpx0) * RS + 4 * rh0, rdst1 = (rpy1 * RW + rpx1) * RS + 4 * rh1;
+    // fetch cursor: (item, chunk) of the next patch fetch; past the last item it keeps re-reading the last one
+    int fk = 0, fc = 0;
+    const float* src0 = nullptr; const float* src1 = nullptr;
+    float m0 = 0.f, m1 = 0.f;
+    auto raw_sources = [&](const Item& it) __attribute__((always_inline)) {
+      const int gy0 = it.y0 + rpy0 - 1, gx0 = it.x0 + rpx0 - 1, gy1 = it.y0 + rpy1 - 1, gx1 = it.x0 + rpx1 - 1;
+      m0 = (gy0 >= 0 && gy0 < H && gx0 >= 0 && gx0 < W) ? 1.f : 0.f;
+      m1 = (gy1 >= 0 && gy1 < H && gx1 >= 0 && gx1 < W) ? 1.f : 0.f;
+      src0 = p.in + ((size_t)(it.b * H + min(max(gy0, 0), H - 1)) * W + min(max(gx0, 0), W - 1)) * Cin + 4 * rh0;
+      src1 = p.in + ((size_t)(it.b * H + min(max(gy1, 0), H - 1)) * W + min(max(gx1, 0), W - 1)) * Cin + 4 * rh1;
+    };
+    raw_sources(sc.item(0));
+    // A global load takes longer (~1.5 us under load) than one ~2k-cycle phase: FOUR patch fetches are kept in flight,
+    // each issued four phases before the LDS write that consumes it.  Static register sets, loop unrolled by 4.
+    f32x4 ra[4], rb[4];
+    float ma[4], mb[4];
+    auto issue = [&](auto set_c) __attribute__((always_inline)) {
+      constexpr int SET = decltype(set_c)::value;
+      ra[SET] = nt_load4(src0 + fc * CK);     // streaming: keep the activations from evicting U out of L2
+      rb[SET] = nt_load4(src1 + fc * CK);
+      ma[SET] = m0; mb[SET] = m1;
+      if (++fc == nchunk) {
+        fc = 0;
+        if (fk + 1 < sc.count) raw_sources(sc.item(++fk));
+      }
+    };
+    auto put = [&](auto set_c, float* rbuf) __attribute__((always_inline)) {
+      constexpr int SET = decltype(set_c)::value;
+      const float a = ma[SET], b2 = mb[SET];
+      *reinterpret_cast<f32x4*>(rbuf + rdst0) = ra[SET] * a;
+      *reinterpret_cast<f32x4*>(rbuf + rdst1) = rb[SET] * b2;
+    };
+    // ---- prologue: F(0..3), W(0), F(4) | T(0), W(1), F(5)
+    issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
+    put(I0{}, raw);
+    issue(I0{});
+    __syncthreads();
+    input_transform(raw, V, ptid);
+    put(I1{}, raw + RAW);
+    issue(I1{});
+    __syncthreads();
+    // ---- steady state, phase s: W(s+2), F(s+6), T(s+1), and the previous item's tile store.
+    //      Everything past the last step writes buffers nobody reads (branch-free on purpose: the waits stay static).
+    int k = 0, c = 0;
+#if W6_TRACE
+    unsigned long long pt_put = 0, pt_tr = 0, pt_st = 0, pt_bar = 0;
+#endif
+    auto phase = [&](auto j_c) __attribute__((always_inline)) {
+      constexpr int J = decltype(j_c)::value;
+      W6_T(t0)
+      put(std::integral_constant<int, (J + 2) & 3>{}, raw + (J & 1) * RAW);
+      issue(std::integral_constant<int, (J + 2) & 3>{});
+      W6_T(t1)
+      if (EXP_NOT == 0) input_transform(raw + ((J + 1) & 1) * RAW, V + ((J + 1) & 1) * VSZ, ptid);
+      W6_T(t2)
+      if (c == 0 && k > 0) store_tile<POOL>(p, sc.item(k - 1), Ot, ptid);
+      W6_T(t3)
+      __syncthreads();
+#if W6_TRACE
+      { const unsigned long long t4 = __builtin_readcyclecounter(); pt_put += t1 - t0; pt_tr += t2 - t1; pt_st += t3 - t2; pt_bar += t4 - t3; }
+#endif
+      if (++c == nchunk) { c = 0; ++k; }
+    };
+    for (int s = 0; s < S; s += 4) {
+      phase(I0{}); phase(I1{}); phase(I2{}); phase(I3{});
+    }
+#if W6_TRACE
+    if (ptid == 0) { atomicAdd(&w6_trace[4], pt_put); atomicAdd(&w6_trace[5], pt_tr); atomicAdd(&w6_trace[6], pt_st); atomicAdd(&w6_trace[7], pt_bar); }
+#endif
+    store_tile<POOL>(p, sc.item(sc.count - 1), Ot, ptid);
+  } else {
+    // ---- FIRST: the raw patches are computed, not fetched: conv1a (+ folded BN + ReLU) of 8 channels over the 10x18
+    //      halo patch straight into a raw buffer.  thread = (channel tc, run): 30 runs of 6 pixels (10 rows x 3);
+    //      taps are float2 reads of the image patch, weights come from LDS (staged once per workgroup).
+    float* w1s = img + 2 * IMG;          // [9][64] + bias [64]
+    for (int e = ptid; e < 9 * 64; e += 256) w1s[e] = p.w1[e];
+    if (ptid < 64) w1s[9 * 64 + ptid] = p.b1[ptid];
+    auto conv1a = [&](const Item& it, int cch, const float* im, float* rbuf) __attribute__((always_inline)) {
+      const int tc = ptid & 7, run = ptid >> 3;
+      if (run >= 30) return;
+      const int py = run / 3, xr = (run % 3) * 6;
+      float wr[9];
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) wr[tp] = w1s[tp * 64 + cch * CK + tc];
+      const float bias = w1s[9 * 64 + cch * CK + tc];
+      float tap[3][8];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float2 tv = *reinterpret_cast<const float2*>(im + (py + dy) * IMG_W + xr + 2 * j);
+          tap[dy][2 * j] = tv.x;
+          tap[dy][2 * j + 1] = tv.y;
+        }
+      const int gy = it.y0 + py - 1;
+      const float rowmask = (gy >= 0 && gy < H) ? 1.f : 0.f;
+#pragma unroll
+      for (int px = 0; px < 6; ++px) {
+        float v = bias;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) v = fmaf(tap[dy][px + dx], wr[dy * 3 + dx], v);
+        const int gx = it.x0 + xr + px - 1;
+        const float mask = (gx >= 0 && gx < W) ? rowmask : 0.f;
+        rbuf[(py * RW + xr + px) * RS + tc] = fmaxf(v, 0.f) * mask;
+      }
+    };
+    auto img_load = [&](const Item& it) -> float {      // one pixel of the 12x20 image patch per thread (ptid < 240)
+      if (ptid >= IMG) return 0.f;
+      const float* im = (it.b < p.split) ? p.in + (size_t)it.b * H * W : p.in2 + (size_t)(it.b - p.split) * H * W;
+      const int gy = it.y0 + ptid / IMG_W - 2, gx = it.x0 + ptid % IMG_W - 2;
+      return (gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.f;
+    };
+    int ck = 0, cc = 0;                    // compute cursor: (item, chunk) of the next conv1a
+    Item ccit = sc.item(0);
+    auto compute_next = [&](float* rbuf) __attribute__((always_inline)) {
+      if (ck < sc.count) conv1a(ccit, cc, img + (ck & 1) * IMG, rbuf);
+      if (++cc == nchunk) { cc = 0; if (++ck < sc.count) ccit = sc.item(ck); }
+    };
+    // ---- prologue: image patch + weights | C(0) | T(0), C(1)
+    float ipix = img_load(ccit);
+    if (ptid < IMG) img[ptid] = ipix;
+    __syncthreads();
+    compute_next(raw);
+    __syncthreads();
+    input_transform(raw, V, ptid);
+    compute_next(raw + RAW);
+    __syncthreads();
+    // ---- steady state, phase s: T(s+1), C(s+2); the next item's image patch is fetched at chunk 2, stored at chunk 5
+    int k = 0, c = 0;
+    auto phase = [&](auto j_c) __attribute__((always_inline)) {
+      constexpr int J = decltype(j_c)::value;     // = s & 1
+      input_transform(raw + (J ^ 1) * RAW, V + (J ^ 1) * VSZ, ptid);       // T(s+1)
+      compute_next(raw + J * RAW);                                         // C(s+2); a no-op past the last step
+      if (c == 2 && k + 1 < sc.count) ipix = img_load(sc.item(k + 1));
+      if (c == 5 && k + 1 < sc.count && ptid < IMG) img[((k + 1) & 1) * IMG + ptid] = ipix;
+      if (c == 0 && k > 0) store_tile<POOL>(p, sc.item(k - 1), Ot, ptid);
+      __syncthreads();
+      if (++c == nchunk) { c = 0; ++k; }
+    };
+    for (int s = 0; s < S; s += 2) { phase(I0{}); phase(I1{}); }
+    store_tile<POOL>(p, sc.item(sc.count - 1), Ot, ptid);
+  }
+}
+
+template <bool POOL, bool RELU, bool FIRST>
+hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    (void)hipGetDeviceProperties(&prop, dev);
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount / NXCD * NXCD : 256;
+  }
+  const size_t lds = (size_t)(2 * VSZ + 2 * RAW + OTSZ + (FIRST ? 2 * IMG + 10 * 64 : 0)) * sizeof(float);
+  auto k = conv3x3_wino6<POOL, RELU, FIRST>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+#if W6_TRACE
+  unsigned long long z[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(w6_trace), z, sizeof(z));
+#endif
+  hipLaunchKernelGGL(k, dim3((unsigned)ncu), dim3(512), lds, s, a);
+#if W6_TRACE
+  (void)hipStreamSynchronize(s);
+  (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(w6_trace), sizeof(z));
+  const double n = (double)z[3];
+  fprintf(stderr, "[w6 trace] H=%d Cin=%d Cout=%d first=%d | consumer/phase: mfma %.0f barrier %.0f epilogue %.0f | producer/phase: put+issue %.0f transform %.0f store %.0f barrier %.0f\n",
+          a.H, a.Cin, a.Cout, (int)FIRST, z[0] / n, z[1] / n, z[2] / n, z[4] / n, z[5] / n, z[6] / n, z[7] / n);
+#endif
+  return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_conv3x3_wino6(const ConvArgs& a, hipStream_t s) {
+  if (a.Cin % (2 * CK) || a.Cout % NT || (a.first && a.Cin != 64) || !a.wu6) return hipErrorInvalidValue;
+  if (a.first) return a.pool ? launch_t<true, true, true>(a, s) : launch_t<false, true, true>(a, s);
+  if (a.pool) return a.relu ? launch_t<true, true, false>(a, s) : launch_t<true, false, false>(a, s);
+  return a.relu ? launch_t<false, true, false>(a, s) : launch_t<false, false, false>(a, s);
+}
+
+}  // namespace imx

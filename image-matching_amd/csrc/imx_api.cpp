@@ -35,6 +35,7 @@ struct ConvW {
   float* w = nullptr;    // direct form  [9][Cin][Cout]
   float* wu = nullptr;   // Winograd F(2x2,3x3) form (conv3x3_wino.hip layout)
   float* wu4 = nullptr;  // Winograd F(2x2,3x3) form (conv3x3_wino4.hip layout)
+  float* wu6 = nullptr;  // Winograd F(2x2,3x3) form (conv3x3_wino6.hip layout: four positions per lane = one dwordx4)
   float* b = nullptr;
   int cin = 0, cout = 0;
 };
@@ -89,7 +90,8 @@ struct imx_handle_s {
   int det_B = 0, det_H = 0, det_W = 0, det_Hc = 0, det_Wc = 0, det_Ksel = 0;
   // debug / timing
   bool debug = false, timing = false;
-  int conv_mode = 1;      // 3x3 conv kernel: 0 direct (IMX_CONV=direct), 1 Winograd 16x16x4 (wino), 2 Winograd 32x32x2 pipelined (wino4)
+  int conv_mode = 4;      // 3x3 conv kernel: 4 auto (conv1a+1b fused: wino, all other layers: wino6), 0 direct (IMX_CONV=direct),
+                          // 1 Winograd 16x16x4 (wino), 2 Winograd 32x32x2 pipelined (wino4), 3 persistent producer/consumer (wino6)
   std::map<std::string, Tap> taps;
   std::vector<TimedEvent> events;
   std::vector<TimingRow> report;
@@ -289,7 +291,9 @@ std::vector<float> wino_transform(const std::vector<float>& w, int cin, int cout
       float* blk = u.data() + ((size_t)cog * nchunk + chunk) * 8192;
       for (int q = 0; q < 16; ++q) {
         const size_t idx = layout == 0 ? (size_t)((((q * 2 + (k >> 2)) * 4 + (col >> 4)) * 4 + (k & 3)) * 16) + (col & 15)
-                                       : (size_t)(q * 8 + k) * 64 + col;     // conv3x3_wino4.hip: [pos][ci][co]
+                           : layout == 1 ? (size_t)(q * 8 + k) * 64 + col     // conv3x3_wino4.hip: [pos][ci][co]
+                                         // conv3x3_wino6.hip: [k-step][pos>>2][co-block][lane = (ci&3)*16 + co&15][pos&3]
+                                         : (size_t)(((((k >> 2) * 4 + (q >> 2)) * 4 + (col >> 4)) * 64 + (k & 3) * 16 + (col & 15)) * 4) + (q & 3);
         blk[idx] = (float)uu[q / 4][q % 4];
       }
     }
@@ -303,6 +307,7 @@ int make_conv(imx_handle_t h, ConvW& out, const std::map<std::string, HostTensor
   out.w = upload(h, w);
   out.wu = upload(h, wino_transform(w, cin, cout));
   out.wu4 = upload(h, wino_transform(w, cin, cout, 1));
+  out.wu6 = upload(h, wino_transform(w, cin, cout, 2));
   out.b = upload(h, b);
   out.cin = cin;
   out.cout = cout;
@@ -379,6 +384,7 @@ int finalize_superpoint(imx_handle_t h) {
     h->conv[7].w = upload(h, w);
     h->conv[7].wu = upload(h, wino_transform(w, 128, 512));
     h->conv[7].wu4 = upload(h, wino_transform(w, 128, 512, 1));
+    h->conv[7].wu6 = upload(h, wino_transform(w, 128, 512, 2));
     h->conv[7].b = upload(h, b);
     h->conv[7].cin = 128;
     h->conv[7].cout = 512;
@@ -522,9 +528,9 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   auto conv = [&](const char* name, const ConvW& w, const float* in, float* out, int hh, int ww, bool pool, bool first) -> int {
     ConvArgs a{};
     a.in = in; a.in2 = first ? img1 : nullptr; a.split = first ? split : 0;
-    a.w = w.w; a.wu = w.wu; a.wu4 = w.wu4; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
+    a.w = w.w; a.wu = w.wu; a.wu4 = w.wu4; a.wu6 = w.wu6; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
     a.B = B; a.H = hh; a.W = ww; a.Cin = w.cin; a.Cout = w.cout; a.relu = 1; a.pool = pool ? 1 : 0; a.first = first ? 1 : 0;
-    RUN(name, h->conv_mode == 2 ? launch_conv3x3_wino4(a, s) : h->conv_mode == 1 ? launch_conv3x3_wino(a, s) : launch_conv3x3(a, s));
+    RUN(name, (h->conv_mode == 3 || (h->conv_mode == 4 && !a.first)) ? launch_conv3x3_wino6(a, s) : h->conv_mode == 2 ? launch_conv3x3_wino4(a, s) : h->conv_mode == 0 ? launch_conv3x3(a, s) : launch_conv3x3_wino(a, s));
     return 0;
   };
   if (conv("conv1ab_pool", h->conv[0], img0, a1, H, W, true, true)) return -1;
@@ -721,7 +727,7 @@ int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
   imx_handle_s* h = new imx_handle_s();
   h->device = device_id;
   h->cfg = *cfg;
-  if (const char* e = getenv("IMX_CONV")) h->conv_mode = std::string(e) == "direct" ? 0 : std::string(e) == "wino4" ? 2 : 1;
+  if (const char* e = getenv("IMX_CONV")) h->conv_mode = std::string(e) == "direct" ? 0 : std::string(e) == "wino4" ? 2 : std::string(e) == "wino6" ? 3 : std::string(e) == "wino" ? 1 : 4;
   build_expected(h);
   *out = h;
   return 0;

@@ -1,7 +1,6 @@
 #!/bin/bash
-# quick GPU check: SuperGlue/matching parity tests + C3 and C5 bench summaries
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-for w in "--workload c3" "--workload c5 --pairs-per-gpu 8 --steps 5"; do
+# bench summaries only (no tests): tools/gpu_bench_only.sh [c3|c5|both]
+for w in "--workload c3"; do
 python bench.py $w --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import sys,json
 j=json.loads(sys.stdin.read()); k=j['roofline']['kernels']
