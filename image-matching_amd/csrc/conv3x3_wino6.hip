@@ -183,15 +183,18 @@ __device__ __forceinline__ void output_transform(f32x4 (&acc)[16][2], float* Ot,
 // ------------------------------------------------------------------------------------------------ producer side
 __device__ __forceinline__ f32x4 nt_load4(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
 
-// input transform V = B^T d B: thread = (channel tc, wtile tw); raw pixel stride 12 keeps the reads conflict free
-__device__ __forceinline__ void input_transform(const float* raw, float* V, int ptid) {
+// input transform V = B^T d B: thread = (channel tc, wtile tw); raw pixel stride 12 keeps the reads conflict free.
+// Split into its LDS-read half and its compute + LDS-write half so other work can sit in the read latency.
+__device__ __forceinline__ void input_transform_load(const float* raw, int ptid, float (&d)[16]) {
   const int tc = ptid & 7, tw = ptid >> 3, twr = tw >> 3, twc = tw & 7;
   const float* rp = raw + ((2 * twr) * RW + 2 * twc) * RS + tc;
-  float d[16];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) d[a * 4 + bb] = rp[(a * RW + bb) * RS];
+}
+__device__ __forceinline__ void input_transform_finish(const float (&d)[16], float* V, int ptid) {
+  const int tc = ptid & 7, tw = ptid >> 3;
   float tt[4][4];
 #pragma unroll
   for (int bb = 0; bb < 4; ++bb) {
@@ -208,6 +211,11 @@ __device__ __forceinline__ void input_transform(const float* raw, float* V, int 
     vp[((xi * 4 + 2) * 4) * VK] = tt[xi][2] - tt[xi][1];
     vp[((xi * 4 + 3) * 4) * VK] = tt[xi][1] - tt[xi][3];
   }
+}
+__device__ __forceinline__ void input_transform(const float* raw, float* V, int ptid) {
+  float d[16];
+  input_transform_load(raw, ptid, d);
+  input_transform_finish(d, V, ptid);
 }
 
 // staged output tile -> HBM, whole channel rows as float4.  All LDS reads are issued before the first store (one LDS
@@ -392,35 +400,35 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
     float* w1s = img + 2 * IMG;          // [9][64] + bias [64]
     for (int e = ptid; e < 9 * 64; e += 256) w1s[e] = p.w1[e];
     if (ptid < 64) w1s[9 * 64 + ptid] = p.b1[ptid];
-    auto conv1a = [&](const Item& it, int cch, const float* im, float* rbuf) __attribute__((always_inline)) {
-      const int tc = ptid & 7, run = ptid >> 3;
-      if (run >= 30) return;
-      const int py = run / 3, xr = (run % 3) * 6;
-      float wr[9];
+    // branch-free: threads 240..255 repeat run 29 (same values to the same addresses)
+    const int c1_tc = ptid & 7, c1_run = min(ptid >> 3, 29), c1_py = c1_run / 3, c1_xr = (c1_run % 3) * 6;
+    struct C1 { float wr[9], bias, tap[3][8]; };
+    auto conv1a_load = [&](int cch, const float* im, C1& r) __attribute__((always_inline)) {
 #pragma unroll
-      for (int tp = 0; tp < 9; ++tp) wr[tp] = w1s[tp * 64 + cch * CK + tc];
-      const float bias = w1s[9 * 64 + cch * CK + tc];
-      float tap[3][8];
+      for (int tp = 0; tp < 9; ++tp) r.wr[tp] = w1s[tp * 64 + cch * CK + c1_tc];
+      r.bias = w1s[9 * 64 + cch * CK + c1_tc];
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float2 tv = *reinterpret_cast<const float2*>(im + (py + dy) * IMG_W + xr + 2 * j);
-          tap[dy][2 * j] = tv.x;
-          tap[dy][2 * j + 1] = tv.y;
+          const float2 tv = *reinterpret_cast<const float2*>(im + (c1_py + dy) * IMG_W + c1_xr + 2 * j);
+          r.tap[dy][2 * j] = tv.x;
+          r.tap[dy][2 * j + 1] = tv.y;
         }
-      const int gy = it.y0 + py - 1;
+    };
+    auto conv1a_finish = [&](const Item& it, const C1& r, float* rbuf) __attribute__((always_inline)) {
+      const int gy = it.y0 + c1_py - 1;
       const float rowmask = (gy >= 0 && gy < H) ? 1.f : 0.f;
 #pragma unroll
       for (int px = 0; px < 6; ++px) {
-        float v = bias;
+        float v = r.bias;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx) v = fmaf(tap[dy][px + dx], wr[dy * 3 + dx], v);
-        const int gx = it.x0 + xr + px - 1;
+          for (int dx = 0; dx < 3; ++dx) v = fmaf(r.tap[dy][px + dx], r.wr[dy * 3 + dx], v);
+        const int gx = it.x0 + c1_xr + px - 1;
         const float mask = (gx >= 0 && gx < W) ? rowmask : 0.f;
-        rbuf[(py * RW + xr + px) * RS + tc] = fmaxf(v, 0.f) * mask;
+        rbuf[(c1_py * RW + c1_xr + px) * RS + c1_tc] = fmaxf(v, 0.f) * mask;
       }
     };
     auto img_load = [&](const Item& it) -> float {      // one pixel of the 12x20 image patch per thread (ptid < 240)
@@ -429,11 +437,16 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
       const int gy = it.y0 + ptid / IMG_W - 2, gx = it.x0 + ptid % IMG_W - 2;
       return (gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.f;
     };
-    int ck = 0, cc = 0;                    // compute cursor: (item, chunk) of the next conv1a
-    Item ccit = sc.item(0);
+    int ck = 0, cc = 0;                    // compute cursor: (item, chunk) of the next conv1a; past the end it repeats the last
+    Item ccit = sc.item(0);                // item's chunks into buffers nobody reads (branch-free)
+    auto advance = [&]() __attribute__((always_inline)) {
+      if (++cc == nchunk) { cc = 0; if (ck + 1 < sc.count) ccit = sc.item(++ck); }
+    };
     auto compute_next = [&](float* rbuf) __attribute__((always_inline)) {
-      if (ck < sc.count) conv1a(ccit, cc, img + (ck & 1) * IMG, rbuf);
-      if (++cc == nchunk) { cc = 0; if (++ck < sc.count) ccit = sc.item(ck); }
+      C1 r;
+      conv1a_load(cc, img + (ck & 1) * IMG, r);
+      conv1a_finish(ccit, r, rbuf);
+      advance();
     };
     // ---- prologue: image patch + weights | C(0) | T(0), C(1)
     float ipix = img_load(ccit);
@@ -448,8 +461,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
     int k = 0, c = 0;
     auto phase = [&](auto j_c) __attribute__((always_inline)) {
       constexpr int J = decltype(j_c)::value;     // = s & 1
-      input_transform(raw + (J ^ 1) * RAW, V + (J ^ 1) * VSZ, ptid);       // T(s+1)
-      compute_next(raw + J * RAW);                                         // C(s+2); a no-op past the last step
+      // T(s+1) and C(s+2) interleaved: both LDS read batches first, then the two compute + write halves
+      float d[16];
+      C1 r;
+      input_transform_load(raw + (J ^ 1) * RAW, ptid, d);
+      conv1a_load(cc, img + (ck & 1) * IMG, r);
+      input_transform_finish(d, V + (J ^ 1) * VSZ, ptid);
+      conv1a_finish(ccit, r, raw + J * RAW);
+      advance();
       if (c == 2 && k + 1 < sc.count) ipix = img_load(sc.item(k + 1));
       if (c == 5 && k + 1 < sc.count && ptid < IMG) img[((k + 1) & 1) * IMG + ptid] = ipix;
       if (c == 0 && k > 0) store_tile<POOL>(p, sc.item(k - 1), Ot, ptid);
