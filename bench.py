@@ -148,11 +148,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # Bring-up hook for 1-GPU boxes: IMX_BENCH_BACKEND=gloo runs every rank on cuda:0 with a host-side gather, to exercise
+    # the multi-rank control flow (barriers, max-over-ranks, who prints) where RCCL cannot run.  Never set by the driver.
+    backend = os.environ.get("IMX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]
     H, W, d, K = wl["H"], wl["W"], wl["d"], wl["K"]
@@ -190,7 +198,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, out, rec
@@ -227,18 +235,25 @@ def main():
     }
 
     # ---- roofline: second pass of the same K steps with per-launch HIP events on the launch stream
-    if rank == 0 and not args.no_roofline_pass:
+    # (every rank runs the steps -- step() contains the all-gather, a rank-0-only pass would hang the others;
+    #  only rank 0 records events and reports)
+    rows = None
+    if not args.no_roofline_pass:
         eng = matching._shared.engine
-        kenc, iters, _ = synth.SG_CONFIGS[d]
-        work = algorithmic_work(B, H, W, d, K, kenc, iters)
-        log("roofline pass (per-launch HIP events)")
-        eng.timing_reset()
-        eng.set_timing(True)
+        if rank == 0:
+            log("roofline pass (per-launch HIP events)")
+            eng.timing_reset()
+            eng.set_timing(True)
         for _ in range(args.steps):
             step()
-        rows = eng.timing_report()
-        eng.set_timing(False)
-        eng.timing_reset()
+        torch.cuda.synchronize()
+        if rank == 0:
+            rows = eng.timing_report()
+            eng.set_timing(False)
+            eng.timing_reset()
+    if rows:
+        kenc, iters, _ = synth.SG_CONFIGS[d]
+        work = algorithmic_work(B, H, W, d, K, kenc, iters)
         tot_ms = sum(r[2] for r in rows)
         name, launches, ms = max(rows, key=lambda r: r[2])
         bound, units = work[name]

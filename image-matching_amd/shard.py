@@ -53,6 +53,8 @@ def gather_records(rec, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return rec
     world = dist.get_world_size(group)
+    if dist.get_backend(group) != "nccl" and rec.is_cuda:      # host-side gather (gloo bring-up); RCCL gathers in HBM
+        return gather_records(rec.cpu(), group).to(rec.device)
     out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
     dist.all_gather_into_tensor(out, rec.contiguous(), group=group)
     return out
