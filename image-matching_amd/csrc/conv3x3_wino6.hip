@@ -16,8 +16,9 @@
 //     a 5.1-6.0k-cycle chunk period plus a 13-17 % prologue/epilogue share).
 //
 // Tile = 4x8 Winograd tiles (8x16 output pixels) x 64 output channels; consumer wave cb owns channels cb*16..+16 for
-// all 32 wtiles: acc[16 positions][2 row blocks] (128 accumulator registers).  LDS: V[2] 36 KB, raw[2] 17 KB,
-// output staging 34 KB (+ 2 image patches in FIRST mode) = 89 KB.  XCD-aware: the work list is cut into 8
+// all 32 wtiles: acc[16 positions][2 row blocks] (128 accumulator registers).  LDS: V ring of 3 x 18 KB (the next
+// chunk's V is complete one phase early, so its first A operands are prefetched across the barrier), raw[2] 17 KB,
+// output staging 34 KB (+ 2 image patches, conv1a weights in FIRST mode) = 107 KB.  XCD-aware: the work list is cut into 8
 // contiguous ranges (workgroup g runs on XCD g % 8), so the 32 workgroups of an XCD walk neighbouring tiles and share
 // halos / weights in that XCD's L2.
 #include "imx_kernels.h"
@@ -101,16 +102,13 @@ __device__ __forceinline__ void load_b_panel(f32x4 (&bf)[8], __amdgpu_buffer_rsr
 // 4(g&3)..+3); A operands from LDS one group ahead; bf[g] = group g's four B registers, refilled in place with the next
 // chunk's right behind the MFMAs that read them (the refill sits in the NEXT scheduling region so it cannot be hoisted
 // above those MFMAs; a second panel does not fit next to 128 accumulators).
-template <bool ZERO>      // ZERO: first chunk of a tile, the accumulators start from 0 (no clearing pass after the epilogue)
-__device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[16][2], const float* Vb, f32x4 (&bf)[8], __amdgpu_buffer_rsrc_t ur, int uoff,
-                                           int voff, int lane) {
-  const float* va = Vb + (lane >> 5) * VK + (lane & 15) * 2 + ((lane >> 4) & 1);
-  float af[2][4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    af[0][i][0] = va[(i * 4) * VK];
-    af[0][i][1] = va[(i * 4) * VK + 32];
-  }
+// af[0] holds this chunk's group-0 A operands on entry (prefetched during the previous chunk, across the barrier: V is a
+// ring of three buffers, so the next chunk's V is complete one phase early) and the next chunk's on exit.
+__device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[16][2], const float* Vb, const float* Vnext, float (&af)[2][4][2], f32x4 (&bf)[8],
+                                           __amdgpu_buffer_rsrc_t ur, int uoff, int voff, int lane) {
+  const int vlane = (lane >> 5) * VK + (lane & 15) * 2 + ((lane >> 4) & 1);
+  const float* va = Vb + vlane;
+  const float* vn = Vnext + vlane;
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     const int cur = g & 1, nxt = cur ^ 1;
@@ -121,14 +119,18 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[16][2], const float* Vb,
         af[nxt][i][0] = va[((qb + i) * 4 + 2 * s1) * VK];
         af[nxt][i][1] = va[((qb + i) * 4 + 2 * s1) * VK + 32];
       }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[nxt][i][0] = vn[(i * 4) * VK];
+        af[nxt][i][1] = vn[(i * 4) * VK + 32];
+      }
     }
     const int q0 = (g & 3) * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-      const bool fresh = ZERO && g < 4;       // k-step 0 touches every accumulator once
-      acc[q0 + i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][0], bf[g][i], fresh ? zero : acc[q0 + i][0], 0, 0, 0);
-      acc[q0 + i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][1], bf[g][i], fresh ? zero : acc[q0 + i][1], 0, 0, 0);
+      acc[q0 + i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][0], bf[g][i], acc[q0 + i][0], 0, 0, 0);
+      acc[q0 + i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][1], bf[g][i], acc[q0 + i][1], 0, 0, 0);
     }
     if (g > 0) bf[g - 1] = u_load(ur, voff, uoff + (g - 1) * 4096);
 #pragma unroll
@@ -245,8 +247,8 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, const Item& it, co
 template <bool POOL, bool RELU, bool FIRST>
 __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* V = smem;                    // [2][VSZ]
-  float* raw = V + 2 * VSZ;           // [2][RAW]
+  float* V = smem;                    // [3][VSZ] ring
+  float* raw = V + 3 * VSZ;           // [2][RAW]
   float* Ot = raw + 2 * RAW;          // [OTSZ]
   float* img = Ot + OTSZ;             // FIRST: [2][IMG] + conv1a weights
 
@@ -281,26 +283,35 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
       return __builtin_amdgcn_readfirstlane((sc.item(k).cob * nchunk + c) * (USZ * 4));
     };
     load_b_panel(bf, ur, ustep(0, 0), voff);
-    if constexpr (FIRST) __syncthreads();
+    if constexpr (FIRST) __syncthreads();     // producers' prologue: 3 phases (+1 in FIRST mode)
     __syncthreads();
     __syncthreads();
+    __syncthreads();
+    float af[2][4][2];
+    {
+      const float* va = V + (lane >> 5) * VK + (lane & 15) * 2 + ((lane >> 4) & 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[0][i][0] = va[(i * 4) * VK];
+        af[0][i][1] = va[(i * 4) * VK + 32];
+      }
+    }
+    int vi = 0;                                   // ring position of the chunk being multiplied
     for (int k = 0; k < sc.count; ++k) {
       const Item it = sc.item(k);
-      for (int c = 0; c < nchunk; c += 2) {
+      for (int c = 0; c < nchunk; ++c) {
+        const int vnx = vi == 2 ? 0 : vi + 1;
         W6_T(t0)
-        mfma_chunk<false>(acc, V, bf, ur, ustep(k, c + 1), voff, lane);
+        mfma_chunk(acc, V + vi * VSZ, V + vnx * VSZ, af, bf, ur, ustep(k, c + 1), voff, lane);
         W6_T(t1)
-        __syncthreads();
+        if (c + 1 == nchunk) output_transform<POOL, RELU>(acc, Ot, p.bias, it.cob * NT, cb, lane);
         W6_T(t2)
-        mfma_chunk<false>(acc, V + VSZ, bf, ur, ustep(k, c + 2), voff, lane);
-        W6_T(t3)
-        if (c + 2 == nchunk) output_transform<POOL, RELU>(acc, Ot, p.bias, it.cob * NT, cb, lane);
-        W6_T(t4)
         __syncthreads();
 #if W6_TRACE
-        const unsigned long long t5 = __builtin_readcyclecounter();
-        tr_work += (t1 - t0) + (t3 - t2); tr_bar += (t2 - t1) + (t5 - t4); tr_epi += t4 - t3;
+        const unsigned long long t3 = __builtin_readcyclecounter();
+        tr_work += t1 - t0; tr_epi += t2 - t1; tr_bar += t3 - t2;
 #endif
+        vi = vnx;
       }
     }
 #if W6_TRACE
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
       *reinterpret_cast<f32x4*>(rbuf + rdst0) = ra[SET] * a;
       *reinterpret_cast<f32x4*>(rbuf + rdst1) = rb[SET] * b2;
     };
-    // ---- prologue: F(0..3), W(0), F(4) | T(0), W(1), F(5)
+    // ---- prologue: F(0..3), W(0), F(4) | T(0), W(1), F(5) | T(1), W(2), F(6)
     issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
     put(I0{}, raw);
     issue(I0{});
@@ -364,19 +375,24 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
     put(I1{}, raw + RAW);
     issue(I1{});
     __syncthreads();
-    // ---- steady state, phase s: W(s+2), F(s+6), T(s+1), and the previous item's tile store.
+    input_transform(raw + RAW, V + VSZ, ptid);
+    put(I2{}, raw);
+    issue(I2{});
+    __syncthreads();
+    // ---- steady state, phase s: W(s+3), F(s+7), T(s+2) into ring slot (s+2)%3, and the previous item's tile store.
     //      Everything past the last step writes buffers nobody reads (branch-free on purpose: the waits stay static).
-    int k = 0, c = 0;
+    int k = 0, c = 0, vt = 2;             // vt = (s+2) % 3
 #if W6_TRACE
     unsigned long long pt_put = 0, pt_tr = 0, pt_st = 0, pt_bar = 0;
 #endif
     auto phase = [&](auto j_c) __attribute__((always_inline)) {
       constexpr int J = decltype(j_c)::value;
       W6_T(t0)
-      put(std::integral_constant<int, (J + 2) & 3>{}, raw + (J & 1) * RAW);
-      issue(std::integral_constant<int, (J + 2) & 3>{});
+      put(std::integral_constant<int, (J + 3) & 3>{}, raw + ((J + 1) & 1) * RAW);
+      issue(std::integral_constant<int, (J + 3) & 3>{});
       W6_T(t1)
-      if (EXP_NOT == 0) input_transform(raw + ((J + 1) & 1) * RAW, V + ((J + 1) & 1) * VSZ, ptid);
+      if (EXP_NOT == 0) input_transform(raw + (J & 1) * RAW, V + vt * VSZ, ptid);
+      vt = vt == 2 ? 0 : vt + 1;
       W6_T(t2)
       if (c == 0 && k > 0) store_tile<POOL>(p, sc.item(k - 1), Ot, ptid);
       W6_T(t3)
@@ -448,7 +464,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
       conv1a_finish(ccit, r, rbuf);
       advance();
     };
-    // ---- prologue: image patch + weights | C(0) | T(0), C(1)
+    // ---- prologue: image patch + weights | C(0) | T(0), C(1) | T(1), C(2)
     float ipix = img_load(ccit);
     if (ptid < IMG) img[ptid] = ipix;
     __syncthreads();
@@ -457,20 +473,25 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
     input_transform(raw, V, ptid);
     compute_next(raw + RAW);
     __syncthreads();
-    // ---- steady state, phase s: T(s+1), C(s+2); the next item's image patch is fetched at chunk 2, stored at chunk 5
-    int k = 0, c = 0;
+    input_transform(raw + RAW, V + VSZ, ptid);
+    compute_next(raw);
+    __syncthreads();
+    // ---- steady state, phase s: T(s+2) into ring slot (s+2)%3, C(s+3); the next item's image patch is fetched at
+    //      chunk 2 and stored at chunk 4 (its first conv1a runs at chunk nchunk-3)
+    int k = 0, c = 0, vt = 2;
     auto phase = [&](auto j_c) __attribute__((always_inline)) {
       constexpr int J = decltype(j_c)::value;     // = s & 1
-      // T(s+1) and C(s+2) interleaved: both LDS read batches first, then the two compute + write halves
+      // T(s+2) and C(s+3) interleaved: both LDS read batches first, then the two compute + write halves
       float d[16];
       C1 r;
-      input_transform_load(raw + (J ^ 1) * RAW, ptid, d);
+      input_transform_load(raw + J * RAW, ptid, d);
       conv1a_load(cc, img + (ck & 1) * IMG, r);
-      input_transform_finish(d, V + (J ^ 1) * VSZ, ptid);
-      conv1a_finish(ccit, r, raw + J * RAW);
+      input_transform_finish(d, V + vt * VSZ, ptid);
+      conv1a_finish(ccit, r, raw + (J ^ 1) * RAW);
       advance();
+      vt = vt == 2 ? 0 : vt + 1;
       if (c == 2 && k + 1 < sc.count) ipix = img_load(sc.item(k + 1));
-      if (c == 5 && k + 1 < sc.count && ptid < IMG) img[((k + 1) & 1) * IMG + ptid] = ipix;
+      if (c == 4 && k + 1 < sc.count && ptid < IMG) img[((k + 1) & 1) * IMG + ptid] = ipix;
       if (c == 0 && k > 0) store_tile<POOL>(p, sc.item(k - 1), Ot, ptid);
       __syncthreads();
       if (++c == nchunk) { c = 0; ++k; }
@@ -490,7 +511,7 @@ hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
     (void)hipGetDeviceProperties(&prop, dev);
     ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount / NXCD * NXCD : 256;
   }
-  const size_t lds = (size_t)(2 * VSZ + 2 * RAW + OTSZ + (FIRST ? 2 * IMG + 10 * 64 : 0)) * sizeof(float);
+  const size_t lds = (size_t)(3 * VSZ + 2 * RAW + OTSZ + (FIRST ? 2 * IMG + 10 * 64 : 0)) * sizeof(float);
   auto k = conv3x3_wino6<POOL, RELU, FIRST>;
   static bool attr = false;
   if (!attr) {
