@@ -158,26 +158,29 @@ __global__ __launch_bounds__(1024) void sinkhorn_slab(SinkhornArgs a, float* __r
   for (int j = tid; j <= n; j += 1024) vs[j] = v[j];
   __syncthreads();
   const float norm = -logf((float)(m + n));
-  for (int r = wave; r < R; r += 16) {          // 16 waves: one row each when R = 16
-    const int i = i0 + r;
-    if (i > m) break;
+  // Row pass: all 16 waves work whatever R is -- a row is split over W = 16/R waves (segments of N1p/W <= 1024
+  // columns, one batch of four float4 loads per lane); their partial (max, sum) pairs are merged through LDS.
+  constexpr int W = 16 / R;
+  __shared__ float pm[16], ps[16];
+  {
+    const int r = wave / W, seg = wave % W, i = i0 + r;
+    const int seglen = a.N1p / W, jlo = seg * seglen, jhi = jlo + seglen;     // N1p % 32 == 0: float4-aligned segments
     LSE acc{-INFINITY, 0.f};
     if (i < m) {
-      // a row is N1p (multiple of 32) floats, 16-byte aligned: four float4 loads per lane are issued before any of
-      // them is consumed, so the wave keeps 4 KB in flight (a scalar loop serialised one 256 B load per latency)
+      // four float4 loads per lane are issued before any of them is consumed, so the wave keeps 4 KB in flight
       const float* Srow = a.S + ((size_t)b * a.N0p + i) * a.N1p;
       float* trow = tile + r * a.N1p;
-      for (int j0 = 0; j0 < n; j0 += 1024) {
+      for (int j0 = jlo; j0 < jhi && j0 < n; j0 += 1024) {
         float4 x[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int j = j0 + k * 256 + lane * 4;
-          x[k] = j < a.N1p ? *reinterpret_cast<const float4*>(Srow + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+          x[k] = j < jhi ? *reinterpret_cast<const float4*>(Srow + j) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int j = j0 + k * 256 + lane * 4;
-          if (j < a.N1p) {
+          if (j < jhi) {
             *reinterpret_cast<float4*>(trow + j) = x[k];
             const float4 vv = *reinterpret_cast<const float4*>(vs + j);
             if (j + 0 < n) lse_add(acc, x[k].x + vv.x);
@@ -187,17 +190,23 @@ __global__ __launch_bounds__(1024) void sinkhorn_slab(SinkhornArgs a, float* __r
           }
         }
       }
-    } else {
-      for (int j = lane; j < n; j += 64) lse_add(acc, a.alpha + vs[j]);
+    } else if (i == m) {
+      for (int j = jlo + lane; j < jhi && j < n; j += 64) lse_add(acc, a.alpha + vs[j]);
     }
-    if (lane == 0) lse_add(acc, a.alpha + vs[n]);
+    if (i <= m && seg == W - 1 && lane == 0) lse_add(acc, a.alpha + vs[n]);      // the dustbin column, once per row
     acc = wave_lse(acc);
-    if (lane == 0) {
-      const float log_mu = i < m ? norm : logf((float)n) + norm;
-      const float ui = log_mu - lse_value(acc);
-      uu[r] = ui;
-      a.u[(size_t)b * (a.N0p + 1) + i] = ui;
-    }
+    if (lane == 0) { pm[wave] = acc.m; ps[wave] = acc.s; }
+  }
+  __syncthreads();
+  if (tid < R && i0 + tid <= m) {
+    LSE t{pm[tid * W], ps[tid * W]};
+#pragma unroll
+    for (int k = 1; k < W; ++k) t = lse_merge(t, LSE{pm[tid * W + k], ps[tid * W + k]});
+    const int i = i0 + tid;
+    const float log_mu = i < m ? norm : logf((float)n) + norm;
+    const float ui = log_mu - lse_value(t);
+    uu[tid] = ui;
+    a.u[(size_t)b * (a.N0p + 1) + i] = ui;
   }
   __syncthreads();
   const int rows = min(R, m + 1 - i0);      // rows of this slab, the last may be the dustbin row
