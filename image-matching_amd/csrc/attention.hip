@@ -408,7 +408,8 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   // A/B switch IMX_ATTN: 1 = one K/V tile in flight, 2 = software-pipelined softmax (attention2_kernel), 3 = two tiles in
   // flight.  Measured (MI355X, C3 HD=32 / C5 HD=64, ms per step): 1: 10.97 / 11.2, 2: 11.5 / 11.1, 3: 11.1 / 10.65 --
   // VALU work placed between MFMAs is not free (in-order issue), so the pipelined form loses; default = best per HD.
-  static const int forced = getenv("IMX_ATTN") ? atoi(getenv("IMX_ATTN")) : 0;
+  const char* env = getenv("IMX_ATTN");        // read per launch (tests switch it within one process)
+  const int forced = env ? atoi(env) : 0;
   const int mode = forced ? forced : (hd == 32 ? 1 : 3);
   if (hd == 32) {
     if (mode == 1) hipLaunchKernelGGL((attention_kernel<32, false>), grid, dim3(256), 0, s, a, scale);

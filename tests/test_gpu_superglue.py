@@ -144,3 +144,13 @@ def test_batched_pairs_equal_single_pair_runs():
     for i in range(4):
         assert np.array_equal(mb[i][0], ma[i][0]) and np.array_equal(mb[i][1], mbb[i][0]), \
             "batched pairs must be bit-identical to single-pair runs"
+
+
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
+def test_every_attention_variant_matches_bit_exact(mode, monkeypatch):
+    """IMX_ATTN selects the attention kernel (1: one K/V tile in flight, 2: software-pipelined softmax, 3: two tiles in
+    flight; the default picks per head size).  Every variant must give the reference's matches on a C3 and the C5
+    fixture (head sizes 32 and 64)."""
+    monkeypatch.setenv("IMX_ATTN", mode)
+    for name in ("c3_pair_s59.npz", "c5_pair_s19.npz"):
+        test_full_size_matches_bit_exact_vs_reference_golden(name)

@@ -171,3 +171,22 @@ def test_dense_forward_for_label_export_vs_reference_golden():
     assert out["semi"].shape == g["semi"].shape and out["desc"].shape == g["desc"].shape
     util.assert_close(out["semi"], g["semi"], "semi")
     util.assert_close(out["desc"], g["desc"], "desc")
+
+
+@pytest.mark.parametrize("mode", ["direct", "wino", "wino4", "wino6"])
+def test_every_conv_kernel_variant_vs_reference_golden(mode, monkeypatch):
+    """The 3x3-conv layers have four implementations (IMX_CONV, read at imx_create): direct implicit GEMM, Winograd with
+    two workgroups per CU, the 32x32x2 variant and the persistent producer/consumer form; the default mixes two of them.
+    Each one alone must reproduce the reference's dense stages and keypoints on the ragged fixture (123x165: partial
+    tiles on both axes) and on the 120x160 one."""
+    monkeypatch.setenv("IMX_CONV", mode)
+    for name in ("sp_ragged.npz", "sp_small.npz"):
+        g = util.golden(name)
+        H, W, seed, K = int(g["H"]), int(g["W"]), int(g["seed"]), int(g["max_keypoints"])
+        eng, L = _engine(128, K)
+        eng.load_state_dict(L.NET_SUPERPOINT, util.sp_sd(128))
+        x = torch.cat(util.pair(seed, H, W))
+        _check_against(eng, x, [g["keypoints0"], g["keypoints1"]], [g["scores0"], g["scores1"]],
+                       [g["descriptors0"], g["descriptors1"]])
+        util.assert_close(_nchw(eng.fetch("x4")), g["x4"], f"x4 ({mode})")
+        util.assert_close(_nchw(eng.fetch("semi")), g["semi"], f"semi ({mode})")
