@@ -273,6 +273,12 @@ def main():
         line["roofline"] = {"bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
                             "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": name,
                             "avg_launch_ms": round(ms / launches, 4), "share_of_gpu_time": round(ms / tot_ms, 4)}
+        if bound == "mfma" and name.startswith("conv") and name not in ("convPb", "convDb") \
+                and os.environ.get("IMX_CONV", "auto") != "direct":
+            # the 3x3 layers run as Winograd F(2x2,3x3): the matrix cores execute 2.25x fewer multiplies than the
+            # algorithmic (direct-form) count `achieved` is defined on -- report the executed rate next to it
+            line["roofline"]["executed"] = {"tflops": round(achieved / 2.25, 3), "frac": round(achieved / 2.25 / peak, 4),
+                                            "note": "Winograd F(2x2,3x3): 36 multiplies per 16 outputs instead of 144"}
         # whole-pair view: algorithmic dense FLOPs of the step / measured step time vs the fp32 MFMA peak
         per_step = {r[0]: r[1] / args.steps for r in rows}          # launches per step
         flops_step = sum(u * per_step.get(k, 0.0) for k, (bd, u) in work.items() if bd == "mfma")
