@@ -49,7 +49,10 @@ constexpr int TR = 4, TC = 8, OH = 2 * TR, OW = 2 * TC;
 constexpr int RH = OH + 2, RW = OW + 2, RS = 12;
 constexpr int CK = 8, NT = 64;
 constexpr int RAW = RH * RW * RS;        // 2160
-constexpr int VK = 72, VSZ = 16 * 4 * VK; // 4608
+constexpr int VK = 72;                    // V channel-pair stride (64 + 8 pad: conflict-free transform writes)
+constexpr int QS = 320;                   // V position stride: 5 x 64 dwords, so the consumers' reads of different positions from one
+                                          // base address fuse into ds_read2st64_b32 -- no per-read address VALU in the MFMA stream
+constexpr int VSZ = 16 * QS;              // 5120
 constexpr int USZ = 16 * 2 * 4 * 4 * 16;  // 8192
 constexpr int IMG_H = RH + 2, IMG_W = RW + 2, IMG = IMG_H * IMG_W;   // 12 x 20
 constexpr int OS = NT + 4;
@@ -106,25 +109,34 @@ __device__ __forceinline__ void load_b_panel(f32x4 (&bf)[8], __amdgpu_buffer_rsr
 // ring of three buffers, so the next chunk's V is complete one phase early) and the next chunk's on exit.
 __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[16][2], const float* Vb, const float* Vnext, float (&af)[2][4][2], f32x4 (&bf)[8],
                                            __amdgpu_buffer_rsrc_t ur, int uoff, int voff, int lane) {
+  // Four element offsets per chunk (k-step 0/1 x row block 0/1), made opaque to the optimiser so that it does not fold them
+  // back into one base + large immediates (which costs a v_add per read): from each base, positions q and q' are
+  // q*QS = q*5*64 dwords apart and fuse into ds_read2st64_b32 with no address arithmetic in the MFMA stream.
   const int vlane = (lane >> 5) * VK + (lane & 15) * 2 + ((lane >> 4) & 1);
-  const float* va = Vb + vlane;
-  const float* vn = Vnext + vlane;
+  int o00 = vlane, o01 = vlane + 32, o10 = vlane + 2 * VK, o11 = vlane + 2 * VK + 32;
+  asm volatile("" : "+v"(o00), "+v"(o01), "+v"(o10), "+v"(o11));      // (the pointers stay LDS pointers)
+  const float* b00 = Vb + o00;
+  const float* b01 = Vb + o01;
+  const float* b10 = Vb + o10;
+  const float* b11 = Vb + o11;
+  const float* n00 = Vnext + o00;
+  const float* n01 = Vnext + o01;
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     const int cur = g & 1, nxt = cur ^ 1;
     if (g + 1 < 8) {
       const int s1 = (g + 1) >> 2, qb = ((g + 1) & 3) * 4;
+      const float* r0 = s1 ? b10 : b00;
+      const float* r1 = s1 ? b11 : b01;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[nxt][i][0] = va[((qb + i) * 4 + 2 * s1) * VK];
-        af[nxt][i][1] = va[((qb + i) * 4 + 2 * s1) * VK + 32];
-      }
+      for (int i = 0; i < 4; ++i) af[nxt][i][0] = r0[(qb + i) * QS];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[nxt][i][1] = r1[(qb + i) * QS];
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[nxt][i][0] = vn[(i * 4) * VK];
-        af[nxt][i][1] = vn[(i * 4) * VK + 32];
-      }
+      for (int i = 0; i < 4; ++i) af[nxt][i][0] = n00[i * QS];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[nxt][i][1] = n01[i * QS];
     }
     const int q0 = (g & 3) * 4;
 #pragma unroll
@@ -208,10 +220,10 @@ __device__ __forceinline__ void input_transform_finish(const float (&d)[16], flo
   float* vp = V + (tc >> 1) * VK + tw * 2 + (tc & 1);
 #pragma unroll
   for (int xi = 0; xi < 4; ++xi) {
-    vp[((xi * 4 + 0) * 4) * VK] = tt[xi][0] - tt[xi][2];
-    vp[((xi * 4 + 1) * 4) * VK] = tt[xi][1] + tt[xi][2];
-    vp[((xi * 4 + 2) * 4) * VK] = tt[xi][2] - tt[xi][1];
-    vp[((xi * 4 + 3) * 4) * VK] = tt[xi][1] - tt[xi][3];
+    vp[(xi * 4 + 0) * QS] = tt[xi][0] - tt[xi][2];
+    vp[(xi * 4 + 1) * QS] = tt[xi][1] + tt[xi][2];
+    vp[(xi * 4 + 2) * QS] = tt[xi][2] - tt[xi][1];
+    vp[(xi * 4 + 3) * QS] = tt[xi][1] - tt[xi][3];
   }
 }
 __device__ __forceinline__ void input_transform(const float* raw, float* V, int ptid) {
@@ -292,8 +304,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
       const float* va = V + (lane >> 5) * VK + (lane & 15) * 2 + ((lane >> 4) & 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        af[0][i][0] = va[(i * 4) * VK];
-        af[0][i][1] = va[(i * 4) * VK + 32];
+        af[0][i][0] = va[i * QS];
+        af[0][i][1] = va[i * QS + 32];
       }
     }
     int vi = 0;                                   // ring position of the chunk being multiplied
@@ -322,6 +334,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
 
   // ========================================================================================== producers
   const int ptid = tid - 256;
+  __builtin_amdgcn_s_setprio(3);      // the few producer instructions must not queue behind the consumers' MFMA stream
 
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
