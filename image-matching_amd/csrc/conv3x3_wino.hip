@@ -41,7 +41,9 @@ constexpr int RPITCH = RW, RS = 12;                       // FIRST: raw conv1a p
 constexpr int CK = 8, NT = 64;
 constexpr int RAW = RH * RPITCH * RS;                     // 2160 (FIRST only)
 constexpr int VK = 72;                                    // V channel-pair stride (64 + 8 pad: conflict-free transform writes)
-constexpr int VSZ = 16 * 4 * VK;                          // 4608
+constexpr int QS = 320;                                   // V position stride = 5 x 64 dwords: reads of different positions from one base
+                                                          // fuse into ds_read2st64_b32 (no per-read address VALU beside the MFMAs)
+constexpr int VSZ = 16 * QS;                              // 5120
 constexpr int USZ = 16 * 2 * 4 * 4 * 16;                  // 8192 = [16 pos][2 k-steps][4 co-blocks][4 k][16 co] per (64 co, 8 ci)
 constexpr int IMG_H = RH + 2, IMG_W = RW + 2;             // FIRST: image patch 12 x 20
 constexpr int RSF = 68;                                   // FIRST: conv1a patch [10*18 px][64 ch], pixel stride 68 (conflict-free)
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
   const int n0 = blockIdx.y * NT;
   const int H = p.H, W = p.W, Cin = p.Cin, Cout = p.Cout;
   const int nchunk = Cin / CK;
-  const float* ublk = p.wu + (size_t)blockIdx.y * nchunk * USZ;
+  const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.wu6, 0, (Cout / NT) * nchunk * USZ * 4, 0x00020000);
+  const int voff = (cb * 64 + lane) * 16;
 
   if constexpr (FIRST) {
     const float* im = (b < p.split) ? p.in + (size_t)b * H * W : p.in2 + (size_t)(b - p.split) * H * W;
@@ -181,12 +184,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
     //      barrier (the registers are dead once the wave leaves its MFMA loop) and land while the wave waits and the
     //      input transform runs, so the MFMA loop below touches no global memory except the
     //      next raw patch.  U never goes through LDS.
-    const float* ub = ublk + (size_t)ch * USZ + cb * 64 + lane;
-    float bf[16][2];             // [position][k-step]: the wave's whole B panel of this chunk (32 registers)
+    // wu6 layout [k-step][pos group][co-block][lane][4 pos]: group g's four B registers are ONE buffer_load_dwordx4 with
+    // SGPR descriptor / offset -- 8 vector-memory instructions and no address VALU per chunk (was 32 loads + 64 adds)
+    f32x4 bf[8];
+    {
+      const int uoff = __builtin_amdgcn_readfirstlane(((int)blockIdx.y * nchunk + ch) * (USZ * 4));
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) bf[q][s2] = ub[(q * 2 + s2) * 256];
+      for (int g = 0; g < 8; ++g)
+        bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
+    }
     __syncthreads();               // previous chunk's MFMA phase is done with raw / V
     IMX_TS(0)
     float d[16];
@@ -211,10 +217,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
       float* vp = V + (tc >> 1) * VK + tw * 2 + (tc & 1);
 #pragma unroll
       for (int xi = 0; xi < 4; ++xi) {       // columns: (B^T d) B ; position p = xi*4 + nu
-        vp[((xi * 4 + 0) * 4) * VK] = tt[xi][0] - tt[xi][2];
-        vp[((xi * 4 + 1) * 4) * VK] = tt[xi][1] + tt[xi][2];
-        vp[((xi * 4 + 2) * 4) * VK] = tt[xi][2] - tt[xi][1];
-        vp[((xi * 4 + 3) * 4) * VK] = tt[xi][1] - tt[xi][3];
+        vp[(xi * 4 + 0) * QS] = tt[xi][0] - tt[xi][2];
+        vp[(xi * 4 + 1) * QS] = tt[xi][1] + tt[xi][2];
+        vp[(xi * 4 + 2) * QS] = tt[xi][2] - tt[xi][1];
+        vp[(xi * 4 + 3) * QS] = tt[xi][1] - tt[xi][3];
       }
     }
     IMX_TS(3)
@@ -226,13 +232,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
     //      positions (8 MFMAs = 256 cycles).  A operands (V) come from LDS one group ahead, B operands
     //      are already in registers; the next chunk's raw patch load/store rides along.
     {
-      const float* va = V + (lane >> 5) * VK + (lane & 15) * 2 + ((lane >> 4) & 1);     // row block 1 is +32 floats
+      // four opaque element offsets (k-step 0/1 x row block 0/1): positions q, q' from one base are q*QS apart -> ds_read2st64
+      const int vlane = (lane >> 5) * VK + (lane & 15) * 2 + ((lane >> 4) & 1);
+      int o00 = vlane, o01 = vlane + 32, o10 = vlane + 2 * VK, o11 = vlane + 2 * VK + 32;
+      asm volatile("" : "+v"(o00), "+v"(o01), "+v"(o10), "+v"(o11));
+      const float* b00 = V + o00;
+      const float* b01 = V + o01;
+      const float* b10 = V + o10;
+      const float* b11 = V + o11;
       float af[2][4][2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[0][i][0] = va[(i * 4) * VK];
-        af[0][i][1] = va[(i * 4) * VK + 32];
-      }
+      for (int i = 0; i < 4; ++i) af[0][i][0] = b00[i * QS];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[0][i][1] = b01[i * QS];
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const int cur = g & 1, nxt = cur ^ 1;
@@ -240,17 +252,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
         if (g == 6) { IMX_SRAW() }
         if (g + 1 < 8) {
           const int s1 = (g + 1) >> 2, qb = ((g + 1) & 3) * 4;
+          const float* r0 = s1 ? b10 : b00;
+          const float* r1 = s1 ? b11 : b01;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            af[nxt][i][0] = va[((qb + i) * 4 + 2 * s1) * VK];
-            af[nxt][i][1] = va[((qb + i) * 4 + 2 * s1) * VK + 32];
-          }
+          for (int i = 0; i < 4; ++i) af[nxt][i][0] = r0[(qb + i) * QS];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[nxt][i][1] = r1[(qb + i) * QS];
         }
         const int q0 = (g & 3) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          acc[q0 + i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][0], bf[q0 + i][g >> 2], acc[q0 + i][0], 0, 0, 0);
-          acc[q0 + i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][1], bf[q0 + i][g >> 2], acc[q0 + i][1], 0, 0, 0);
+          acc[q0 + i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][0], bf[g][i], acc[q0 + i][0], 0, 0, 0);
+          acc[q0 + i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i][1], bf[g][i], acc[q0 + i][1], 0, 0, 0);
         }
         // one MFMA, then one LDS read (next group's A operand) / one other instruction in its shadow
 #pragma unroll
@@ -367,7 +380,7 @@ hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
 }  // namespace
 
 hipError_t launch_conv3x3_wino(const ConvArgs& a, hipStream_t s) {
-  if (a.Cin % CK || a.Cout % NT || (a.first && a.Cin != 64) || !a.wu) return hipErrorInvalidValue;
+  if (a.Cin % CK || a.Cout % NT || (a.first && a.Cin != 64) || !a.wu6) return hipErrorInvalidValue;
   if (a.first) return a.pool ? launch_t<true, true, true>(a, s) : launch_t<false, true, true>(a, s);
   if (a.pool) return a.relu ? launch_t<true, true, false>(a, s) : launch_t<true, false, false>(a, s);
   return a.relu ? launch_t<false, true, false>(a, s) : launch_t<false, false, false>(a, s);
