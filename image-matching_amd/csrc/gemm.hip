@@ -123,6 +123,13 @@ __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
   //      leaves as float4 row segments with bias / ReLU / residual applied on whole rows.
   constexpr int OS = NT + 4;
   const int hi = lane >> 5;
+  // this thread's column quad is the same for every row it stores (e % (NT/4) == tid % (NT/4)): its bias is loaded once,
+  // up front -- inside the store loop each iteration waited a full global-load latency for it (16 x ~1.3k cycles measured)
+  constexpr int ROWS_IT = BM * (NT / 4) / 256;          // rows per thread: 16 (NT = 128) / 8 (NT = 64)
+  const int c4 = (tid % (NT / 4)) * 4, gcol = n0 + c4, row0 = tid / (NT / 4);
+  const bool vec_ok = (p.ldo & 3) == 0 && (!p.res || (p.ldr & 3) == 0);
+  float4 bsv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias && gcol < p.Npad) bsv = *reinterpret_cast<const float4*>(p.bias + gcol);
 #pragma unroll
   for (int n = 0; n < NB; ++n) {
     const int col = n * 32 + (lane & 31);
@@ -130,29 +137,34 @@ __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
     for (int r = 0; r < 16; ++r) smem[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hi) * OS + col] = acc[n][r];
   }
   __syncthreads();
-  const bool vec_ok = (p.ldo & 3) == 0 && (!p.res || (p.ldr & 3) == 0);
+  if (gcol >= p.N) return;
+  const bool fast = vec_ok && gcol + 3 < p.N;
+  // rows in batches of 8: all residual loads and LDS reads of a batch are issued before the first store
 #pragma unroll
-  for (int it = 0; it < BM * (NT / 4) / 256; ++it) {
-    const int e = tid + it * 256;
-    const int row = e / (NT / 4), c4 = (e % (NT / 4)) * 4;
-    const int grow = r0 + row, gcol = n0 + c4;
-    if (grow >= p.M || gcol >= p.N) continue;
-    float4 v = *reinterpret_cast<const float4*>(smem + row * OS + c4);
-    if (p.bias) {
-      const float4 bsv = *reinterpret_cast<const float4*>(p.bias + gcol);
-      v.x += bsv.x; v.y += bsv.y; v.z += bsv.z; v.w += bsv.w;
+  for (int b0 = 0; b0 < ROWS_IT; b0 += 8) {
+    float4 v[8], rv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = row0 + (b0 + i) * (256 / (NT / 4)), grow = r0 + row;
+      rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (fast && p.res && grow < p.M) rv[i] = *reinterpret_cast<const float4*>(p.res + (size_t)grow * p.ldr + gcol);
+      v[i] = *reinterpret_cast<const float4*>(smem + row * OS + c4);
     }
-    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (vec_ok && gcol + 3 < p.N) {
-      if (p.res) {
-        const float4 rv = *reinterpret_cast<const float4*>(p.res + (size_t)grow * p.ldr + gcol);
-        v.x = rv.x + v.x; v.y = rv.y + v.y; v.z = rv.z + v.z; v.w = rv.w + v.w;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = row0 + (b0 + i) * (256 / (NT / 4)), grow = r0 + row;
+      if (grow >= p.M) continue;
+      float4 o = v[i];
+      o.x += bsv.x; o.y += bsv.y; o.z += bsv.z; o.w += bsv.w;
+      if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      if (fast) {
+        o.x = rv[i].x + o.x; o.y = rv[i].y + o.y; o.z = rv[i].z + o.z; o.w = rv[i].w + o.w;
+        *reinterpret_cast<float4*>(p.out + (size_t)grow * p.ldo + gcol) = o;
+      } else {                                // ragged N (e.g. 65) or unaligned leading dimension
+        const float vv[4] = {o.x, o.y, o.z, o.w};
+        for (int j = 0; j < 4 && gcol + j < p.N; ++j)
+          p.out[(size_t)grow * p.ldo + gcol + j] = (p.res ? p.res[(size_t)grow * p.ldr + gcol + j] : 0.f) + vv[j];
       }
-      *reinterpret_cast<float4*>(p.out + (size_t)grow * p.ldo + gcol) = v;
-    } else {                                // ragged N (e.g. 65) or unaligned leading dimension
-      const float vv[4] = {v.x, v.y, v.z, v.w};
-      for (int j = 0; j < 4 && gcol + j < p.N; ++j)
-        p.out[(size_t)grow * p.ldo + gcol + j] = (p.res ? p.res[(size_t)grow * p.ldr + gcol + j] : 0.f) + vv[j];
     }
   }
 }
