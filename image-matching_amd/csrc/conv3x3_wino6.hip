@@ -429,35 +429,39 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
     float* w1s = img + 2 * IMG;          // [9][64] + bias [64]
     for (int e = ptid; e < 9 * 64; e += 256) w1s[e] = p.w1[e];
     if (ptid < 64) w1s[9 * 64 + ptid] = p.b1[ptid];
-    // branch-free: threads 240..255 repeat run 29 (same values to the same addresses)
-    const int c1_tc = ptid & 7, c1_run = min(ptid >> 3, 29), c1_py = c1_run / 3, c1_xr = (c1_run % 3) * 6;
-    struct C1 { float wr[9], bias, tap[3][8]; };
+    // Packed over channel PAIRS: thread = (pair cp of the chunk's 8 channels, run of 3 pixels; 60 runs cover the 10x18
+    // patch, threads 240..255 repeat run 59).  Both channels of a pair share every tap, so each multiply-add is one
+    // v_pk_fma_f32 with the tap broadcast: half the FMA instructions per channel -- the producers' instruction count is
+    // what bounds a phase beside the consumers' MFMAs.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int c1_cp = ptid & 3, c1_run = min(ptid >> 2, 59), c1_py = c1_run / 6, c1_xr = (c1_run % 6) * 3;
+    struct C1 { f32x2 w[9], bias; float tap[3][5]; };
     auto conv1a_load = [&](int cch, const float* im, C1& r) __attribute__((always_inline)) {
 #pragma unroll
-      for (int tp = 0; tp < 9; ++tp) r.wr[tp] = w1s[tp * 64 + cch * CK + c1_tc];
-      r.bias = w1s[9 * 64 + cch * CK + c1_tc];
+      for (int tp = 0; tp < 9; ++tp) r.w[tp] = *reinterpret_cast<const f32x2*>(w1s + tp * 64 + cch * CK + 2 * c1_cp);
+      r.bias = *reinterpret_cast<const f32x2*>(w1s + 9 * 64 + cch * CK + 2 * c1_cp);
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float2 tv = *reinterpret_cast<const float2*>(im + (c1_py + dy) * IMG_W + c1_xr + 2 * j);
-          r.tap[dy][2 * j] = tv.x;
-          r.tap[dy][2 * j + 1] = tv.y;
-        }
+        for (int j = 0; j < 5; ++j) r.tap[dy][j] = im[(c1_py + dy) * IMG_W + c1_xr + j];
     };
     auto conv1a_finish = [&](const Item& it, const C1& r, float* rbuf) __attribute__((always_inline)) {
       const int gy = it.y0 + c1_py - 1;
       const float rowmask = (gy >= 0 && gy < H) ? 1.f : 0.f;
+      const f32x2 zero2 = {0.f, 0.f};
 #pragma unroll
-      for (int px = 0; px < 6; ++px) {
-        float v = r.bias;
+      for (int px = 0; px < 3; ++px) {
+        f32x2 v = r.bias;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx) v = fmaf(r.tap[dy][px + dx], r.wr[dy * 3 + dx], v);
+          for (int dx = 0; dx < 3; ++dx) {
+            const float t = r.tap[dy][px + dx];
+            v = __builtin_elementwise_fma((f32x2){t, t}, r.w[dy * 3 + dx], v);
+          }
         const int gx = it.x0 + c1_xr + px - 1;
         const float mask = (gx >= 0 && gx < W) ? rowmask : 0.f;
-        rbuf[(c1_py * RW + c1_xr + px) * RS + c1_tc] = fmaxf(v, 0.f) * mask;
+        *reinterpret_cast<f32x2*>(rbuf + (c1_py * RW + c1_xr + px) * RS + 2 * c1_cp) = __builtin_elementwise_max(v, zero2) * mask;
       }
     };
     auto img_load = [&](const Item& it) -> float {      // one pixel of the 12x20 image patch per thread (ptid < 240)
