@@ -73,51 +73,54 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
 
   if constexpr (FIRST) {
     const float* im = (b < p.split) ? p.in + (size_t)b * H * W : p.in2 + (size_t)(b - p.split) * H * W;
-    float wr[9];                       // issued together with the image patch loads: one latency, not two
+    // conv1a weights of this lane's channel PAIR, issued together with the image patch loads: one latency, not two
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int c1_cp = tid & 31, c1_g = tid >> 5;
+    f32x2 wr[9];
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) wr[tp] = p.w1[tp * 64 + lane];
-    const float bias = p.b1[lane];
+    for (int tp = 0; tp < 9; ++tp) wr[tp] = *reinterpret_cast<const f32x2*>(p.w1 + tp * 64 + 2 * c1_cp);
+    const f32x2 bias = *reinterpret_cast<const f32x2*>(p.b1 + 2 * c1_cp);
     for (int e = tid; e < IMG_H * IMG_W; e += 256) {
       const int py = e / IMG_W, px = e % IMG_W;
       const int gy = y0 + py - 2, gx = x0 + px - 2;
       img[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.f;
     }
     __syncthreads();
-    // conv1a + folded BN + ReLU for ALL 64 channels of the 10x18 halo patch, once per workgroup.  lane = channel
-    // (its 9 weights + bias live in registers), wave = 5 half-rows of 9 pixels; the image taps are wave-uniform
-    // float4 broadcasts from LDS (9 reads per half-row), so the phase is FMA-bound instead of LDS-bound.
-    // Positions outside the image are conv1b's zero padding.
+    // conv1a + folded BN + ReLU for ALL 64 channels of the 10x18 halo patch, once per workgroup, packed over channel
+    // pairs: lane = (pair, one of 8 pixel groups); a group takes runs g, g+8, .. of the 30 six-pixel runs.  Both channels
+    // share every tap, so each multiply-add is one v_pk_fma_f32 with the tap broadcast -- 216 packed FMAs per lane instead
+    // of 405 scalar ones (the prologue runs beside the co-resident workgroup's MFMAs, where instructions are expensive).
+    // Positions outside the image are conv1b's zero padding (mask multiply, no branches).
     {
-      auto half_row = [&](int hr, auto odd_c) {
-        constexpr int ODD = decltype(odd_c)::value;        // odd half-rows start at pixel 9: taps 9..19 sit in floats 8..19
-        const int py = hr >> 1, xo = ODD * 9, xb = ODD * 8;
-        float tap[3][12];
+      const f32x2 zero2 = {0.f, 0.f};
+#pragma unroll 1
+      for (int run = c1_g; run < 30; run += 8) {
+        const int py = run / 3, xr = (run % 3) * 6;
+        float tap[3][8];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-          for (int q4 = 0; q4 < 3; ++q4) {
-            const float4 tv = *reinterpret_cast<const float4*>(img + (py + dy) * IMG_W + xb + 4 * q4);
-            tap[dy][4 * q4] = tv.x; tap[dy][4 * q4 + 1] = tv.y; tap[dy][4 * q4 + 2] = tv.z; tap[dy][4 * q4 + 3] = tv.w;
+          for (int j = 0; j < 4; ++j) {
+            const float2 tv = *reinterpret_cast<const float2*>(img + (py + dy) * IMG_W + xr + 2 * j);
+            tap[dy][2 * j] = tv.x;
+            tap[dy][2 * j + 1] = tv.y;
           }
         const int gy = y0 + py - 1;
-        const float rowmask = (gy >= 0 && gy < H) ? 1.f : 0.f;      // masks as multiplies: no per-pixel scalar branches
+        const float rowmask = (gy >= 0 && gy < H) ? 1.f : 0.f;
 #pragma unroll
-        for (int px = 0; px < 9; ++px) {
-          float v = bias;
+        for (int px = 0; px < 6; ++px) {
+          f32x2 v = bias;
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) v = fmaf(tap[dy][px + dx + ODD], wr[dy * 3 + dx], v);
-          const int gx = x0 + xo + px - 1;
+            for (int dx = 0; dx < 3; ++dx) {
+              const float t = tap[dy][px + dx];
+              v = __builtin_elementwise_fma((f32x2){t, t}, wr[dy * 3 + dx], v);
+            }
+          const int gx = x0 + xr + px - 1;
           const float mask = (gx >= 0 && gx < W) ? rowmask : 0.f;
-          raw[(py * RW + xo + px) * RSF + lane] = fmaxf(v, 0.f) * mask;
+          *reinterpret_cast<f32x2*>(raw + (py * RW + xr + px) * RSF + 2 * c1_cp) = __builtin_elementwise_max(v, zero2) * mask;
         }
-      };
-#pragma unroll 1
-      for (int k = 0; k < 5; ++k) {
-        const int hr = __builtin_amdgcn_readfirstlane(wave * 5 + k);
-        if (hr & 1) half_row(hr, std::integral_constant<int, 1>{});
-        else half_row(hr, std::integral_constant<int, 0>{});
       }
     }
   }
