@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
   //      (measured on the wino4 variant: 19k -> 7k cycles).  The pooled tile is 4x smaller: direct stores.
   constexpr int OS = NT + 4;
   float* Ot = smem;
-  if constexpr (!POOL) __syncthreads();          // every wave is done with V / raw
+  __syncthreads();          // every wave is done with V / raw (the staging tile aliases them)
 #pragma unroll
   for (int jb = 0; jb < 2; ++jb) {          // jb = wtile row block
     const int col = cb * 16 + (lane & 15);
@@ -315,10 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
       float y10 = t1[0] + t1[1] + t1[2] + bs, y11 = t1[1] - t1[2] - t1[3] + bs;
       if (RELU) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
       if constexpr (POOL) {
-        const int Ho = H >> 1, Wo = W >> 1;
-        const int oy = (y0 >> 1) + wr, ox = (x0 >> 1) + wc;
-        if (oy < Ho && ox < Wo)
-          p.out[((size_t)(b * Ho + oy) * Wo + ox) * Cout + n0 + col] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
+        Ot[(wr * TC + wc) * OS + col] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));     // pooled tile: 4 x 8 pixels, staged too
       } else {
         float* o = Ot + ((2 * wr) * OW + 2 * wc) * OS + col;
         o[0] = y00;
@@ -328,7 +325,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
       }
     }
   }
-  if constexpr (!POOL) {
+  if constexpr (POOL) {
+    __syncthreads();
+    const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+    for (int it = 0; it < TR * TC * (NT / 4) / 256; ++it) {
+      const int e = tid + it * 256;
+      const int pix = e / (NT / 4), v4 = e % (NT / 4);
+      const int oy = (y0 >> 1) + pix / TC, ox = (x0 >> 1) + pix % TC;
+      if (oy < Ho && ox < Wo)
+        *reinterpret_cast<float4*>(p.out + ((size_t)(b * Ho + oy) * Wo + ox) * Cout + n0 + 4 * v4) =
+            *reinterpret_cast<const float4*>(Ot + pix * OS + 4 * v4);
+    }
+  } else {
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < OH * OW * (NT / 4) / 256; ++it) {
