@@ -406,11 +406,11 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   dim3 grid((unsigned)((nmax + 127) / 128), (unsigned)a.heads, (unsigned)(2 * a.B));
   const float scale = (float)(1.4426950408889634 / sqrt((double)hd));   // log2(e)/sqrt(HD)
   // A/B switch IMX_ATTN: 1 = one K/V tile in flight, 2 = software-pipelined softmax (attention2_kernel), 3 = two tiles in
-  // flight.  Measured (MI355X, C3 HD=32 / C5 HD=64, ms per step): 1: 10.97 / 11.2, 2: 11.5 / 11.1, 3: 11.1 / 10.65 --
-  // VALU work placed between MFMAs is not free (in-order issue), so the pipelined form loses; default = best per HD.
+  // flight (default).  Measured on MI355X, whole step, C3 (HD=32, 64 pairs) / C5 (HD=64, 8 pairs), pairs/s:
+  // 1: 1172 / 203.1, 2: 1163 / 203.6, 3: 1185 / 207.6 -- VALU work placed between MFMAs is not free (in-order issue),
+  // so the pipelined form gains nothing; keeping two tiles of K/V in flight hides the L2 latency of the staging loads.
   const char* env = getenv("IMX_ATTN");        // read per launch (tests switch it within one process)
-  const int forced = env ? atoi(env) : 0;
-  const int mode = forced ? forced : (hd == 32 ? 1 : 3);
+  const int mode = env ? atoi(env) : 3;
   if (hd == 32) {
     if (mode == 1) hipLaunchKernelGGL((attention_kernel<32, false>), grid, dim3(256), 0, s, a, scale);
     else if (mode == 2) hipLaunchKernelGGL(attention2_kernel<32>, grid, dim3(256), 0, s, a, scale);
