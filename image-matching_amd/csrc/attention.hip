@@ -30,7 +30,7 @@ namespace {
 // DEEP: two K/V tiles in flight in registers (a global load can take longer than one tile's MFMAs), same LDS.
 template <int HD, bool DEEP>
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale) {
-  constexpr int KS = HD + 1;          // K tile row stride (odd: conflict-free column reads)
+  constexpr int KS = HD + 4;          // K tile row stride: rows 16-byte aligned, 8 lanes of a b128 read cover all 32 banks
   constexpr int OB = HD / 32;         // output blocks of 32 dims
   __shared__ __attribute__((aligned(16))) float Kt[2][32 * KS];
   __shared__ __attribute__((aligned(16))) float Vt[2][32 * HD];
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
   _Pragma("unroll") for (int it = 0; it < ITER; ++it) {                                        \
     const int e = tid + it * 256, key = e / V4, v4 = e % V4;                                   \
     float* kd = &Kt[buf_][key * KS + 4 * v4];                                                  \
-    kd[0] = kreg[set_][it][0]; kd[1] = kreg[set_][it][1]; kd[2] = kreg[set_][it][2]; kd[3] = kreg[set_][it][3]; \
+    *reinterpret_cast<f32x4*>(kd) = kreg[set_][it];                                            \
     *reinterpret_cast<f32x4*>(&Vt[buf_][key * HD + 4 * v4]) = vreg[set_][it];                  \
   }
 
@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
       const float* vp = &Vt[buf][(4 * hi) * HD + l31];
       float kf[HD / 2], vf[OB][16];
 #pragma unroll
-      for (int t = 0; t < HD / 2; ++t) kf[t] = kp[t];
+      for (int t = 0; t < HD / 2; t += 4) {           // a lane's HD/2 values of its key row are contiguous: b128 reads
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + t);
+        kf[t] = kv[0]; kf[t + 1] = kv[1]; kf[t + 2] = kv[2]; kf[t + 3] = kv[3];
+      }
 #pragma unroll
       for (int o = 0; o < OB; ++o)
 #pragma unroll
@@ -130,21 +133,26 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float mn = fmaxf(m, mx);
       const float alpha = __builtin_amdgcn_exp2f(m - mn);      // m = -inf on the first tile -> 0
-      float rs = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pr = __builtin_amdgcn_exp2f(S[r] - mn);
-        S[r] = pr;
-        rs += pr;
-      }
+      for (int r = 0; r < 16; ++r) S[r] = __builtin_amdgcn_exp2f(S[r] - mn);
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 rs2 = {0.f, 0.f};                          // row sum in packed adds (8 instead of 16)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) rs2 += (f32x2){S[r], S[r + 1]};
+      float rs = rs2[0] + rs2[1];
       rs += __shfl_xor(rs, 32);
       l = l * alpha + rs;
       m = mn;
-      // ---- O^T = O^T * alpha + V^T . P^T
+      // ---- O^T = O^T * alpha + V^T . P^T ; the rescale is skipped when no lane of the wave saw a larger maximum
+      //      (alpha == 1 exactly -- the common case after the first tiles)
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+        for (int o = 0; o < OB; ++o)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[o][r] *= alpha;
+      }
 #pragma unroll
       for (int o = 0; o < OB; ++o) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) O[o][r] *= alpha;
 #pragma unroll
         for (int st = 0; st < 16; ++st)
           O[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[o][st], S[st], O[o], 0, 0, 0);
