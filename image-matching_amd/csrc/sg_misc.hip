@@ -170,31 +170,50 @@ __global__ __launch_bounds__(1024) void sinkhorn_slab(SinkhornArgs a, float* __r
       // four float4 loads per lane are issued before any of them is consumed, so the wave keeps 4 KB in flight
       const float* Srow = a.S + ((size_t)b * a.N0p + i) * a.N1p;
       float* trow = tile + r * a.N1p;
-      for (int j0 = jlo; j0 < jhi && j0 < n; j0 += 1024) {
+      // The segment (<= 1024 columns) is one batch of four float4 per lane, so the row's values sit in registers and the
+      // log-sum-exp can be the two-pass form (exact maximum first, then ONE fma + v_exp per element) instead of the
+      // online form's ~8 VALU per element; the maximum is wave-wide, as in torch.logsumexp.
+      if (jlo < n) {
         float4 x[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int j = j0 + k * 256 + lane * 4;
+          const int j = jlo + k * 256 + lane * 4;
           x[k] = j < jhi ? *reinterpret_cast<const float4*>(Srow + j) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        float t[16];
+        float mx = -INFINITY;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int j = j0 + k * 256 + lane * 4;
+          const int j = jlo + k * 256 + lane * 4;
+          float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
           if (j < jhi) {
             *reinterpret_cast<float4*>(trow + j) = x[k];
-            const float4 vv = *reinterpret_cast<const float4*>(vs + j);
-            if (j + 0 < n) lse_add(acc, x[k].x + vv.x);
-            if (j + 1 < n) lse_add(acc, x[k].y + vv.y);
-            if (j + 2 < n) lse_add(acc, x[k].z + vv.z);
-            if (j + 3 < n) lse_add(acc, x[k].w + vv.w);
+            vv = *reinterpret_cast<const float4*>(vs + j);
           }
+          t[4 * k + 0] = (j < jhi && j + 0 < n) ? x[k].x + vv.x : -INFINITY;
+          t[4 * k + 1] = (j < jhi && j + 1 < n) ? x[k].y + vv.y : -INFINITY;
+          t[4 * k + 2] = (j < jhi && j + 2 < n) ? x[k].z + vv.z : -INFINITY;
+          t[4 * k + 3] = (j < jhi && j + 3 < n) ? x[k].w + vv.w : -INFINITY;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) mx = fmaxf(mx, t[4 * k + c]);
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        if (mx > -INFINITY) {
+          const float ml = -mx * LOG2E;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sum += __builtin_amdgcn_exp2f(fmaf(t[e], LOG2E, ml));      // exp(t - mx); -inf -> 0
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        acc = LSE{mx, sum};
       }
     } else if (i == m) {
       for (int j = jlo + lane; j < jhi && j < n; j += 64) lse_add(acc, a.alpha + vs[j]);
     }
+    if (i == m) acc = wave_lse(acc);             // (real rows are already wave-reduced)
     if (i <= m && seg == W - 1 && lane == 0) lse_add(acc, a.alpha + vs[n]);      // the dustbin column, once per row
-    acc = wave_lse(acc);
     if (lane == 0) { pm[wave] = acc.m; ps[wave] = acc.s; }
   }
   __syncthreads();
@@ -212,18 +231,21 @@ __global__ __launch_bounds__(1024) void sinkhorn_slab(SinkhornArgs a, float* __r
   const int rows = min(R, m + 1 - i0);      // rows of this slab, the last may be the dustbin row
   float2* pb = reinterpret_cast<float2*>(part + ((size_t)b * nslab_max + slab) * (a.N1p + 1) * 2);
   for (int j = tid; j <= n; j += 1024) {
-    LSE acc{-INFINITY, 0.f};
     float t[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) t[r] = tile[r * a.N1p + j];          // rows beyond `rows` hold stale data, unused
+    for (int r = 0; r < R; ++r) t[r] = tile[r * a.N1p + j];          // rows beyond `rows` hold stale data, masked below
+    float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (r < rows) {
-        const bool real = (i0 + r < m) && (j < n);
-        lse_add(acc, (real ? t[r] : a.alpha) + uu[r]);
-      }
+      const bool real = (i0 + r < m) && (j < n);
+      t[r] = r < rows ? (real ? t[r] : a.alpha) + uu[r] : -INFINITY;
+      mx = fmaxf(mx, t[r]);
     }
-    pb[j] = make_float2(acc.m, acc.s);
+    const float ml = -mx * LOG2E;                                     // rows >= 1: mx is finite
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) sum += __builtin_amdgcn_exp2f(fmaf(t[r], LOG2E, ml));
+    pb[j] = make_float2(mx, sum);
   }
 }
 
