@@ -206,12 +206,20 @@ __global__ __launch_bounds__(1024) void nms_fast_kernel(const float* __restrict_
     }
     __syncthreads();
     if (hact) {
+      if constexpr (R == 4) {          // window 9 = 3 x 3: 14 + 8 three-input maxima instead of 8 x 8 two-input ones
+        float m3[NV - 2];
 #pragma unroll
-      for (int o = 0; o < ST; ++o) {
-        float m = v[o];
+        for (int k = 0; k < NV - 2; ++k) m3[k] = fmaxf(fmaxf(v[k], v[k + 1]), v[k + 2]);
 #pragma unroll
-        for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, v[o + k]);
-        P[hbase + R + o] = m;
+        for (int o = 0; o < ST; ++o) P[hbase + R + o] = fmaxf(fmaxf(m3[o], m3[o + 3]), m3[o + 6]);
+      } else {
+#pragma unroll
+        for (int o = 0; o < ST; ++o) {
+          float m = v[o];
+#pragma unroll
+          for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, v[o + k]);
+          P[hbase + R + o] = m;
+        }
       }
     }
     __syncthreads();
@@ -222,12 +230,20 @@ __global__ __launch_bounds__(1024) void nms_fast_kernel(const float* __restrict_
     }
     __syncthreads();
     if (vact) {
+      if constexpr (R == 4) {
+        float m3[NV - 2];
 #pragma unroll
-      for (int o = 0; o < ST; ++o) {
-        float m = v[o];
+        for (int k = 0; k < NV - 2; ++k) m3[k] = fmaxf(fmaxf(v[k], v[k + 1]), v[k + 2]);
 #pragma unroll
-        for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, v[o + k]);
-        P[vbase + (R + o) * PITCH] = m;
+        for (int o = 0; o < ST; ++o) P[vbase + (R + o) * PITCH] = fmaxf(fmaxf(m3[o], m3[o + 3]), m3[o + 6]);
+      } else {
+#pragma unroll
+        for (int o = 0; o < ST; ++o) {
+          float m = v[o];
+#pragma unroll
+          for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, v[o + k]);
+          P[vbase + (R + o) * PITCH] = m;
+        }
       }
     }
     __syncthreads();
