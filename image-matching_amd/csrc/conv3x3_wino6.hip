@@ -349,25 +349,27 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
     const int rdst0 = (rpy0 * RW + rpx0) * RS + 4 * rh0, rdst1 = (rpy1 * RW + rpx1) * RS + 4 * rh1;
     // fetch cursor: (item, chunk) of the next patch fetch; past the last item it keeps re-reading the last one
     int fk = 0, fc = 0;
-    const float* src0 = nullptr; const float* src1 = nullptr;
-    float m0 = 0.f, m1 = 0.f;
+    // Patch fetches are buffer loads: the descriptor (this item's image) and the chunk offset live in SGPRs, the thread's
+    // pixel offset is one VGPR per item, and an out-of-image pixel simply gets an out-of-range offset -- the hardware
+    // returns zeros (conv padding) with no clamp, mask multiply or 64-bit address arithmetic in the producers' stream.
+    __amdgpu_buffer_rsrc_t frc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
+    int voff0 = 0, voff1 = 0;
+    const int img_bytes = H * W * Cin * 4;
     auto raw_sources = [&](const Item& it) __attribute__((always_inline)) {
       const int gy0 = it.y0 + rpy0 - 1, gx0 = it.x0 + rpx0 - 1, gy1 = it.y0 + rpy1 - 1, gx1 = it.x0 + rpx1 - 1;
-      m0 = (gy0 >= 0 && gy0 < H && gx0 >= 0 && gx0 < W) ? 1.f : 0.f;
-      m1 = (gy1 >= 0 && gy1 < H && gx1 >= 0 && gx1 < W) ? 1.f : 0.f;
-      src0 = p.in + ((size_t)(it.b * H + min(max(gy0, 0), H - 1)) * W + min(max(gx0, 0), W - 1)) * Cin + 4 * rh0;
-      src1 = p.in + ((size_t)(it.b * H + min(max(gy1, 0), H - 1)) * W + min(max(gx1, 0), W - 1)) * Cin + 4 * rh1;
+      frc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)it.b * H * W * Cin), 0, img_bytes, 0x00020000);
+      voff0 = (gy0 >= 0 && gy0 < H && gx0 >= 0 && gx0 < W) ? ((gy0 * W + gx0) * Cin + 4 * rh0) * 4 : img_bytes;
+      voff1 = (gy1 >= 0 && gy1 < H && gx1 >= 0 && gx1 < W) ? ((gy1 * W + gx1) * Cin + 4 * rh1) * 4 : img_bytes;
     };
     raw_sources(sc.item(0));
     // A global load takes longer (~1.5 us under load) than one ~2k-cycle phase: FOUR patch fetches are kept in flight,
     // each issued four phases before the LDS write that consumes it.  Static register sets, loop unrolled by 4.
     f32x4 ra[4], rb[4];
-    float ma[4], mb[4];
     auto issue = [&](auto set_c) __attribute__((always_inline)) {
       constexpr int SET = decltype(set_c)::value;
-      ra[SET] = nt_load4(src0 + fc * CK);     // streaming: keep the activations from evicting U out of L2
-      rb[SET] = nt_load4(src1 + fc * CK);
-      ma[SET] = m0; mb[SET] = m1;
+      const int soff = __builtin_amdgcn_readfirstlane(fc * CK * 4);
+      ra[SET] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frc, voff0, soff, 2));     // slc: streaming
+      rb[SET] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frc, voff1, soff, 2));
       if (++fc == nchunk) {
         fc = 0;
         if (fk + 1 < sc.count) raw_sources(sc.item(++fk));
@@ -375,9 +377,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
     };
     auto put = [&](auto set_c, float* rbuf) __attribute__((always_inline)) {
       constexpr int SET = decltype(set_c)::value;
-      const float a = ma[SET], b2 = mb[SET];
-      *reinterpret_cast<f32x4*>(rbuf + rdst0) = ra[SET] * a;
-      *reinterpret_cast<f32x4*>(rbuf + rdst1) = rb[SET] * b2;
+      *reinterpret_cast<f32x4*>(rbuf + rdst0) = ra[SET];
+      *reinterpret_cast<f32x4*>(rbuf + rdst1) = rb[SET];
     };
     // ---- prologue: F(0..3), W(0), F(4) | T(0), W(1), F(5) | T(1), W(2), F(6)
     issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
