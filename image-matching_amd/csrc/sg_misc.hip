@@ -141,7 +141,8 @@ __global__ __launch_bounds__(1024) void sinkhorn_cols(SinkhornArgs a) {
 
 // Slab form of one Sinkhorn iteration: a workgroup (16 waves) keeps R rows of S in LDS, computes their
 // u (row pass, :145) and immediately the partial column log-sum-exps of (Z + u) over those rows
-// (:146), so S is read from HBM/L2 once per iteration instead of twice.  A second, small kernel merges
+// (:146), so S is read from HBM/L2 once per iteration instead of twice.  Both passes hold their operands in
+// registers, so each log-sum-exp is two-pass (exact max, then one fma + v_exp per element).  A second, small kernel merges
 // the per-slab partials into v.  Slab `m / R` also owns the dustbin row i = m.
 template <int R>
 __global__ __launch_bounds__(1024) void sinkhorn_slab(SinkhornArgs a, float* __restrict__ part, int nslab_max) {
