@@ -49,6 +49,10 @@ def load_library():
         raise RuntimeError(
             f"libimx.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc, gfx950). image_matching_amd has no CPU fallback.")
+    # torch must bring ITS HIP runtime into the process first: the library shares device memory and streams with torch
+    # tensors, and loading libimx.so (linked against /opt/rocm's libamdhip64) before torch left the process with two
+    # runtimes -- imx_create then saw no device (measured: build() followed by smoke() in one interpreter).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, f32p = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
     lib.imx_version.restype = ctypes.c_char_p
