@@ -154,3 +154,27 @@ def test_every_attention_variant_matches_bit_exact(mode, monkeypatch):
     monkeypatch.setenv("IMX_ATTN", mode)
     for name in ("c3_pair_s59.npz", "c5_pair_s19.npz"):
         test_full_size_matches_bit_exact_vs_reference_golden(name)
+
+
+@pytest.mark.parametrize("name", ["c3_pair_s59.npz", "c5_pair_s19.npz"])
+def test_full_size_transport_marginals(name):
+    """Size-independent property at BASELINE sizes: the Sinkhorn loop ends on a `v` update
+    (superglue_test.py:144-147), so whatever the iteration count the COLUMN marginals of exp(Z) are exact: every
+    keypoint column sums to 1, the dustbin column to M; rows are only approximately normalised."""
+    g = util.golden(name)
+    H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
+    data = _oracle_pair_inputs(seed, H, W, d, K)
+    eng, L = _engine(d)
+    sd = util.sg_sd(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, sd)
+    eng.set_debug(True)
+    _run(eng, {k: v.cuda() for k, v in data.items()}, (1, 1, H, W))
+    S = eng.fetch("scores_in")[0, :K, :K].astype(np.float64)
+    u, v = eng.fetch("u")[0].astype(np.float64), eng.fetch("v")[0].astype(np.float64)
+    Z = np.full((K + 1, K + 1), float(sd["bin_score"]))
+    Z[:K, :K] = S
+    Z = Z + u[:K + 1, None] + v[None, :K + 1] + np.log(2.0 * K)
+    P = np.exp(Z)
+    np.testing.assert_allclose(P[:, :K].sum(0), 1.0, rtol=3e-4)
+    np.testing.assert_allclose(P[:, K].sum(), float(K), rtol=3e-4)
+    assert np.all(P[:K].sum(1) > 0.5) and np.all(P[:K].sum(1) < 1.5)
