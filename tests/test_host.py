@@ -26,6 +26,26 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.imx_version()
 
 
+def test_header_is_plain_c_and_the_c_example_links(tmp_path):
+    """include/imx.h must be consumable from C (it is the drop-in boundary, not a C++/torch header): the plain-C
+    example compiles as C99, links against libimx.so + the HIP runtime only, and -- with no GPU here -- exits through
+    imx_create's clean "no HIP device" error rather than any CPU fallback."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc") or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("gcc / ROCm headers not present")
+    exe = str(tmp_path / "abi_example")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                    "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "examples", "abi_example.c"), "-L" + libdir, "-limx",
+                    "-L/opt/rocm/lib", "-lamdhip64", "-o", exe], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+    assert "gfx950" in r.stdout
+    if not torch.cuda.is_available():
+        assert r.returncode == 2 and "no CPU path" in r.stderr
+
+
 def test_config_struct_matches_header_layout():
     # 7 SuperPoint words + 1 + 64 + 1 + 8 + 2 = 83 32-bit words
     assert ctypes.sizeof(_lib.ImxConfig) == 4 * (7 + 1 + _lib.IMX_MAX_GNN_LAYERS + 1 + _lib.IMX_MAX_KENC + 2)
