@@ -12,6 +12,7 @@
 #include "imx_kernels.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace imx {
 
@@ -140,6 +141,42 @@ __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
   __syncthreads();
   if (gcol >= p.N) return;
   const bool fast = vec_ok && gcol + 3 < p.N;
+  if (fast && r0 + BM <= p.M) {
+    // Common case (whole tile inside M, aligned rows): straight-line stores -- no per-row bounds tests, row pointers
+    // advance by a constant, ReLU / residual chosen once.  The epilogue runs beside the neighbour workgroup's MFMA loop,
+    // where every instruction costs tens of cycles.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int RSTEP = 256 / (NT / 4);
+    const f32x4 bias4 = {bsv.x, bsv.y, bsv.z, bsv.w};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    float* op = p.out + (size_t)(r0 + row0) * p.ldo + gcol;
+    const float* rp = p.res ? p.res + (size_t)(r0 + row0) * p.ldr + gcol : nullptr;
+    const size_t ostep = (size_t)RSTEP * p.ldo, rstep = (size_t)RSTEP * p.ldr;
+    const float* sp = smem + row0 * OS + c4;
+    auto rows = [&](auto relu_c, auto res_c) __attribute__((always_inline)) {
+      constexpr bool RELU = decltype(relu_c)::value, RES = decltype(res_c)::value;
+#pragma unroll
+      for (int b0 = 0; b0 < ROWS_IT; b0 += 8) {
+        f32x4 v[8], rv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if constexpr (RES) rv[i] = *reinterpret_cast<const f32x4*>(rp + (b0 + i) * rstep);
+          v[i] = *reinterpret_cast<const f32x4*>(sp + (b0 + i) * RSTEP * OS);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          f32x4 o = v[i] + bias4;
+          if constexpr (RELU) o = __builtin_elementwise_max(o, zero4);
+          if constexpr (RES) o = rv[i] + o;
+          *reinterpret_cast<f32x4*>(op + (b0 + i) * ostep) = o;
+        }
+      }
+    };
+    using T = std::true_type; using F = std::false_type;
+    if (p.relu) { if (p.res) rows(T{}, T{}); else rows(T{}, F{}); }
+    else { if (p.res) rows(F{}, T{}); else rows(F{}, F{}); }
+    return;
+  }
   // rows in batches of 8: all residual loads and LDS reads of a batch are issued before the first store
 #pragma unroll
   for (int b0 = 0; b0 < ROWS_IT; b0 += 8) {
@@ -278,7 +315,27 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma16(GemmArgs p) {
       }
     }
     __syncthreads();
-    if (gcol < p.N) {
+    if (fast && gcol < p.N && r0 + BM <= p.M) {        // whole tile inside M: straight-line stores (see gemm_mfma)
+      const f32x4 bias4 = {bsv.x, bsv.y, bsv.z, bsv.w};
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      float* op = p.out + (size_t)(r0 + 64 * half + row0) * p.ldo + gcol;
+      const float* rp = p.res ? p.res + (size_t)(r0 + 64 * half + row0) * p.ldr + gcol : nullptr;
+      const size_t ostep = (size_t)RSTEP * p.ldo, rstep = (size_t)RSTEP * p.ldr;
+      const float* sp = smem + row0 * OS + c4;
+      f32x4 v[ROWS_IT], rv[ROWS_IT];
+#pragma unroll
+      for (int i = 0; i < ROWS_IT; ++i) {
+        rv[i] = zero4;
+        if (p.res) rv[i] = *reinterpret_cast<const f32x4*>(rp + i * rstep);
+        v[i] = *reinterpret_cast<const f32x4*>(sp + i * RSTEP * OS);
+      }
+#pragma unroll
+      for (int i = 0; i < ROWS_IT; ++i) {
+        f32x4 o = v[i] + bias4;
+        if (p.relu) o = __builtin_elementwise_max(o, zero4);
+        *reinterpret_cast<f32x4*>(op + i * ostep) = rv[i] + o;
+      }
+    } else if (gcol < p.N) {
       float4 v[ROWS_IT], rv[ROWS_IT];
 #pragma unroll
       for (int i = 0; i < ROWS_IT; ++i) {
