@@ -40,44 +40,54 @@ __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
     for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
   // register-staged double buffering: chunk c+1 is fetched from L2/HBM while chunk c feeds the MFMAs.
-  // (named scalars, not arrays: hipcc keeps small float4 arrays in scratch once sched_barrier is used)
-  float4 ar0, ar1, ar2, ar3, wr0, wr1, wr2, wr3;
+  // Per-thread source pointers are set up once (rows >= M read a clamped row: their results are never stored), so a
+  // chunk's fetch is 8 unconditional loads + pointer increments -- no zero-fill, bounds branches or 64-bit multiplies
+  // in the K loop.
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 ar0, ar1, ar2, ar3, wr0, wr1, wr2, wr3;
   static_assert(A_IT == 4 && (W_IT == 2 || W_IT == 4), "staging map");
-#define IMX_GA(reg_, it_)                                                                           \
-  {                                                                                                 \
-    const int e = tid + (it_) * 256, row = e / (CK / 4), v4 = e % (CK / 4);                         \
-    reg_ = (r0 + row < p.M) ? *reinterpret_cast<const float4*>(src + (size_t)(r0 + row) * lda + cc + 4 * v4) \
-                            : make_float4(0.f, 0.f, 0.f, 0.f);                                      \
-  }
-#define IMX_GW(reg_, it_, c0_)                                                                      \
-  {                                                                                                 \
-    const int idx = (tid + (it_) * 256) * 4, k = idx / NT, col = idx % NT;                          \
-    reg_ = *reinterpret_cast<const float4*>(p.w + (size_t)((c0_) + k) * p.Npad + n0 + col);         \
+  const float* asrc0[4]; const float* asrc1[4]; const float* wsrc[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int e = tid + it * 256, row = min(r0 + e / (CK / 4), p.M - 1), v4 = e % (CK / 4);
+    asrc0[it] = p.a0 + (size_t)row * p.lda0 + 4 * v4;
+    asrc1[it] = p.a1 ? p.a1 + (size_t)row * p.lda1 + 4 * v4 : asrc0[it];
+    const int idx = (tid + it * 256) * 4, k = idx / NT, col = idx % NT;
+    wsrc[it] = p.w + (size_t)k * p.Npad + n0 + col;
   }
 #define IMX_GLOAD(c0_)                                                                              \
   {                                                                                                 \
-    const float* src; int lda, cc;                                                                  \
-    if ((c0_) < p.K0) { src = p.a0; lda = p.lda0; cc = (c0_); } else { src = p.a1; lda = p.lda1; cc = (c0_) - p.K0; } \
-    IMX_GA(ar0, 0) IMX_GA(ar1, 1) IMX_GA(ar2, 2) IMX_GA(ar3, 3)                                     \
-    IMX_GW(wr0, 0, c0_) IMX_GW(wr1, 1, c0_)                                                         \
-    if constexpr (W_IT == 4) { IMX_GW(wr2, 2, c0_) IMX_GW(wr3, 3, c0_) }                            \
+    const int c0v = (c0_);                                                                          \
+    const bool first = c0v < p.K0;                                                                  \
+    const int cc = first ? c0v : c0v - p.K0;                                                        \
+    ar0 = *reinterpret_cast<const f32x4*>((first ? asrc0[0] : asrc1[0]) + cc);                      \
+    ar1 = *reinterpret_cast<const f32x4*>((first ? asrc0[1] : asrc1[1]) + cc);                      \
+    ar2 = *reinterpret_cast<const f32x4*>((first ? asrc0[2] : asrc1[2]) + cc);                      \
+    ar3 = *reinterpret_cast<const f32x4*>((first ? asrc0[3] : asrc1[3]) + cc);                      \
+    const size_t wo = (size_t)c0v * p.Npad;                                                         \
+    wr0 = *reinterpret_cast<const f32x4*>(wsrc[0] + wo);                                            \
+    wr1 = *reinterpret_cast<const f32x4*>(wsrc[1] + wo);                                            \
+    if constexpr (W_IT == 4) {                                                                      \
+      wr2 = *reinterpret_cast<const f32x4*>(wsrc[2] + wo);                                          \
+      wr3 = *reinterpret_cast<const f32x4*>(wsrc[3] + wo);                                          \
+    }                                                                                               \
   }
 #define IMX_SA(reg_, it_)                                                                           \
   {                                                                                                 \
     const int e = tid + (it_) * 256, row = e / (CK / 4), v4 = e % (CK / 4);                         \
     float* d = at + row * SA + 4 * v4;                                                              \
-    d[0] = reg_.x; d[1] = reg_.y; d[2] = reg_.z; d[3] = reg_.w;                                     \
+    d[0] = reg_[0]; d[1] = reg_[1]; d[2] = reg_[2]; d[3] = reg_[3];                                 \
   }
 #define IMX_LSTORE(buf_)                                                                            \
   {                                                                                                 \
     float* at = smem + (buf_) * BUF;                                                                \
     float* wt = at + BM * SA;                                                                       \
     IMX_SA(ar0, 0) IMX_SA(ar1, 1) IMX_SA(ar2, 2) IMX_SA(ar3, 3)                                     \
-    *reinterpret_cast<float4*>(wt + (tid + 0 * 256) * 4) = wr0;                                     \
-    *reinterpret_cast<float4*>(wt + (tid + 1 * 256) * 4) = wr1;                                     \
+    *reinterpret_cast<f32x4*>(wt + (tid + 0 * 256) * 4) = wr0;                                     \
+    *reinterpret_cast<f32x4*>(wt + (tid + 1 * 256) * 4) = wr1;                                     \
     if constexpr (W_IT == 4) {                                                                      \
-      *reinterpret_cast<float4*>(wt + (tid + 2 * 256) * 4) = wr2;                                   \
-      *reinterpret_cast<float4*>(wt + (tid + 3 * 256) * 4) = wr3;                                   \
+      *reinterpret_cast<f32x4*>(wt + (tid + 2 * 256) * 4) = wr2;                                   \
+      *reinterpret_cast<f32x4*>(wt + (tid + 3 * 256) * 4) = wr3;                                   \
     }                                                                                               \
   }
 
@@ -115,8 +125,6 @@ __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
   }
 #undef IMX_GLOAD
 #undef IMX_LSTORE
-#undef IMX_GA
-#undef IMX_GW
 #undef IMX_SA
 
   // ---- epilogue through LDS (the operand buffers are free after the loop's last barrier): the
