@@ -133,12 +133,17 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float mn = fmaxf(m, mx);
       const float alpha = __builtin_amdgcn_exp2f(m - mn);      // m = -inf on the first tile -> 0
-#pragma unroll
-      for (int r = 0; r < 16; ++r) S[r] = __builtin_amdgcn_exp2f(S[r] - mn);
       typedef float f32x2 __attribute__((ext_vector_type(2)));
-      f32x2 rs2 = {0.f, 0.f};                          // row sum in packed adds (8 instead of 16)
+      const f32x2 mn2 = {mn, mn};
+      f32x2 rs2 = {0.f, 0.f};                          // shift and row sum in packed ops (8 + 8 instead of 16 + 16)
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) rs2 += (f32x2){S[r], S[r + 1]};
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 dd = (f32x2){S[r], S[r + 1]} - mn2;
+        const f32x2 pp = {__builtin_amdgcn_exp2f(dd[0]), __builtin_amdgcn_exp2f(dd[1])};
+        S[r] = pp[0];
+        S[r + 1] = pp[1];
+        rs2 += pp;
+      }
       float rs = rs2[0] + rs2[1];
       rs += __shfl_xor(rs, 32);
       l = l * alpha + rs;
