@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void match_finalize(MatchArgs a) {
 }  // namespace
 
 // rows per LDS slab (R * N1p floats <= 64 KB); 0 = use the two-pass kernels
-int sinkhorn_slab_rows(int N1p) { return N1p <= 1024 ? 16 : N1p <= 2048 ? 8 : N1p <= 4096 ? 4 : 0; }
+int sinkhorn_slab_rows(int N1p) { return N1p <= 2048 ? 8 : N1p <= 4096 ? 4 : 0; }   // 8 rows even when 16 fit: 4 workgroups per CU (36 KB) hide the load latency better
 
 hipError_t launch_kenc0(const Kenc0Args& a, hipStream_t s) {
   long total = (long)a.B * a.Np * a.C1;
