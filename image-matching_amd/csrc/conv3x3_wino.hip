@@ -298,32 +298,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino(ConvArgs p, int tiles_x, 
   for (int jb = 0; jb < 2; ++jb) {          // jb = wtile row block
     const int col = cb * 16 + (lane & 15);
     const float bs = p.bias[n0 + col];
+#define ACC(q_) acc[q_][jb]
+    // The four accumulator registers of a (position, row block) are the same lane's four wtiles r = 0..3: the whole
+    // transform runs on them as f32x4 values, i.e. as v_pk_add_f32 pairs -- half the VALU instructions of a scalar loop
+    // over r, with no swizzles.
+    f32x4 t0[4], t1[4];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      t0[nu] = ACC(0 * 4 + nu) + ACC(1 * 4 + nu) + ACC(2 * 4 + nu);
+      t1[nu] = ACC(1 * 4 + nu) - ACC(2 * 4 + nu) - ACC(3 * 4 + nu);
+    }
+    const f32x4 bs4 = {bs, bs, bs, bs}, zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 y00 = t0[0] + t0[1] + t0[2] + bs4, y01 = t0[1] - t0[2] - t0[3] + bs4;
+    f32x4 y10 = t1[0] + t1[1] + t1[2] + bs4, y11 = t1[1] - t1[2] - t1[3] + bs4;
+    if (RELU) {
+      y00 = __builtin_elementwise_max(y00, zero4); y01 = __builtin_elementwise_max(y01, zero4);
+      y10 = __builtin_elementwise_max(y10, zero4); y11 = __builtin_elementwise_max(y11, zero4);
+    }
+    f32x4 pooled = zero4;
+    if constexpr (POOL) pooled = __builtin_elementwise_max(__builtin_elementwise_max(y00, y01), __builtin_elementwise_max(y10, y11));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int w = jb * 16 + 4 * (lane >> 4) + r;
       const int wr = w >> 3, wc = w & 7;
-      float m[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) m[q] = acc[q][jb][r];
-      float t0[4], t1[4];
-#pragma unroll
-      for (int nu = 0; nu < 4; ++nu) {
-        t0[nu] = m[0 * 4 + nu] + m[1 * 4 + nu] + m[2 * 4 + nu];
-        t1[nu] = m[1 * 4 + nu] - m[2 * 4 + nu] - m[3 * 4 + nu];
-      }
-      float y00 = t0[0] + t0[1] + t0[2] + bs, y01 = t0[1] - t0[2] - t0[3] + bs;
-      float y10 = t1[0] + t1[1] + t1[2] + bs, y11 = t1[1] - t1[2] - t1[3] + bs;
-      if (RELU) { y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f); }
       if constexpr (POOL) {
-        Ot[(wr * TC + wc) * OS + col] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));     // pooled tile: 4 x 8 pixels, staged too
+        Ot[(wr * TC + wc) * OS + col] = pooled[r];
       } else {
         float* o = Ot + ((2 * wr) * OW + 2 * wc) * OS + col;
-        o[0] = y00;
-        o[OS] = y01;
-        o[OW * OS] = y10;
-        o[OW * OS + OS] = y11;
+        o[0] = y00[r];
+        o[OS] = y01[r];
+        o[OW * OS] = y10[r];
+        o[OW * OS + OS] = y11[r];
       }
     }
+#undef ACC
   }
   if constexpr (POOL) {
     __syncthreads();
