@@ -23,6 +23,7 @@
 // halos / weights in that XCD's L2.
 #include "imx_kernels.h"
 #include <type_traits>
+#include <cstdlib>
 #include <cstdio>
 
 namespace imx {
@@ -210,13 +211,14 @@ __device__ __forceinline__ f32x4 nt_load4(const float* p) { return __builtin_non
 
 // input transform V = B^T d B: thread = (channel tc, wtile tw); raw pixel stride 12 keeps the reads conflict free.
 // Split into its LDS-read half and its compute + LDS-write half so other work can sit in the read latency.
+template <int RSX = RS>
 __device__ __forceinline__ void input_transform_load(const float* raw, int ptid, float (&d)[16]) {
   const int tc = ptid & 7, tw = ptid >> 3, twr = tw >> 3, twc = tw & 7;
-  const float* rp = raw + ((2 * twr) * RW + 2 * twc) * RS + tc;
+  const float* rp = raw + ((2 * twr) * RW + 2 * twc) * RSX + tc;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb) d[a * 4 + bb] = rp[(a * RW + bb) * RS];
+    for (int bb = 0; bb < 4; ++bb) d[a * 4 + bb] = rp[(a * RW + bb) * RSX];
 }
 __device__ __forceinline__ void input_transform_finish(const float (&d)[16], float* V, int ptid) {
   const int tc = ptid & 7, tw = ptid >> 3;
@@ -530,6 +532,168 @@ __global__ __launch_bounds__(512) void conv3x3_wino6(ConvArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Sixteen input channels per phase (two 8-channel chunks back to back, ONE barrier per 128 MFMAs).  The producers are
+// bound by dependent LDS round trips (read patch -> add -> write V), not by issue slots: with two independent
+// transforms per thread and phase those round trips overlap, and the barrier count halves.  Same arithmetic and U / V
+// layouts as conv3x3_wino6; V is double-buffered ([2 buffers][2 halves]), raw patches hold 16 channels per pixel
+// (stride 20: conflict-free reads).  LDS 144 KB.  Not for the fused first layer.
+constexpr int RS2 = 20, RAW2 = RH * RW * RS2;      // 3600
+template <bool POOL, bool RELU>
+__global__ __launch_bounds__(512) void conv3x3_wino6x2(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* V = smem;                    // [2][2][VSZ]
+  float* raw = V + 4 * VSZ;           // [2][RAW2]
+  float* Ot = raw + 2 * RAW2;         // [OTSZ]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Sched sc;
+  sc.init(p, blockIdx.x, gridDim.x);
+  if (sc.count == 0) return;
+  const int nchunk = p.Cin / CK, nphase = nchunk / 2;
+  const int S = sc.count * nphase;
+  const int H = p.H, W = p.W, Cin = p.Cin;
+
+  if (wave < 4) {
+    // ======================================================================================== consumers
+    const int cb = wave;
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][j][r] = 0.f;
+    f32x4 bf[8];
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.wu6, 0, (p.Cout / NT) * nchunk * USZ * 4, 0x00020000);
+    const int voff = (cb * 64 + lane) * 16;
+    auto ustep = [&](int k, int c) __attribute__((always_inline)) -> int {      // byte offset of a chunk's U block (scalar)
+      if (c >= nchunk) { c -= nchunk; ++k; }
+      if (k >= sc.count) { k = sc.count - 1; c = nchunk - 1; }
+      return __builtin_amdgcn_readfirstlane((sc.item(k).cob * nchunk + c) * (USZ * 4));
+    };
+    load_b_panel(bf, ur, ustep(0, 0), voff);
+    __syncthreads();
+    __syncthreads();
+    float af[2][4][2];
+    const int vlane = (lane >> 5) * VK + (lane & 15) * 2 + ((lane >> 4) & 1);
+    int buf = 0;
+    for (int k = 0; k < sc.count; ++k) {
+      const Item it = sc.item(k);
+      for (int c = 0; c < nphase; ++c) {
+        const float* v0 = V + buf * 2 * VSZ;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {               // this phase's first A operands (its V became visible at the barrier)
+          af[0][i][0] = v0[vlane + i * QS];
+          af[0][i][1] = v0[vlane + i * QS + 32];
+        }
+        mfma_chunk(acc, v0, v0 + VSZ, af, bf, ur, ustep(k, 2 * c + 1), voff, lane);
+        mfma_chunk(acc, v0 + VSZ, v0 + VSZ, af, bf, ur, ustep(k, 2 * c + 2), voff, lane);
+        if (c + 1 == nphase) output_transform<POOL, RELU>(acc, Ot, p.bias, it.cob * NT, cb, lane);
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+    return;
+  }
+
+  // ========================================================================================== producers
+  const int ptid = tid - 256;
+  __builtin_amdgcn_s_setprio(3);
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  // this thread's three raw-patch items: e < 720: pixel e>>2, channel quarter e&3 (threads without a third repeat their first)
+  int rdst[3], rpy[3], rpx[3], rq[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int e = ptid + 256 * i < RH * RW * 4 ? ptid + 256 * i : ptid;
+    rpy[i] = (e >> 2) / RW; rpx[i] = (e >> 2) % RW; rq[i] = e & 3;
+    rdst[i] = (rpy[i] * RW + rpx[i]) * RS2 + 4 * rq[i];
+  }
+  int fk = 0, fc = 0;
+  __amdgpu_buffer_rsrc_t frc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
+  int fvoff[3] = {0, 0, 0};
+  const int img_bytes = H * W * Cin * 4;
+  auto raw_sources = [&](const Item& it) __attribute__((always_inline)) {
+    frc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)it.b * H * W * Cin), 0, img_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int gy = it.y0 + rpy[i] - 1, gx = it.x0 + rpx[i] - 1;
+      fvoff[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? ((gy * W + gx) * Cin + 4 * rq[i]) * 4 : img_bytes;
+    }
+  };
+  raw_sources(sc.item(0));
+  f32x4 ra[4][3];
+  auto issue = [&](auto set_c) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+    const int soff = __builtin_amdgcn_readfirstlane(fc * 2 * CK * 4);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ra[SET][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frc, fvoff[i], soff, 2));
+    if (++fc == nphase) {
+      fc = 0;
+      if (fk + 1 < sc.count) raw_sources(sc.item(++fk));
+    }
+  };
+  auto put = [&](auto set_c, float* rbuf) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<f32x4*>(rbuf + rdst[i]) = ra[SET][i];
+  };
+  auto transform2 = [&](const float* rbuf, float* vbuf) __attribute__((always_inline)) {
+    float d0[16], d1[16];                          // two independent transforms: their LDS round trips overlap
+    input_transform_load<RS2>(rbuf, ptid, d0);
+    input_transform_load<RS2>(rbuf + CK, ptid, d1);
+    input_transform_finish(d0, vbuf, ptid);
+    input_transform_finish(d1, vbuf + VSZ, ptid);
+  };
+  // ---- prologue: F(0..3), W(0), F(4) | T(0), W(1), F(5)
+  issue(I0{}); issue(I1{}); issue(I2{}); issue(I3{});
+  put(I0{}, raw);
+  issue(I0{});
+  __syncthreads();
+  transform2(raw, V);
+  put(I1{}, raw + RAW2);
+  issue(I1{});
+  __syncthreads();
+  // ---- steady state, phase s: W(s+2), F(s+6), T(s+1), and the previous item's tile store
+  int k = 0, c = 0;
+  auto phase = [&](auto j_c) __attribute__((always_inline)) {
+    constexpr int J = decltype(j_c)::value;
+    put(std::integral_constant<int, (J + 2) & 3>{}, raw + (J & 1) * RAW2);
+    issue(std::integral_constant<int, (J + 2) & 3>{});
+    transform2(raw + ((J + 1) & 1) * RAW2, V + ((J + 1) & 1) * 2 * VSZ);
+    if (c == 0 && k > 0) store_tile<POOL>(p, sc.item(k - 1), Ot, ptid);
+    __syncthreads();
+    if (++c == nphase) { c = 0; ++k; }
+  };
+  for (int s = 0; s < S; s += 4) {
+    phase(I0{}); phase(I1{}); phase(I2{}); phase(I3{});
+  }
+  store_tile<POOL>(p, sc.item(sc.count - 1), Ot, ptid);
+}
+
+template <bool POOL, bool RELU>
+hipError_t launch_x2(const ConvArgs& a, hipStream_t s) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    (void)hipGetDeviceProperties(&prop, dev);
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount / NXCD * NXCD : 256;
+  }
+  const size_t lds = (size_t)(4 * VSZ + 2 * RAW2 + OTSZ) * sizeof(float);
+  auto k = conv3x3_wino6x2<POOL, RELU>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)ncu), dim3(512), lds, s, a);
+  return hipGetLastError();
+}
+
 template <bool POOL, bool RELU, bool FIRST>
 hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
   static int ncu = 0;
@@ -566,6 +730,11 @@ hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
 hipError_t launch_conv3x3_wino6(const ConvArgs& a, hipStream_t s) {
   if (a.Cin % (2 * CK) || a.Cout % NT || (a.first && a.Cin != 64) || !a.wu6) return hipErrorInvalidValue;
   if (a.first) return a.pool ? launch_t<true, true, true>(a, s) : launch_t<false, true, true>(a, s);
+  static const bool x1 = getenv("IMX_WINO6_X1") != nullptr;       // A/B: 8 channels per phase
+  if (!x1 && a.Cin % 64 == 0) {
+    if (a.pool) return a.relu ? launch_x2<true, true>(a, s) : launch_x2<true, false>(a, s);
+    return a.relu ? launch_x2<false, true>(a, s) : launch_x2<false, false>(a, s);
+  }
   if (a.pool) return a.relu ? launch_t<true, true, false>(a, s) : launch_t<true, false, false>(a, s);
   return a.relu ? launch_t<false, true, false>(a, s) : launch_t<false, false, false>(a, s);
 }
