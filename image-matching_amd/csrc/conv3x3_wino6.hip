@@ -730,7 +730,7 @@ hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
 hipError_t launch_conv3x3_wino6(const ConvArgs& a, hipStream_t s) {
   if (a.Cin % (2 * CK) || a.Cout % NT || (a.first && a.Cin != 64) || !a.wu6) return hipErrorInvalidValue;
   if (a.first) return a.pool ? launch_t<true, true, true>(a, s) : launch_t<false, true, true>(a, s);
-  static const bool x1 = getenv("IMX_WINO6_X1") != nullptr;       // A/B: 8 channels per phase
+  const bool x1 = getenv("IMX_WINO6_X1") != nullptr;       // A/B: 8 channels per phase (read per launch: tests switch it)
   if (!x1 && a.Cin % 64 == 0) {
     if (a.pool) return a.relu ? launch_x2<true, true>(a, s) : launch_x2<true, false>(a, s);
     return a.relu ? launch_x2<false, true>(a, s) : launch_x2<false, false>(a, s);
