@@ -7,7 +7,8 @@
 //
 //   * one workgroup of 8 waves per CU, persistent over a list of (tile, 64-channel block) work items;
 //   * waves 0-3 are CONSUMERS: nothing but v_mfma_f32_16x16x4_f32 (64 per 8-channel chunk), their A operands from
-//     LDS (V) and B operands (U) from L2 into a double-buffered register panel, and the in-lane output transform;
+//     LDS (V, ds_read2st64) and B operands (U) from L2 into a 32-register panel refilled in place (8 buffer_load_dwordx4
+//     per chunk), and the in-lane output transform;
 //   * waves 4-7 are PRODUCERS: they fetch the next raw 10x18x8 input patches (or compute them: FIRST mode fuses
 //     conv1a), run the input transform into the other V buffer, and write finished output tiles from an LDS
 //     staging tile to HBM as whole 256-byte channel rows;
@@ -21,6 +22,9 @@
 // output staging 34 KB (+ 2 image patches, conv1a weights in FIRST mode) = 107 KB.  XCD-aware: the work list is cut into 8
 // contiguous ranges (workgroup g runs on XCD g % 8), so the 32 workgroups of an XCD walk neighbouring tiles and share
 // halos / weights in that XCD's L2.
+//
+// Two kernels: conv3x3_wino6 (8 input channels per phase; also the FIRST = fused conv1a form) and conv3x3_wino6x2
+// (16 per phase, the default whenever Cin % 64 == 0; see its comment).
 #include "imx_kernels.h"
 #include <type_traits>
 #include <cstdlib>
