@@ -28,12 +28,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vectors: 
 namespace {
 
 // DEEP: two K/V tiles in flight in registers (a global load can take longer than one tile's MFMAs), same LDS.
-template <int HD, bool DEEP>
+// TK: keys per staged K/V tile and barrier (32 or 64; 64 = two 32-key sub-tiles multiplied back to back).
+template <int HD, bool DEEP, int TK = 32>
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale) {
   constexpr int KS = HD + 4;          // K tile row stride: rows 16-byte aligned, 8 lanes of a b128 read cover all 32 banks
   constexpr int OB = HD / 32;         // output blocks of 32 dims
-  __shared__ __attribute__((aligned(16))) float Kt[2][32 * KS];
-  __shared__ __attribute__((aligned(16))) float Vt[2][32 * HD];
+  __shared__ __attribute__((aligned(16))) float Kt[2][TK * KS];
+  __shared__ __attribute__((aligned(16))) float Vt[2][TK * HD];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
   const int head = blockIdx.y;
@@ -72,15 +73,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
     for (int r = 0; r < 16; ++r) O[o][r] = 0.f;
   float m = -INFINITY, l = 0.f;
 
-  const int nt = (nk + 31) / 32;
+  const int nt = (nk + TK - 1) / TK;        // staged tiles
   // staging map: 32 keys x HD dims, float4 per thread-iteration
   constexpr int V4 = HD / 4;                 // float4 per row
-  constexpr int ITER = (32 * V4) / 256;      // 1 (HD=32) or 2 (HD=64)
+  constexpr int ITER = (TK * V4) / 256;      // 1..4
   f32x4 kreg[2][ITER], vreg[2][ITER];
 #define IMX_GLOAD(set_, kt_)                                                                   \
   _Pragma("unroll") for (int it = 0; it < ITER; ++it) {                                        \
     const int e = tid + it * 256, key = e / V4, v4 = e % V4;                                   \
-    const float* base = p.qkv + (kbase + (size_t)(kt_) * 32 + key) * ld + head * HD + 4 * v4;  \
+    const int krow = min((kt_) * TK + key, Nkp - 1);      /* rows past the padded count are never used */ \
+    const float* base = p.qkv + (kbase + (size_t)krow) * ld + head * HD + 4 * v4;              \
     kreg[set_][it] = *reinterpret_cast<const f32x4*>(base + p.d);                              \
     vreg[set_][it] = *reinterpret_cast<const f32x4*>(base + 2 * p.d);                          \
   }
@@ -93,11 +95,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
   }
 
   // one key tile: S^T = K.Q^T, online softmax, O^T = O^T*alpha + V^T.P^T
-  auto tile = [&](int kt, int buf) __attribute__((always_inline)) {
+  auto tile32 = [&](int kt, int buf, int sub) __attribute__((always_inline)) {      // kt = 32-key tile index
     if (wave_active) {
       // ---- fetch this tile's K and V fragments from LDS up front (V lands during the S MFMAs)
-      const float* kp = &Kt[buf][l31 * KS + hi * (HD / 2)];
-      const float* vp = &Vt[buf][(4 * hi) * HD + l31];
+      const float* kp = &Kt[buf][(sub * 32 + l31) * KS + hi * (HD / 2)];
+      const float* vp = &Vt[buf][(sub * 32 + 4 * hi) * HD + l31];
       float kf[HD / 2], vf[OB][16];
 #pragma unroll
       for (int t = 0; t < HD / 2; t += 4) {           // a lane's HD/2 values of its key row are contiguous: b128 reads
@@ -162,6 +164,14 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
         for (int st = 0; st < 16; ++st)
           O[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[o][st], S[st], O[o], 0, 0, 0);
       }
+    }
+  };
+
+  auto tile = [&](int kts, int buf) __attribute__((always_inline)) {               // one staged tile = TK/32 sub-tiles
+#pragma unroll
+    for (int sub = 0; sub < TK / 32; ++sub) {
+      const int kt = kts * (TK / 32) + sub;
+      if (kt * 32 < nk) tile32(kt, buf, sub);          // block-uniform
     }
   };
 
@@ -427,10 +437,12 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   if (hd == 32) {
     if (mode == 1) hipLaunchKernelGGL((attention_kernel<32, false>), grid, dim3(256), 0, s, a, scale);
     else if (mode == 2) hipLaunchKernelGGL(attention2_kernel<32>, grid, dim3(256), 0, s, a, scale);
+    else if (mode == 4) hipLaunchKernelGGL((attention_kernel<32, true, 64>), grid, dim3(256), 0, s, a, scale);
     else hipLaunchKernelGGL((attention_kernel<32, true>), grid, dim3(256), 0, s, a, scale);
   } else if (hd == 64) {
     if (mode == 1) hipLaunchKernelGGL((attention_kernel<64, false>), grid, dim3(256), 0, s, a, scale);
     else if (mode == 2) hipLaunchKernelGGL(attention2_kernel<64>, grid, dim3(256), 0, s, a, scale);
+    else if (mode == 4) hipLaunchKernelGGL((attention_kernel<64, true, 64>), grid, dim3(256), 0, s, a, scale);
     else hipLaunchKernelGGL((attention_kernel<64, true>), grid, dim3(256), 0, s, a, scale);
   } else {
     return hipErrorInvalidValue;

@@ -146,7 +146,7 @@ def test_batched_pairs_equal_single_pair_runs():
             "batched pairs must be bit-identical to single-pair runs"
 
 
-@pytest.mark.parametrize("mode", ["1", "2", "3"])
+@pytest.mark.parametrize("mode", ["1", "2", "3", "4"])
 def test_every_attention_variant_matches_bit_exact(mode, monkeypatch):
     """IMX_ATTN selects the attention kernel (1: one K/V tile in flight, 2: software-pipelined softmax, 3: two tiles in
     flight; the default picks per head size).  Every variant must give the reference's matches on a C3 and the C5
