@@ -155,7 +155,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # IMX_BENCH_FORCE_PG=1: take the N>1 control flow (RCCL init, barriers, all-gather, max-over-ranks) at world 1 too, so
+    # that a 1-GPU box can check the exact code the driver's N=2,4,8 launches run.  Never set by the driver.
+    use_pg = world > 1 or os.environ.get("IMX_BENCH_FORCE_PG", "0") == "1"
+    if use_pg:
+        os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # nccl == RCCL on ROCm
@@ -182,10 +186,10 @@ def main():
             return {"counts0": cnt[:B], "counts1": cnt[B:], "matches0": cnt.new_zeros(1) + 1}, torch.zeros(world * B, 1)
         out = matching.match_batch(img0, img1)
         rec = shard.pack_records(pair_ids, out)
-        return out, shard.gather_records(rec)
+        return out, shard.gather_records(rec, force=use_pg)
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
 
     def timed(n):
@@ -197,7 +201,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_pg:
             t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -284,14 +288,14 @@ def main():
         flops_step = sum(u * per_step.get(k, 0.0) for k, (bd, u) in work.items() if bd == "mfma")
         line["roofline"]["pair_mfma_frac"] = round(flops_step / (dt / args.steps) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)
         line["roofline"]["kernels"] = {r[0]: {"launches": r[1], "ms_per_step": round(r[2] / args.steps, 4)} for r in rows}
-    if world > 1:
+    if use_pg:
         barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not sp_only:
         log("cpu baseline (oracle on host cores)")
         line["cpu_baseline"] = cpu_baseline(wl, cfg, sd_sp, sd_sg)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -47,10 +47,11 @@ def unpack_records(rec):
     return out
 
 
-def gather_records(rec, group=None):
+def gather_records(rec, group=None, force=False):
     """All ranks contribute (B, w) records (same B on every rank); returns (world*B, w) on every
-    rank, ordered by rank.  Without an initialised process group (world 1) returns `rec`."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    rank, ordered by rank.  Without an initialised process group (world 1) returns `rec`; `force`
+    runs the collective even at world 1 (bring-up check of the RCCL path on a 1-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return rec
     world = dist.get_world_size(group)
     if dist.get_backend(group) != "nccl" and rec.is_cuda:      # host-side gather (gloo bring-up); RCCL gathers in HBM

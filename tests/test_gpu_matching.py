@@ -138,3 +138,25 @@ def test_pair_sharding_is_order_independent():
     assert torch.equal(shard.sort_by_pair_id(parts), whole)
     rec = shard.unpack_records(whole)
     assert rec["pair_id"].tolist() == list(range(n_pairs)) and (rec["counts0"] == K).all()
+
+
+def test_bench_through_the_driver_launch_line_with_rccl():
+    """The driver starts N>1 benches as `python -m torch.distributed.run ... bench.py --gpus N`.  On a 1-GPU box the
+    same launch line with one rank and IMX_BENCH_FORCE_PG=1 runs every statement of the N>1 control flow over the
+    real RCCL backend: process-group init with a device id, barriers, the all-gather of the match records
+    (shard.gather_records), the max-over-ranks all-reduce, rank 0 printing one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IMX_BENCH_FORCE_PG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--pairs-per-gpu", "4", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak" and "roofline" in line
