@@ -36,6 +36,7 @@ struct ConvW {
   float* wu = nullptr;   // Winograd F(2x2,3x3) form (conv3x3_wino.hip layout)
   float* wu4 = nullptr;  // Winograd F(2x2,3x3) form (conv3x3_wino4.hip layout)
   float* wu6 = nullptr;  // Winograd F(2x2,3x3) form (conv3x3_wino6.hip layout: four positions per lane = one dwordx4)
+  float* wu24 = nullptr; // Winograd F(2x4,3x3) form (conv1ab_wino24.hip layout), conv1b only
   float* b = nullptr;
   int cin = 0, cout = 0;
 };
@@ -90,6 +91,7 @@ struct imx_handle_s {
   int det_B = 0, det_H = 0, det_W = 0, det_Hc = 0, det_Wc = 0, det_Ksel = 0;
   // debug / timing
   bool debug = false, timing = false;
+  bool conv1_f24 = true;  // fused first layer: conv1b as Winograd F(2x4,3x3) (conv1ab_wino24.hip); IMX_CONV1=f22 keeps the F(2x2,3x3) kernel
   int conv_mode = 4;      // 3x3 conv kernel: 4 auto (conv1a+1b fused: wino, all other layers: wino6), 0 direct (IMX_CONV=direct),
                           // 1 Winograd 16x16x4 (wino), 2 Winograd 32x32x2 pipelined (wino4), 3 persistent producer/consumer (wino6)
   std::map<std::string, Tap> taps;
@@ -300,6 +302,34 @@ std::vector<float> wino_transform(const std::vector<float>& w, int cin, int cout
   return u;
 }
 
+// U = G2 g G4^T (4 x 6 per (co, ci); F(2,3) down the rows, F(4,3) along the columns), laid out as conv1ab_wino24.hip's MFMA
+// B fragments read it: [chunk of 8 ci][quad = position pair][co-block][lane = (ci pair)*16 + co%16][(position parity)*2 + ci%2],
+// position p = j*4 + i: a lane's four B registers of a quad are one buffer_load_dwordx4.
+std::vector<float> wino24_transform(const std::vector<float>& w, int cin, int cout) {
+  static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  static const double G4[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                  {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+  const int nchunk = cin / 8;
+  std::vector<float> u((size_t)nchunk * 12288, 0.f);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci) {
+      double g[3][3];
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((size_t)(ky * 3 + kx) * cin + ci) * cout + co];
+      const int chunk = ci / 8, kk = ci % 8, k = kk >> 1, sstep = kk & 1;
+      float* blk = u.data() + (size_t)chunk * 12288;
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 6; ++j) {
+          double acc = 0.0;
+          for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) acc += G2[i][ky] * g[ky][kx] * G4[j][kx];
+          const int pos = j * 4 + i, quad = pos >> 1, e = (pos & 1) * 2 + sstep;
+          blk[(size_t)(((quad * 4 + (co >> 4)) * 64 + k * 16 + (co & 15)) * 4) + e] = (float)acc;
+        }
+    }
+  return u;
+}
+
 int make_conv(imx_handle_t h, ConvW& out, const std::map<std::string, HostTensor>& raw, const std::string& conv,
               const std::string& bn, int cin, int cout) {
   std::vector<float> w((size_t)9 * cin * cout), b(cout);
@@ -376,6 +406,12 @@ int finalize_superpoint(imx_handle_t h) {
   const int cin[8] = {1, 64, 64, 64, 64, 128, 128, 128}, cout[8] = {64, 64, 64, 64, 128, 128, 128, 128};
   for (int i = 1; i < 8; ++i)
     if (make_conv(h, h->conv[i - 1], raw, ck[i], bk[i], cin[i], cout[i])) return -1;
+  {   // conv1b again in the F(2x4,3x3) form of the fused first-layer kernel
+    std::vector<float> w((size_t)9 * 64 * 64), b(64);
+    put_conv3(raw, ck[1], bk[1], 64, 64, 64, 0, w, b);
+    h->conv[0].wu24 = upload(h, wino24_transform(w, 64, 64));
+    if (!h->conv[0].wu24) return fail(h, "weight upload failed (conv1b, F(2x4))");
+  }
   // heads: convPa | convDa merged into one 128 -> 512 convolution
   {
     std::vector<float> w((size_t)9 * 128 * 512), b(512);
@@ -528,9 +564,9 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   auto conv = [&](const char* name, const ConvW& w, const float* in, float* out, int hh, int ww, bool pool, bool first) -> int {
     ConvArgs a{};
     a.in = in; a.in2 = first ? img1 : nullptr; a.split = first ? split : 0;
-    a.w = w.w; a.wu = w.wu; a.wu4 = w.wu4; a.wu6 = w.wu6; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
+    a.w = w.w; a.wu = w.wu; a.wu4 = w.wu4; a.wu6 = w.wu6; a.wu24 = w.wu24; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
     a.B = B; a.H = hh; a.W = ww; a.Cin = w.cin; a.Cout = w.cout; a.relu = 1; a.pool = pool ? 1 : 0; a.first = first ? 1 : 0;
-    RUN(name, (h->conv_mode == 3 || (h->conv_mode == 4 && !a.first)) ? launch_conv3x3_wino6(a, s) : h->conv_mode == 2 ? launch_conv3x3_wino4(a, s) : h->conv_mode == 0 ? launch_conv3x3(a, s) : launch_conv3x3_wino(a, s));
+    RUN(name, (h->conv_mode == 4 && a.first && a.pool && h->conv1_f24) ? launch_conv1ab_wino24(a, s) : (h->conv_mode == 3 || (h->conv_mode == 4 && !a.first)) ? launch_conv3x3_wino6(a, s) : h->conv_mode == 2 ? launch_conv3x3_wino4(a, s) : h->conv_mode == 0 ? launch_conv3x3(a, s) : launch_conv3x3_wino(a, s));
     return 0;
   };
   if (conv("conv1ab_pool", h->conv[0], img0, a1, H, W, true, true)) return -1;
@@ -727,6 +763,7 @@ int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
   imx_handle_s* h = new imx_handle_s();
   h->device = device_id;
   h->cfg = *cfg;
+  if (const char* e = getenv("IMX_CONV1")) h->conv1_f24 = std::string(e) != "f22";
   if (const char* e = getenv("IMX_CONV")) h->conv_mode = std::string(e) == "direct" ? 0 : std::string(e) == "wino4" ? 2 : std::string(e) == "wino6" ? 3 : std::string(e) == "wino" ? 1 : 4;
   build_expected(h);
   *out = h;

@@ -173,13 +173,15 @@ def test_dense_forward_for_label_export_vs_reference_golden():
     util.assert_close(out["desc"], g["desc"], "desc")
 
 
-@pytest.mark.parametrize("mode", ["direct", "wino", "wino4", "wino6", "wino6-x1"])
+@pytest.mark.parametrize("mode", ["direct", "wino", "wino4", "wino6", "wino6-x1", "auto-f22"])
 def test_every_conv_kernel_variant_vs_reference_golden(mode, monkeypatch):
     """The 3x3-conv layers have four implementations (IMX_CONV, read at imx_create): direct implicit GEMM, Winograd with
     two workgroups per CU, the 32x32x2 variant and the persistent producer/consumer form; the default mixes two of them.
     Each one alone must reproduce the reference's dense stages and keypoints on the ragged fixture (123x165: partial
     tiles on both axes) and on the 120x160 one."""
     monkeypatch.setenv("IMX_CONV", mode.split("-")[0])
+    if mode.endswith("-f22"):           # default dispatch, but the fused first layer as F(2x2,3x3) (default: F(2x4,3x3))
+        monkeypatch.setenv("IMX_CONV1", "f22")
     if mode.endswith("-x1"):            # the 8-channels-per-phase form of the persistent kernel (default: 16)
         monkeypatch.setenv("IMX_WINO6_X1", "1")
     for name in ("sp_ragged.npz", "sp_small.npz"):
