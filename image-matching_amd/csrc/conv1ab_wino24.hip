@@ -20,6 +20,8 @@
 //     [chunk][quad][co-block][lane][4]) ONE buffer_load_dwordx4, issued before the chunk barrier: U never touches LDS.
 // LDS 62 KB, 2 workgroups per CU.
 #include "imx_kernels.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace imx {
 
@@ -31,7 +33,7 @@ constexpr int OH = 8, OW = 16;                 // output pixels per workgroup (4
 constexpr int RH = OH + 2, RW = OW + 2;        // conv1a patch (pad-1 halo)
 constexpr int IMG_H = RH + 2, IMG_W = RW + 2;  // image patch 12 x 20
 constexpr int RS = 66;                         // conv1a patch pixel stride: wtile columns 4 px apart land 8 banks apart
-constexpr int RAWSZ = RH * RW * RS;            // 11880
+constexpr int RAWSZ = 192 * RS;                // 10x18 = 180 pixels + 12 pad (the conv1a GEMM's twelfth pixel block stores unmasked)
 constexpr int KS = 18;                         // V: 16-byte slots per k index (16 wtiles + 2: conflict-free b128 writes)
 constexpr int QSL = 4 * KS;                    // slots per quad
 constexpr int NQ = 12;                         // quads per chunk: 24 positions x 2 k-steps / 4
@@ -39,7 +41,17 @@ constexpr int VSZ = NQ * QSL * 4;              // 3456
 constexpr int UCH = NQ * 4 * 64 * 4;           // 12288 floats of U per (64 co, 8 ci)
 constexpr int CK = 8, NT = 64, OS = NT + 4;
 
-__global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x, int tiles_y) {
+template <bool TRACE>
+__global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x, int tiles_y, int ntiles, unsigned* trace) {
+  // TRACE: per-phase s_memtime deltas summed over chunks and tiles (bring-up instrumentation, IMX_WINO_TRACE=1)
+  unsigned tph[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = 0;
+#define IMX_TS(i_)                                                   \
+  if constexpr (TRACE) {                                             \
+    const unsigned long long now = __builtin_readcyclecounter();     \
+    tph[i_] += (unsigned)(now - tprev);                              \
+    tprev = now;                                                     \
+  }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* V = smem;
   float* raw = V + VSZ;
@@ -47,191 +59,268 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cb = wave;
-  int t = blockIdx.x;
-  const int tx = t % tiles_x; t /= tiles_x;
-  const int ty = t % tiles_y;
-  const int b = t / tiles_y;
-  const int x0 = tx * OW, y0 = ty * OH;
   const int H = p.H, W = p.W, Cout = p.Cout;
   constexpr int nchunk = 64 / CK;
   const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.wu24, 0, nchunk * UCH * 4, 0x00020000);
   const int voff = (cb * 64 + lane) * 16;
 
-  // ---- conv1a + folded BN + ReLU for all 64 channels of the 10x18 halo patch, packed over channel pairs: lane = (pair,
-  //      one of 8 pixel groups), a group takes runs g, g+8, .. of the 30 six-pixel runs; every multiply-add is one
-  //      v_pk_fma_f32 with the tap broadcast.  Positions outside the image are conv1b's zero padding (mask multiply).
-  {
-    const float* im = (b < p.split) ? p.in + (size_t)b * H * W : p.in2 + (size_t)(b - p.split) * H * W;
-    const int c1_cp = tid & 31, c1_g = tid >> 5;
-    f32x2 wr[9];
+  // ---- per-lane constants of the conv1a GEMM (see the tile loop): A = weights, 12 registers, loaded once per workgroup
+  const int n = lane & 15, kq = lane >> 4;
+  const float c2 = kq == 0 ? 1.f : 0.f, a2 = kq == 1 ? 1.f : 0.f;      // third k-step: tap 8 | the bias "tap" (input 1) | zero padding
+  float wa[4][3];
+  int toff[3];
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) wr[tp] = *reinterpret_cast<const f32x2*>(p.w1 + tp * 64 + 2 * c1_cp);
-    const f32x2 bias = *reinterpret_cast<const f32x2*>(p.b1 + 2 * c1_cp);
-    for (int e = tid; e < IMG_H * IMG_W; e += 256) {
-      const int py = e / IMG_W, px = e % IMG_W;
-      const int gy = y0 + py - 2, gx = x0 + px - 2;
-      img[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.f;
-    }
-    __syncthreads();
-    const f32x2 zero2 = {0.f, 0.f};
-#pragma unroll 1
-    for (int run = c1_g; run < 30; run += 8) {
-      const int py = run / 3, xr = (run % 3) * 6;
-      float tap[3][8];
+  for (int ks = 0; ks < 3; ++ks) {
+    const int tap = 4 * ks + kq;
+    toff[ks] = tap < 9 ? (tap / 3) * IMG_W + tap % 3 : 0;
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float2 tv = *reinterpret_cast<const float2*>(img + (py + dy) * IMG_W + xr + 2 * j);
-          tap[dy][2 * j] = tv.x;
-          tap[dy][2 * j + 1] = tv.y;
-        }
-      const int gy = y0 + py - 1;
-      const float rowmask = (gy >= 0 && gy < H) ? 1.f : 0.f;
-#pragma unroll
-      for (int px = 0; px < 6; ++px) {
-        f32x2 v = bias;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const float tt = tap[dy][px + dx];
-            v = __builtin_elementwise_fma((f32x2){tt, tt}, wr[dy * 3 + dx], v);
-          }
-        const int gx = x0 + xr + px - 1;
-        const float mask = (gx >= 0 && gx < W) ? rowmask : 0.f;
-        *reinterpret_cast<f32x2*>(raw + (py * RW + xr + px) * RS + 2 * c1_cp) = __builtin_elementwise_max(v, zero2) * mask;
-      }
+    for (int cbk = 0; cbk < 4; ++cbk) {
+      const float* src = tap < 9 ? p.w1 + tap * 64 + cbk * 16 + n : p.b1 + cbk * 16 + n;
+      const float v = *(tap <= 9 ? src : p.b1);
+      wa[cbk][ks] = tap <= 9 ? v : 0.f;
     }
   }
-
-  f32x4 acc[24];
-#pragma unroll
-  for (int q = 0; q < 24; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // transform lane = (channel pair tk, wtile tw): a quarter-wave (16 lanes) = 4 pairs x the 4 wtiles of one wtile row
+  // ---- per-lane constants of the input transform: lane = (channel pair tk, wtile tw), a quarter-wave (16 lanes) = 4 pairs x
+  //      the 4 wtiles of one wtile row; transformed row i = wave:  i0 = d0 - d2, i1 = d1 + d2, i2 = d2 - d1, i3 = d1 - d3
   const int tk = lane & 3, tw = lane >> 2, twr = tw >> 2, twc = tw & 3;
   const float* rbase = raw + ((2 * twr) * RW + 4 * twc) * RS + 2 * tk;
-  float* vwr = V + (tk * KS + tw) * 4;
+  const int ra = wave == 0 ? 0 : wave == 2 ? 2 : 1, rb = wave == 0 ? 2 : wave == 1 ? 2 : wave == 2 ? 1 : 3;
+  const float sg = wave == 1 ? 1.f : -1.f;
+  const f32x2 sg2 = {sg, sg};
+  const float* rpa = rbase + ra * RW * RS;
+  const float* rpb = rbase + rb * RW * RS;
+  float* vwr = V + (tk * KS + tw) * 4 + (wave >> 1) * QSL * 4 + (wave & 1) * 2;
   int aoff = ((lane >> 4) * KS + (lane & 15)) * 4;
   asm volatile("" : "+v"(aoff));               // opaque: the 12 quad reads are immediate offsets from one base
   const float* vrd = V + aoff;
 
-  for (int ch = 0; ch < nchunk; ++ch) {
-    // ---- this chunk's B operands: 12 buffer_load_dwordx4 (SGPR descriptor + offset), landing while the wave waits at
-    //      the barriers and the transform runs
-    f32x4 bf[NQ];
+  // ---- persistent over a contiguous range of tiles (coordinates advance incrementally: no divisions in the loop); the
+  //      NEXT tile's image patch element (12x20 patch: one float per thread) is fetched a whole tile ahead, so a tile's
+  //      prologue never waits on HBM
+  const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_begin = (int)blockIdx.x * per, t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
+  int tx = t_begin % tiles_x, ty = (t_begin / tiles_x) % tiles_y, b = t_begin / (tiles_x * tiles_y);
+  const int ipy = tid / IMG_W - 2, ipx = tid % IMG_W - 2;
+  auto fetch_px = [&](int ftx, int fty, int fb, bool live) -> float {
+    const int gy = fty * OH + ipy, gx = ftx * OW + ipx;
+    const float* im = (fb < p.split) ? p.in + (size_t)fb * H * W : p.in2 + (size_t)(fb - p.split) * H * W;
+    return (live && tid < IMG_H * IMG_W && gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.f;
+  };
+  float pre = fetch_px(tx, ty, b, t_begin < t_end);
+  // conv1a gather geometry of this lane's three pixel blocks (tile independent)
+  int gpy[3], gpx[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int pp = (3 * wave + j) * 16 + n;          // pixel of the 10x18 patch (180 real + 12 pad)
+    const int pc = pp < RH * RW ? pp : RH * RW - 1;  // pad columns gather a valid address (their B column is zeroed)
+    gpy[j] = pc / RW;
+    gpx[j] = pc % RW;
+  }
+  int ntile_done = 0;
+
+  for (int t = t_begin; t < t_end; ++t) {
+    if constexpr (TRACE) tprev = __builtin_readcyclecounter();
+    const int x0 = tx * OW, y0 = ty * OH, bcur = b;
+    if (tid < IMG_H * IMG_W) img[tid] = pre;
+    if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++b; } }      // -> next tile
+    pre = fetch_px(tx, ty, b, t + 1 < t_end);
+    __syncthreads();             // image patch visible; the previous tile's epilogue is done with the staging tile
+
+    // ---- conv1a + folded BN + ReLU for all 64 channels of the 10x18 halo patch ON THE MATRIX CORES (the packed-FMA form
+    //      cost ~470 instructions per wave, each ~20 cycles beside the co-resident workgroup's MFMA stream):
+    //      D[channel][pixel] = W[channel][tap] * im2col[tap][pixel], K = 9 taps + the bias as a tenth "tap" whose input is
+    //      1, padded to three k-steps of 4.  B = image gathers from LDS; a pixel outside the image gets an all-zero B
+    //      column (taps AND bias), so its output is relu(0) = 0: conv1b's zero padding without a mask multiply.  A lane's
+    //      four D registers are four consecutive channels of one pixel -> two ds_write_b64.
+    //      wave w takes pixel blocks 3w..3w+2 (of twelve 16-pixel blocks) x all four 16-channel blocks: 36 MFMAs.
     {
-      const int uoff = __builtin_amdgcn_readfirstlane(ch * (UCH * 4));
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int g = 0; g < NQ; ++g)
-        bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
-    }
-    __syncthreads();               // previous chunk's MFMA phase is done with V (first chunk: conv1a patch complete)
-    if (wave == (ch & 3)) {
-      // ---- input transform  V = B2^T d B4  for (wtile tw, channels ch*8 + 2 tk, +1)
-      const float* rp = rbase + ch * CK;
-      f32x2 T[4][6];
+      for (int j = 0; j < 3; ++j) {
+        const int pp = (3 * wave + j) * 16 + n;
+        const int py = gpy[j], px = gpx[j];
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        const float m = (pp < RH * RW && gy >= 0 && gy < H && gx >= 0 && gx < W) ? 1.f : 0.f;   // branch-free: finite * 0
+        const float* ip = img + py * IMG_W + px;
+        float bv[3];
+        bv[0] = ip[toff[0]] * m;
+        bv[1] = ip[toff[1]] * m;
+        bv[2] = (ip[toff[2]] * c2 + a2) * m;
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {            // along the columns: F(4,3)  B4^T
-        f32x2 d[6];
+        for (int cbk = 0; cbk < 4; ++cbk) {
+          f32x4 d = zero4;
 #pragma unroll
-        for (int bb = 0; bb < 6; ++bb) d[bb] = *reinterpret_cast<const f32x2*>(rp + (a * RW + bb) * RS);
-        const f32x2 e42 = d[4] - 4.f * d[2], e31 = d[3] - 4.f * d[1];
-        const f32x2 f42 = d[4] - d[2], f31 = d[3] - d[1];
-        T[a][0] = 4.f * d[0] - 5.f * d[2] + d[4];
-        T[a][1] = e42 + e31;
-        T[a][2] = e42 - e31;
-        T[a][3] = f42 + 2.f * f31;
-        T[a][4] = f42 - 2.f * f31;
-        T[a][5] = 4.f * d[1] - 5.f * d[3] + d[5];
+          for (int ks = 0; ks < 3; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cbk][ks], bv[ks], d, 0, 0, 0);
+          d = __builtin_elementwise_max(d, zero4);
+          float* o = raw + pp * RS + cbk * 16 + 4 * kq;
+          *reinterpret_cast<f32x2*>(o) = (f32x2){d[0], d[1]};
+          *reinterpret_cast<f32x2*>(o + 2) = (f32x2){d[2], d[3]};
+        }
       }
+    }
+
+    f32x4 acc[24];
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {            // down the rows: F(2,3)  B2^T ; position p = j*4 + i
-        const f32x2 o0 = T[0][j] - T[2][j], o1 = T[1][j] + T[2][j];
-        const f32x2 o2 = T[2][j] - T[1][j], o3 = T[1][j] - T[3][j];
-        *reinterpret_cast<f32x4*>(vwr + (2 * j) * QSL * 4) = (f32x4){o0.x, o0.y, o1.x, o1.y};
-        *reinterpret_cast<f32x4*>(vwr + (2 * j + 1) * QSL * 4) = (f32x4){o2.x, o2.y, o3.x, o3.y};
+    for (int q = 0; q < 24; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    IMX_TS(4)
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+      // ---- this chunk's B operands: 12 buffer_load_dwordx4 (SGPR descriptor + offset), landing while the wave waits at
+      //      the barriers and the transform runs
+      f32x4 bf[NQ];
+      {
+        const int uoff = __builtin_amdgcn_readfirstlane(ch * (UCH * 4));
+#pragma unroll
+        for (int g = 0; g < NQ; ++g)
+          bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
+      }
+      __syncthreads();               // previous chunk's MFMA phase is done with V (first chunk: conv1a patch complete)
+      IMX_TS(0)
+      {
+        // ---- input transform  V = B2^T d B4, split over the four waves by transformed ROW i = wave: every wave handles
+        //      all 64 (wtile, channel pair) items but only the two patch rows its row of B2^T touches -- 6 ds_read_b64
+        //      pairs, 6 + 12 packed operations, 6 ds_write_b64 (its half of the quads (j, i>>1)); one wave doing whole
+        //      items (24 reads, 72 operations, 12 writes) while three wait cost 2.4k cycles per chunk instead of 0.7k
+        const float* pa = rpa + ch * CK;
+        const float* pb = rpb + ch * CK;
+        f32x2 o[6];
+#pragma unroll
+        for (int bb = 0; bb < 6; ++bb)           // down the rows: F(2,3)  B2^T, row i
+          o[bb] = __builtin_elementwise_fma(sg2, *reinterpret_cast<const f32x2*>(pb + bb * RS), *reinterpret_cast<const f32x2*>(pa + bb * RS));
+        const f32x2 e42 = o[4] - 4.f * o[2], e31 = o[3] - 4.f * o[1];   // along the columns: F(4,3)  B4^T
+        const f32x2 f42 = o[4] - o[2], f31 = o[3] - o[1];
+        f32x2 T[6];
+        T[0] = 4.f * o[0] - 5.f * o[2] + o[4];
+        T[1] = e42 + e31;
+        T[2] = e42 - e31;
+        T[3] = f42 + 2.f * f31;
+        T[4] = f42 - 2.f * f31;
+        T[5] = 4.f * o[1] - 5.f * o[3] + o[5];
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) *reinterpret_cast<f32x2*>(vwr + (2 * jj) * QSL * 4) = T[jj];   // position p = j*4 + i
+      }
+      IMX_TS(1)
+      __syncthreads();
+      IMX_TS(2)
+      // ---- 24 positions x 2 k-steps of v_mfma_f32_16x16x4_f32 in 12 quads: A operands one ds_read_b128 per quad, one
+      //      quad ahead; B operands already in registers
+      {
+        f32x4 af[2];
+        af[0] = *reinterpret_cast<const f32x4*>(vrd);
+#pragma unroll
+        for (int g = 0; g < NQ; ++g) {
+          const int cur = g & 1, nxt = cur ^ 1;
+          if (g + 1 < NQ) af[nxt] = *reinterpret_cast<const f32x4*>(vrd + (g + 1) * QSL * 4);
+          acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][0], bf[g][0], acc[2 * g], 0, 0, 0);
+          acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][2], bf[g][2], acc[2 * g + 1], 0, 0, 0);
+          acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][1], bf[g][1], acc[2 * g], 0, 0, 0);
+          acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][3], bf[g][3], acc[2 * g + 1], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read (next quad's A operands)
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      IMX_TS(3)
+    }
+
+    // ---- output transform Y = A2^T M A4, 2x2 max-pool, bias, ReLU (max-pool commutes with both), LDS-staged float4 stores.
+    //      acc[j*4 + i][r]: wtile (row lane>>4, column r), channel cb*16 + (lane&15).
+    float* Ot = smem;
+    __syncthreads();          // every wave is done with V (the staging tile aliases it)
+    {
+      const int col = cb * 16 + (lane & 15);
+      const float bs = p.bias[col];
+      f32x4 s0[6], s1[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        s0[j] = acc[j * 4 + 0] + acc[j * 4 + 1] + acc[j * 4 + 2];
+        s1[j] = acc[j * 4 + 1] - acc[j * 4 + 2] - acc[j * 4 + 3];
+      }
+      f32x4 pooled[2];
+      {
+        f32x4 y[2][4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const f32x4* m = r ? s1 : s0;
+          const f32x4 a12 = m[1] + m[2], b12 = m[1] - m[2], c34 = m[3] + m[4], d34 = m[3] - m[4];
+          y[r][0] = m[0] + a12 + c34;
+          y[r][1] = b12 + 2.f * d34;
+          y[r][2] = a12 + 4.f * c34;
+          y[r][3] = b12 + 8.f * d34 + m[5];
+        }
+        pooled[0] = __builtin_elementwise_max(__builtin_elementwise_max(y[0][0], y[0][1]), __builtin_elementwise_max(y[1][0], y[1][1]));
+        pooled[1] = __builtin_elementwise_max(__builtin_elementwise_max(y[0][2], y[0][3]), __builtin_elementwise_max(y[1][2], y[1][3]));
+      }
+      const f32x4 bs4 = {bs, bs, bs, bs}, zero4 = {0.f, 0.f, 0.f, 0.f};
+      const int wr = lane >> 4;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const f32x4 v = __builtin_elementwise_max(pooled[hh] + bs4, zero4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ot[(wr * (OW / 2) + 2 * r + hh) * OS + col] = v[r];
       }
     }
     __syncthreads();
-    // ---- 24 positions x 2 k-steps of v_mfma_f32_16x16x4_f32 in 12 quads: A operands one ds_read_b128 per quad, one
-    //      quad ahead; B operands already in registers
-    {
-      f32x4 af[2];
-      af[0] = *reinterpret_cast<const f32x4*>(vrd);
+    const int Ho = H >> 1, Wo = W >> 1;
 #pragma unroll
-      for (int g = 0; g < NQ; ++g) {
-        const int cur = g & 1, nxt = cur ^ 1;
-        if (g + 1 < NQ) af[nxt] = *reinterpret_cast<const f32x4*>(vrd + (g + 1) * QSL * 4);
-        acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][0], bf[g][0], acc[2 * g], 0, 0, 0);
-        acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][2], bf[g][2], acc[2 * g + 1], 0, 0, 0);
-        acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][1], bf[g][1], acc[2 * g], 0, 0, 0);
-        acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][3], bf[g][3], acc[2 * g + 1], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read (next quad's A operands)
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+    for (int it = 0; it < (OH / 2) * (OW / 2) * (NT / 4) / 256; ++it) {
+      const int e = tid + it * 256;
+      const int pix = e / (NT / 4), v4 = e % (NT / 4);
+      const int oy = (y0 >> 1) + pix / (OW / 2), ox = (x0 >> 1) + pix % (OW / 2);
+      if (oy < Ho && ox < Wo)
+        *reinterpret_cast<float4*>(p.out + ((size_t)(bcur * Ho + oy) * Wo + ox) * Cout + 4 * v4) =
+            *reinterpret_cast<const float4*>(Ot + pix * OS + 4 * v4);
     }
+    IMX_TS(5)
+    ++ntile_done;
   }
-
-  // ---- output transform Y = A2^T M A4, 2x2 max-pool, bias, ReLU (max-pool commutes with both), LDS-staged float4 stores.
-  //      acc[j*4 + i][r]: wtile (row lane>>4, column r), channel cb*16 + (lane&15).
-  float* Ot = smem;
-  __syncthreads();          // every wave is done with V (the staging tile aliases it)
-  {
-    const int col = cb * 16 + (lane & 15);
-    const float bs = p.bias[col];
-    f32x4 s0[6], s1[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      s0[j] = acc[j * 4 + 0] + acc[j * 4 + 1] + acc[j * 4 + 2];
-      s1[j] = acc[j * 4 + 1] - acc[j * 4 + 2] - acc[j * 4 + 3];
+#undef IMX_TS
+  if constexpr (TRACE) {
+    if (lane == 0 && blockIdx.x < 1024) {
+      unsigned* o = trace + (blockIdx.x * 4 + wave) * 8;
+      for (int i = 0; i < 6; ++i) o[i] = tph[i];
+      o[6] = (unsigned)ntile_done;
     }
-    f32x4 pooled[2];
-    {
-      f32x4 y[2][4];
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const f32x4* m = r ? s1 : s0;
-        const f32x4 a12 = m[1] + m[2], b12 = m[1] - m[2], c34 = m[3] + m[4], d34 = m[3] - m[4];
-        y[r][0] = m[0] + a12 + c34;
-        y[r][1] = b12 + 2.f * d34;
-        y[r][2] = a12 + 4.f * c34;
-        y[r][3] = b12 + 8.f * d34 + m[5];
-      }
-      pooled[0] = __builtin_elementwise_max(__builtin_elementwise_max(y[0][0], y[0][1]), __builtin_elementwise_max(y[1][0], y[1][1]));
-      pooled[1] = __builtin_elementwise_max(__builtin_elementwise_max(y[0][2], y[0][3]), __builtin_elementwise_max(y[1][2], y[1][3]));
-    }
-    const f32x4 bs4 = {bs, bs, bs, bs}, zero4 = {0.f, 0.f, 0.f, 0.f};
-    const int wr = lane >> 4;
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const f32x4 v = __builtin_elementwise_max(pooled[hh] + bs4, zero4);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Ot[(wr * (OW / 2) + 2 * r + hh) * OS + col] = v[r];
-    }
-  }
-  __syncthreads();
-  const int Ho = H >> 1, Wo = W >> 1;
-#pragma unroll
-  for (int it = 0; it < (OH / 2) * (OW / 2) * (NT / 4) / 256; ++it) {
-    const int e = tid + it * 256;
-    const int pix = e / (NT / 4), v4 = e % (NT / 4);
-    const int oy = (y0 >> 1) + pix / (OW / 2), ox = (x0 >> 1) + pix % (OW / 2);
-    if (oy < Ho && ox < Wo)
-      *reinterpret_cast<float4*>(p.out + ((size_t)(b * Ho + oy) * Wo + ox) * Cout + 4 * v4) =
-          *reinterpret_cast<const float4*>(Ot + pix * OS + 4 * v4);
   }
 }
 }  // namespace
 
 hipError_t launch_conv1ab_wino24(const ConvArgs& a, hipStream_t s) {
   if (!a.first || !a.pool || a.Cin != 64 || a.Cout != 64 || !a.wu24) return hipErrorInvalidValue;
-  const int tiles_x = (a.W + OW - 1) / OW, tiles_y = (a.H + OH - 1) / OH;
+  const int tiles_x = (a.W + OW - 1) / OW, tiles_y = (a.H + OH - 1) / OH, ntiles = tiles_x * tiles_y * a.B;
   const size_t lds = (size_t)(VSZ + RAWSZ + IMG_H * IMG_W) * sizeof(float);
-  hipLaunchKernelGGL(conv1ab_wino24, dim3((unsigned)(tiles_x * tiles_y * a.B)), dim3(256), lds, s, a, tiles_x, tiles_y);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    ncu = prop.multiProcessorCount;
+  }
+  const dim3 grid((unsigned)(ntiles < 2 * ncu ? ntiles : 2 * ncu));     // persistent: two workgroups per CU
+  if (getenv("IMX_WINO_TRACE")) {      // bring-up instrumentation: per-phase cycle counts per wave, averaged over tiles
+    static unsigned* dbuf = nullptr;
+    constexpr int NREC = 1024 * 4 * 8;
+    if (!dbuf) (void)hipMalloc(&dbuf, NREC * sizeof(unsigned));
+    (void)hipMemsetAsync(dbuf, 0, NREC * sizeof(unsigned), s);
+    hipLaunchKernelGGL(conv1ab_wino24<true>, grid, dim3(256), lds, s, a, tiles_x, tiles_y, ntiles, dbuf);
+    (void)hipStreamSynchronize(s);
+    static unsigned host[NREC];
+    (void)hipMemcpy(host, dbuf, sizeof(host), hipMemcpyDeviceToHost);
+    const int n = grid.x < 1024 ? (int)grid.x : 1024;
+    for (int w = 0; w < 4; ++w) {
+      double sum[6] = {0}, nt = 0;
+      for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < 6; ++j) sum[j] += host[(i * 4 + w) * 8 + j];
+        nt += host[(i * 4 + w) * 8 + 6];
+      }
+      fprintf(stderr, "[wino24 trace] wave %d | per tile: prologue %.0f  chunks 8 x (barrier1 %.0f  transform %.0f  barrier2 %.0f  mfma %.0f)  "
+                      "epilogue %.0f cycles  (%.0f tiles per workgroup)\n", w, sum[4] / nt, sum[0] / nt / 8, sum[1] / nt / 8, sum[2] / nt / 8,
+              sum[3] / nt / 8, sum[5] / nt, nt / n);
+    }
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(conv1ab_wino24<false>, grid, dim3(256), lds, s, a, tiles_x, tiles_y, ntiles, (unsigned*)nullptr);
   return hipGetLastError();
 }
 
