@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
   }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* V = smem;
-  float* raw = V + VSZ;
+  float* raw = V + 2 * VSZ;             // V is double buffered: chunk c+1 is transformed inside chunk c's MFMA phase
   float* img = raw + RAWSZ;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -103,8 +103,11 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
   const int ipy = tid / IMG_W - 2, ipx = tid % IMG_W - 2;
   auto fetch_px = [&](int ftx, int fty, int fb, bool live) -> float {
     const int gy = fty * OH + ipy, gx = ftx * OW + ipx;
+    const bool ok = live && tid < IMG_H * IMG_W && gy >= 0 && gy < H && gx >= 0 && gx < W;
     const float* im = (fb < p.split) ? p.in + (size_t)fb * H * W : p.in2 + (size_t)(fb - p.split) * H * W;
-    return (live && tid < IMG_H * IMG_W && gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.f;
+    const float* src = ok ? im + (size_t)gy * W + gx : p.in;   // unconditional load from a clamped address (past the last tile
+    const float v = *src;                                      // `fb` is out of range): keeps the vmcnt bookkeeping exact
+    return ok ? v : 0.f;
   };
   float pre = fetch_px(tx, ty, b, t_begin < t_end);
   // conv1a gather geometry of this lane's three pixel blocks (tile independent)
@@ -117,6 +120,13 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
     gpx[j] = pc % RW;
   }
   int ntile_done = 0;
+  const float bs = p.bias[cb * 16 + (lane & 15)];      // conv1b bias of this lane's output channel
+  f32x4 bf[NQ];                  // B operands of the coming chunk (chunk 0 here; refilled in place from then on)
+#pragma unroll
+  for (int g = 0; g < NQ; ++g) bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, g * 4096, 0));
+  // drain every load once here: the compiler's waitcnt bookkeeping at the chunk-loop header then sees only the loop's own
+  // in-order refills (vmcnt(11) per quad) instead of merging in this preamble's arbitrary order (it chose vmcnt(1))
+  __builtin_amdgcn_s_waitcnt(0x0F70);
 
   for (int t = t_begin; t < t_end; ++t) {
     if constexpr (TRACE) tprev = __builtin_readcyclecounter();
@@ -164,60 +174,78 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
     for (int q = 0; q < 24; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     IMX_TS(4)
 
+    // ---- transform of chunk 0 (the later ones ride inside the MFMA phases)
+    __syncthreads();               // conv1a patch complete
+    IMX_TS(0)
+    {
+      f32x2 va[6], vb[6];
+#pragma unroll
+      for (int bb = 0; bb < 6; ++bb) { va[bb] = *reinterpret_cast<const f32x2*>(rpa + bb * RS); vb[bb] = *reinterpret_cast<const f32x2*>(rpb + bb * RS); }
+      f32x2 o[6];
+#pragma unroll
+      for (int bb = 0; bb < 6; ++bb) o[bb] = __builtin_elementwise_fma(sg2, vb[bb], va[bb]);
+      const f32x2 e42 = o[4] - 4.f * o[2], e31 = o[3] - 4.f * o[1], f42 = o[4] - o[2], f31 = o[3] - o[1];
+      f32x2 T[6];
+      T[0] = 4.f * o[0] - 5.f * o[2] + o[4];
+      T[1] = e42 + e31; T[2] = e42 - e31; T[3] = f42 + 2.f * f31; T[4] = f42 - 2.f * f31;
+      T[5] = 4.f * o[1] - 5.f * o[3] + o[5];
+#pragma unroll
+      for (int jj = 0; jj < 6; ++jj) *reinterpret_cast<f32x2*>(vwr + (2 * jj) * QSL * 4) = T[jj];
+    }
+    IMX_TS(1)
+
+#pragma unroll 1
     for (int ch = 0; ch < nchunk; ++ch) {
-      // ---- this chunk's B operands: 12 buffer_load_dwordx4 (SGPR descriptor + offset), landing while the wave waits at
-      //      the barriers and the transform runs
-      f32x4 bf[NQ];
-      {
-        const int uoff = __builtin_amdgcn_readfirstlane(ch * (UCH * 4));
-#pragma unroll
-        for (int g = 0; g < NQ; ++g)
-          bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
-      }
-      __syncthreads();               // previous chunk's MFMA phase is done with V (first chunk: conv1a patch complete)
-      IMX_TS(0)
-      {
-        // ---- input transform  V = B2^T d B4, split over the four waves by transformed ROW i = wave: every wave handles
-        //      all 64 (wtile, channel pair) items but only the two patch rows its row of B2^T touches -- 6 ds_read_b64
-        //      pairs, 6 + 12 packed operations, 6 ds_write_b64 (its half of the quads (j, i>>1)); one wave doing whole
-        //      items (24 reads, 72 operations, 12 writes) while three wait cost 2.4k cycles per chunk instead of 0.7k
-        const float* pa = rpa + ch * CK;
-        const float* pb = rpb + ch * CK;
-        f32x2 o[6];
-#pragma unroll
-        for (int bb = 0; bb < 6; ++bb)           // down the rows: F(2,3)  B2^T, row i
-          o[bb] = __builtin_elementwise_fma(sg2, *reinterpret_cast<const f32x2*>(pb + bb * RS), *reinterpret_cast<const f32x2*>(pa + bb * RS));
-        const f32x2 e42 = o[4] - 4.f * o[2], e31 = o[3] - 4.f * o[1];   // along the columns: F(4,3)  B4^T
-        const f32x2 f42 = o[4] - o[2], f31 = o[3] - o[1];
-        f32x2 T[6];
-        T[0] = 4.f * o[0] - 5.f * o[2] + o[4];
-        T[1] = e42 + e31;
-        T[2] = e42 - e31;
-        T[3] = f42 + 2.f * f31;
-        T[4] = f42 - 2.f * f31;
-        T[5] = 4.f * o[1] - 5.f * o[3] + o[5];
-#pragma unroll
-        for (int jj = 0; jj < 6; ++jj) *reinterpret_cast<f32x2*>(vwr + (2 * jj) * QSL * 4) = T[jj];   // position p = j*4 + i
-      }
-      IMX_TS(1)
-      __syncthreads();
+      __syncthreads();               // V[ch & 1] complete; the other buffer's readers (chunk ch-1) are done
       IMX_TS(2)
-      // ---- 24 positions x 2 k-steps of v_mfma_f32_16x16x4_f32 in 12 quads: A operands one ds_read_b128 per quad, one
-      //      quad ahead; B operands already in registers
+      // ---- 24 positions x 2 k-steps of v_mfma_f32_16x16x4_f32 in 12 quads (A operands: one ds_read_b128 per quad, one
+      //      quad ahead; B operands: registers, each quad's four refilled IN PLACE with the next chunk's right behind the
+      //      MFMAs that consumed them -- chunk 7 fetches chunk 0 for the next tile: U is tile independent).
+      //      The NEXT chunk's input transform rides along in the same instruction stream:  V = B2^T d B4 split over the
+      //      four waves by transformed ROW i = wave (every wave handles all 64 (wtile, channel pair) items but only the two
+      //      patch rows its row of B2^T touches: 12 ds_read_b64, 6 + 12 packed operations, 6 ds_write_b64), issued as the
+      //      LDS reads at quad 0, three dense batches of six packed operations at quads 3 / 5 / 7 and the writes at quad 9
+      //      (a VALU batch costs ~11 + 4.5 n cycles of matrix-pipe time, one instruction alone ~15, and a separate phase
+      //      beside the other workgroup's MFMAs ~29 per instruction: tools/ubench/mfma_valu.hip and the cycle trace).
+      //      After chunk 7 the transform reads channels 64.. of the padded patch and writes the idle V buffer: harmless.
       {
+        const float* vr = vrd + (ch & 1) * VSZ;
+        float* vw = vwr + ((ch + 1) & 1) * VSZ;
+        const float* pa = rpa + (ch + 1) * CK;
+        const float* pb = rpb + (ch + 1) * CK;
+        const int uoff = __builtin_amdgcn_readfirstlane(((ch + 1) & (nchunk - 1)) * (UCH * 4));
+        f32x2 va[6], vb[6], o[6], T[6], e42, e31, f42, f31;
         f32x4 af[2];
-        af[0] = *reinterpret_cast<const f32x4*>(vrd);
+        af[0] = *reinterpret_cast<const f32x4*>(vr);
 #pragma unroll
         for (int g = 0; g < NQ; ++g) {
           const int cur = g & 1, nxt = cur ^ 1;
-          if (g + 1 < NQ) af[nxt] = *reinterpret_cast<const f32x4*>(vrd + (g + 1) * QSL * 4);
+          if (g + 1 < NQ) af[nxt] = *reinterpret_cast<const f32x4*>(vr + (g + 1) * QSL * 4);
           acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][0], bf[g][0], acc[2 * g], 0, 0, 0);
           acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][2], bf[g][2], acc[2 * g + 1], 0, 0, 0);
           acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][1], bf[g][1], acc[2 * g], 0, 0, 0);
           acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][3], bf[g][3], acc[2 * g + 1], 0, 0, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read (next quad's A operands)
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
+          if (g == 0) {
+#pragma unroll
+            for (int bb = 0; bb < 6; ++bb) { va[bb] = *reinterpret_cast<const f32x2*>(pa + bb * RS); vb[bb] = *reinterpret_cast<const f32x2*>(pb + bb * RS); }
+          }
+          if (g == 3) {
+#pragma unroll
+            for (int bb = 0; bb < 6; ++bb) o[bb] = __builtin_elementwise_fma(sg2, vb[bb], va[bb]);   // down the rows: F(2,3), row i
+          }
+          if (g == 5) {                                                                          // along the columns: F(4,3)
+            e42 = o[4] - 4.f * o[2]; e31 = o[3] - 4.f * o[1]; f42 = o[4] - o[2]; f31 = o[3] - o[1];
+            T[0] = 4.f * o[0] - 5.f * o[2] + o[4];
+          }
+          if (g == 7) {
+            T[1] = e42 + e31; T[2] = e42 - e31; T[3] = f42 + 2.f * f31; T[4] = f42 - 2.f * f31;
+            T[5] = 4.f * o[1] - 5.f * o[3] + o[5];
+          }
+          if (g == 9) {
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) *reinterpret_cast<f32x2*>(vw + (2 * jj) * QSL * 4) = T[jj];   // position p = j*4 + i
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -230,7 +258,6 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
     __syncthreads();          // every wave is done with V (the staging tile aliases it)
     {
       const int col = cb * 16 + (lane & 15);
-      const float bs = p.bias[col];
       f32x4 s0[6], s1[6];
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
@@ -289,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
 hipError_t launch_conv1ab_wino24(const ConvArgs& a, hipStream_t s) {
   if (!a.first || !a.pool || a.Cin != 64 || a.Cout != 64 || !a.wu24) return hipErrorInvalidValue;
   const int tiles_x = (a.W + OW - 1) / OW, tiles_y = (a.H + OH - 1) / OH, ntiles = tiles_x * tiles_y * a.B;
-  const size_t lds = (size_t)(VSZ + RAWSZ + IMG_H * IMG_W) * sizeof(float);
+  const size_t lds = (size_t)(2 * VSZ + RAWSZ + IMG_H * IMG_W) * sizeof(float);
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
