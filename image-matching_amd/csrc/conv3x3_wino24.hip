@@ -1,0 +1,335 @@
+// conv3x3_wino24.hip — 3x3 / pad 1 convolution + folded BatchNorm + ReLU (+ MaxPool2d(2)) of superpoint/models/unet_parts.py:10-48
+// and superpoint_test.py:113-123 as Winograd F(2x4, 3x3) on the fp32 matrix cores, for every layer after the fused first one
+// (that one is conv1ab_wino24.hip; the arithmetic, the operand-quad layout and the in-stream transform are the same):
+//   Y = A2^T [ (G2 g G4^T) (.) (B2^T d B4) ] A4   per 2-row x 4-column output tile ("wtile") and 4x6 input patch d:
+//   24 multiplies per 8 outputs (3x fewer than direct, 1.33x fewer than F(2x2,3x3)), summed over input channels as 24
+//   independent GEMMs  M_p[wtile][co] = sum_ci V_p[wtile][ci] U_p[ci][co]  on v_mfma_f32_16x16x4_f32.
+//
+// Persistent: 2 workgroups per CU walk work items (8x16-pixel tile, 64-channel output block), item i -> workgroup i % grid, so
+// that at any moment the chip works on neighbouring tiles and every output block of a tile (input patches and the current U
+// panels stay in L2).  Workgroup = 4 waves; wave = 16 output channels x the 16 wtiles x 24 positions = 24 accumulators of 4
+// VGPRs; the D layout of the 16x16 MFMA gives a lane one channel and one row of four wtiles with all 24 positions, so the
+// output transform, bias, ReLU and the 2x2 max-pool are in-lane.
+// The K loop is ONE continuous stream of 8-channel chunks across items, one barrier per chunk.  During the MFMA phase of
+// stream position s (48 MFMAs per wave, A operands one ds_read_b128 per quad of four, B operands registers refilled in place
+// with position s+1's U panel right behind the MFMAs that consumed them), the same instruction stream carries:
+//   * the input transform of position s+1 (raw[(s+1)&1] -> V[(s+1)&1]), split over the four waves by transformed row, as LDS
+//     reads + three dense batches of six packed operations + LDS writes;
+//   * the raw 10x18x8 patch of position s+2 going from registers to raw[s&1] (it was fetched during phase s-1);
+//   * the fetch of position s+3's patch: two buffer_load_dwordx4 per thread through a per-image descriptor; pixels outside
+//     the image get an out-of-range offset and come back as the zero padding.
+// (Why in-stream: beside a saturated MFMA stream another wave's VALU instruction issues once per ~41 cycles; inside the MFMA
+// wave a batch of n costs ~11 + 4.5 n cycles of matrix-pipe time -- tools/ubench/mfma_valu.hip.)
+// LDS: V 2 x 13.5 KB, raw 2 x 7.5 KB, output staging tile 8.5 KB (pooled) / 36 KB (full resolution): 50.5 / 78 KB.
+#include "imx_kernels.h"
+
+namespace imx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+constexpr int OH = 8, OW = 16;                 // output pixels per item (4 x 4 wtiles of 2 x 4)
+constexpr int RH = OH + 2, RW = OW + 2;        // input patch (pad-1 halo)
+constexpr int RSC = 10;                        // raw chunk: pixel stride (8 channels + 2: wtile columns 4 px apart land 8 banks apart)
+constexpr int RAWC = 192 * RSC;                // 180 pixels + pad
+constexpr int KS = 18, QSL = 4 * KS, NQ = 12;  // V: [12 quads][4 k][18 slots][4]
+constexpr int VSZ = NQ * QSL * 4;              // 3456
+constexpr int UCH = NQ * 4 * 64 * 4;           // 12288 floats of U per (64 co, 8 ci)
+constexpr int CK = 8, NT = 64, OS = NT + 4;
+constexpr int OWP = OW + 1;                    // full-resolution staging tile: row pitch 17 pixels (wtile rows 8 banks apart)
+constexpr unsigned OOB = 0x7ffffff0u;          // byte offset beyond any image: buffer loads return 0
+
+struct Item { int b, y0, x0, cob; };
+
+template <bool POOL, bool RELU>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x, int tiles_y, int nitems) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* V = smem;                  // [2][VSZ]
+  float* raw = V + 2 * VSZ;         // [2][RAWC]
+  float* Ot = raw + 2 * RAWC;       // output staging tile
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cb = wave;
+  const int H = p.H, W = p.W, Cin = p.Cin, Cout = p.Cout;
+  const int nchunk = Cin / CK, ncob = Cout / NT;
+  const int grid = (int)gridDim.x;
+  if ((int)blockIdx.x >= nitems) return;
+  const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.wu24, 0, ncob * nchunk * UCH * 4, 0x00020000);
+  const int voff = (cb * 64 + lane) * 16;
+  const int img_bytes = H * W * Cin * 4;
+
+  // ---- per-lane constants of the input transform: lane = (channel pair tk, wtile tw); transformed row i = wave:
+  //      i0 = d0 - d2, i1 = d1 + d2, i2 = d2 - d1, i3 = d1 - d3  (rows of B2^T)
+  const int tk = lane & 3, tw = lane >> 2, twr = tw >> 2, twc = tw & 3;
+  const int ra = wave == 0 ? 0 : wave == 2 ? 2 : 1, rb = wave == 0 ? 2 : wave == 1 ? 2 : wave == 2 ? 1 : 3;
+  const float sg = wave == 1 ? 1.f : -1.f;
+  const f32x2 sg2 = {sg, sg};
+  const float* rpa = raw + ((2 * twr + ra) * RW + 4 * twc) * RSC + 2 * tk;
+  const float* rpb = raw + ((2 * twr + rb) * RW + 4 * twc) * RSC + 2 * tk;
+  float* vwr = V + (tk * KS + tw) * 4 + (wave >> 1) * QSL * 4 + (wave & 1) * 2;
+  int aoff = ((lane >> 4) * KS + (lane & 15)) * 4;
+  asm volatile("" : "+v"(aoff));               // opaque: the 12 quad reads are immediate offsets from one base
+  const float* vrd = V + aoff;
+
+  // ---- loader: thread -> two (pixel, channel half) float4 of the 10x18x8 patch (360 of them; threads >= 104 repeat their
+  //      first one: same source, same destination)
+  int lpy[2], lpx[2], ldst[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = (k == 1 && tid + 256 < RH * RW * 2) ? tid + 256 : tid;
+    const int px = e >> 1, half = e & 1;
+    lpy[k] = px / RW - 1;
+    lpx[k] = px % RW - 1;
+    ldst[k] = px * RSC + half * 4;
+  }
+  const int lhalf = tid & 1;          // both of a thread's entries have its parity
+  auto decode = [&](int it) -> Item {
+    Item r;
+    r.cob = it % ncob;
+    const int tile = it / ncob;
+    r.x0 = (tile % tiles_x) * OW;
+    r.y0 = ((tile / tiles_x) % tiles_y) * OH;
+    r.b = tile / (tiles_x * tiles_y);
+    return r;
+  };
+  Item cur = decode((int)blockIdx.x), nxt = cur;
+  int item_c = (int)blockIdx.x;
+  // loader cursor
+  int litem = item_c, lchunk = 0;
+  __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
+  unsigned goff[2];
+  auto loader_item = [&](const Item& it, bool live) {
+    lrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)(live ? it.b : 0) * H * W * Cin), 0, live ? img_bytes : 0, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int gy = it.y0 + lpy[k], gx = it.x0 + lpx[k];
+      goff[k] = (live && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (unsigned)(((gy * W + gx) * Cin + lhalf * 4) * 4) : OOB;
+    }
+  };
+  f32x4 r0, r1;
+  auto issue_load = [&]() {
+    const int so = __builtin_amdgcn_readfirstlane(lchunk * (CK * 4));
+    r0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)goff[0], so, 0));
+    r1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)goff[1], so, 0));
+    if (++lchunk == nchunk) {        // the loader moves on to this workgroup's next item (at most one item ahead of the MFMAs)
+      lchunk = 0;
+      litem += grid;
+      const bool live = litem < nitems;
+      if (live) nxt = decode(litem);
+      loader_item(nxt, live);
+    }
+  };
+  auto store_raw = [&](int buf) {
+    float* d0 = raw + buf * RAWC + ldst[0];
+    float* d1 = raw + buf * RAWC + ldst[1];
+    *reinterpret_cast<f32x2*>(d0) = (f32x2){r0[0], r0[1]};
+    *reinterpret_cast<f32x2*>(d0 + 2) = (f32x2){r0[2], r0[3]};
+    *reinterpret_cast<f32x2*>(d1) = (f32x2){r1[0], r1[1]};
+    *reinterpret_cast<f32x2*>(d1 + 2) = (f32x2){r1[2], r1[3]};
+  };
+
+  // ---- pipeline fill: positions 0 and 1 into raw[0] / raw[1], position 2 in flight, B panel of position 0, V[0]
+  loader_item(cur, true);
+  issue_load();
+  store_raw(0);
+  issue_load();
+  store_raw(1);
+  issue_load();
+  f32x4 bf[NQ];
+  {
+    const int uoff = __builtin_amdgcn_readfirstlane(cur.cob * nchunk * (UCH * 4));
+#pragma unroll
+    for (int g = 0; g < NQ; ++g) bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
+  }
+  // drain every load once: the waitcnt bookkeeping at the stream-loop header then sees only the loop's own in-order loads
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  {
+    f32x2 o[6];
+#pragma unroll
+    for (int bb = 0; bb < 6; ++bb)
+      o[bb] = __builtin_elementwise_fma(sg2, *reinterpret_cast<const f32x2*>(rpb + bb * RSC), *reinterpret_cast<const f32x2*>(rpa + bb * RSC));
+    const f32x2 e42 = o[4] - 4.f * o[2], e31 = o[3] - 4.f * o[1], f42 = o[4] - o[2], f31 = o[3] - o[1];
+    f32x2 T[6];
+    T[0] = 4.f * o[0] - 5.f * o[2] + o[4];
+    T[1] = e42 + e31; T[2] = e42 - e31; T[3] = f42 + 2.f * f31; T[4] = f42 - 2.f * f31;
+    T[5] = 4.f * o[1] - 5.f * o[3] + o[5];
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) *reinterpret_cast<f32x2*>(vwr + (2 * jj) * QSL * 4) = T[jj];
+  }
+
+  f32x4 acc[24];
+  int chunk = 0, par = 0;          // par = stream position & 1
+  float bs = 0.f;                  // bias of this lane's output channel (current item)
+
+#pragma unroll 1
+  for (;;) {
+    __syncthreads();               // V[par] and raw[par ^ 1] (position s+1) complete; the buffers written below are free
+    {
+      // B panel of position s+1: next chunk of this item, or chunk 0 of the next item's output block
+      const bool last = chunk + 1 == nchunk;
+      const int ncb = last ? nxt.cob : cur.cob, nch = last ? 0 : chunk + 1;
+      const int uoff = __builtin_amdgcn_readfirstlane((ncb * nchunk + nch) * (UCH * 4));
+      bs = p.bias[cur.cob * NT + cb * 16 + (lane & 15)];      // every phase (one dword): an unconditional load keeps the vmcnt
+      const float* vr = vrd + par * VSZ;                       // bookkeeping exact, and the epilogue never waits for it
+      float* vw = vwr + (par ^ 1) * VSZ;
+      const float* pa = rpa + (par ^ 1) * RAWC;
+      const float* pb = rpb + (par ^ 1) * RAWC;
+      f32x2 va[6], vb[6], o[6], T[6], e42, e31, f42, f31;
+      f32x4 af[2];
+      af[0] = *reinterpret_cast<const f32x4*>(vr);
+      const bool first = chunk == 0;
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < NQ; ++g) {
+        const int cu = g & 1, nx = cu ^ 1;
+        if (g + 1 < NQ) af[nx] = *reinterpret_cast<const f32x4*>(vr + (g + 1) * QSL * 4);
+        if (first) {                 // uniform: the item's first chunk starts from literal-zero accumulators
+          acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][0], bf[g][0], zero4, 0, 0, 0);
+          acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][2], bf[g][2], zero4, 0, 0, 0);
+        } else {
+          acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][0], bf[g][0], acc[2 * g], 0, 0, 0);
+          acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][2], bf[g][2], acc[2 * g + 1], 0, 0, 0);
+        }
+        acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][1], bf[g][1], acc[2 * g], 0, 0, 0);
+        acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][3], bf[g][3], acc[2 * g + 1], 0, 0, 0);
+        bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
+        if (g == 0) {
+#pragma unroll
+          for (int bb = 0; bb < 6; ++bb) { va[bb] = *reinterpret_cast<const f32x2*>(pa + bb * RSC); vb[bb] = *reinterpret_cast<const f32x2*>(pb + bb * RSC); }
+        }
+        if (g == 1) {                // position s+2's patch: registers -> raw[par]; then fetch position s+3
+          store_raw(par);
+          issue_load();
+        }
+        if (g == 3) {
+#pragma unroll
+          for (int bb = 0; bb < 6; ++bb) o[bb] = __builtin_elementwise_fma(sg2, vb[bb], va[bb]);   // down the rows: F(2,3), row i
+        }
+        if (g == 5) {                                                                          // along the columns: F(4,3)
+          e42 = o[4] - 4.f * o[2]; e31 = o[3] - 4.f * o[1]; f42 = o[4] - o[2]; f31 = o[3] - o[1];
+          T[0] = 4.f * o[0] - 5.f * o[2] + o[4];
+        }
+        if (g == 7) {
+          T[1] = e42 + e31; T[2] = e42 - e31; T[3] = f42 + 2.f * f31; T[4] = f42 - 2.f * f31;
+          T[5] = 4.f * o[1] - 5.f * o[3] + o[5];
+        }
+        if (g == 9) {
+#pragma unroll
+          for (int jj = 0; jj < 6; ++jj) *reinterpret_cast<f32x2*>(vw + (2 * jj) * QSL * 4) = T[jj];   // position p = j*4 + i
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    par ^= 1;
+    if (++chunk < nchunk) continue;
+
+    // ---- item done: output transform Y = A2^T M A4, bias, ReLU, (2x2 max-pool), LDS-staged float4 stores.
+    //      acc[j*4 + i][r]: wtile (row lane>>4, column r), channel cob*64 + cb*16 + (lane&15).
+    chunk = 0;
+    {
+      const int col = cb * 16 + (lane & 15);
+      f32x4 s0[6], s1[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        s0[j] = acc[j * 4 + 0] + acc[j * 4 + 1] + acc[j * 4 + 2];
+        s1[j] = acc[j * 4 + 1] - acc[j * 4 + 2] - acc[j * 4 + 3];
+      }
+      f32x4 y[2][4];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const f32x4* m = r ? s1 : s0;
+        const f32x4 a12 = m[1] + m[2], b12 = m[1] - m[2], c34 = m[3] + m[4], d34 = m[3] - m[4];
+        y[r][0] = m[0] + a12 + c34;
+        y[r][1] = b12 + 2.f * d34;
+        y[r][2] = a12 + 4.f * c34;
+        y[r][3] = b12 + 8.f * d34 + m[5];
+      }
+      const f32x4 bs4 = {bs, bs, bs, bs}, zero4 = {0.f, 0.f, 0.f, 0.f};
+      const int wr = lane >> 4;
+      if constexpr (POOL) {
+        f32x4 pooled[2];
+        pooled[0] = __builtin_elementwise_max(__builtin_elementwise_max(y[0][0], y[0][1]), __builtin_elementwise_max(y[1][0], y[1][1]));
+        pooled[1] = __builtin_elementwise_max(__builtin_elementwise_max(y[0][2], y[0][3]), __builtin_elementwise_max(y[1][2], y[1][3]));
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          f32x4 v = pooled[hh] + bs4;
+          if (RELU) v = __builtin_elementwise_max(v, zero4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Ot[(wr * (OW / 2) + 2 * r + hh) * OS + col] = v[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            f32x4 v = y[r][x] + bs4;
+            if (RELU) v = __builtin_elementwise_max(v, zero4);
+#pragma unroll
+            for (int wc = 0; wc < 4; ++wc) Ot[((2 * wr + r) * OWP + 4 * wc + x) * OS + col] = v[wc];
+          }
+      }
+    }
+    __syncthreads();
+    if constexpr (POOL) {
+      const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+      for (int it = 0; it < (OH / 2) * (OW / 2) * (NT / 4) / 256; ++it) {
+        const int e = tid + it * 256;
+        const int pix = e / (NT / 4), v4 = e % (NT / 4);
+        const int oy = (cur.y0 >> 1) + pix / (OW / 2), ox = (cur.x0 >> 1) + pix % (OW / 2);
+        if (oy < Ho && ox < Wo)
+          *reinterpret_cast<float4*>(p.out + ((size_t)(cur.b * Ho + oy) * Wo + ox) * Cout + cur.cob * NT + 4 * v4) =
+              *reinterpret_cast<const float4*>(Ot + pix * OS + 4 * v4);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < OH * OW * (NT / 4) / 256; ++it) {
+        const int e = tid + it * 256;
+        const int pix = e / (NT / 4), v4 = e % (NT / 4);
+        const int row = pix / OW, pxx = pix % OW;
+        const int oy = cur.y0 + row, ox = cur.x0 + pxx;
+        if (oy < H && ox < W)
+          *reinterpret_cast<float4*>(p.out + ((size_t)(cur.b * H + oy) * W + ox) * Cout + cur.cob * NT + 4 * v4) =
+              *reinterpret_cast<const float4*>(Ot + (row * OWP + pxx) * OS + 4 * v4);
+      }
+    }
+    item_c += grid;
+    if (item_c >= nitems) break;
+    cur = nxt;
+  }
+}
+
+template <bool POOL, bool RELU>
+hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
+  const int tiles_x = (a.W + OW - 1) / OW, tiles_y = (a.H + OH - 1) / OH;
+  const int nitems = tiles_x * tiles_y * a.B * (a.Cout / NT);
+  const size_t lds = (size_t)(2 * VSZ + 2 * RAWC + (POOL ? (OH / 2) * (OW / 2) * OS : OH * OWP * OS)) * sizeof(float);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    ncu = prop.multiProcessorCount;
+  }
+  auto k = conv3x3_wino24<POOL, RELU>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const dim3 grid((unsigned)(nitems < 2 * ncu ? nitems : 2 * ncu));
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, tiles_x, tiles_y, nitems);
+  return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s) {
+  if (a.first || a.Cin % 32 || a.Cout % NT || !a.wu24) return hipErrorInvalidValue;
+  if ((size_t)a.H * a.W * a.Cin * 4 >= (size_t)OOB) return hipErrorInvalidValue;     // per-image byte offsets are 31-bit
+  if (a.pool) return a.relu ? launch_t<true, true>(a, s) : launch_t<true, false>(a, s);
+  return a.relu ? launch_t<false, true>(a, s) : launch_t<false, false>(a, s);
+}
+
+}  // namespace imx

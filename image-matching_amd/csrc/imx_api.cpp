@@ -91,6 +91,7 @@ struct imx_handle_s {
   int det_B = 0, det_H = 0, det_W = 0, det_Hc = 0, det_Wc = 0, det_Ksel = 0;
   // debug / timing
   bool debug = false, timing = false;
+  bool convn_f24 = true;  // every other 3x3 layer as Winograd F(2x4,3x3) (conv3x3_wino24.hip); IMX_CONVN=f22 keeps the F(2x2,3x3) kernel
   bool conv1_f24 = true;  // fused first layer: conv1b as Winograd F(2x4,3x3) (conv1ab_wino24.hip); IMX_CONV1=f22 keeps the F(2x2,3x3) kernel
   int conv_mode = 4;      // 3x3 conv kernel: 4 auto (conv1a+1b fused: wino, all other layers: wino6), 0 direct (IMX_CONV=direct),
                           // 1 Winograd 16x16x4 (wino), 2 Winograd 32x32x2 pipelined (wino4), 3 persistent producer/consumer (wino6)
@@ -310,21 +311,22 @@ std::vector<float> wino24_transform(const std::vector<float>& w, int cin, int co
   static const double G4[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
   const int nchunk = cin / 8;
-  std::vector<float> u((size_t)nchunk * 12288, 0.f);
+  std::vector<float> u((size_t)(cout / 64) * nchunk * 12288, 0.f);
   for (int co = 0; co < cout; ++co)
     for (int ci = 0; ci < cin; ++ci) {
       double g[3][3];
       for (int ky = 0; ky < 3; ++ky)
         for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((size_t)(ky * 3 + kx) * cin + ci) * cout + co];
       const int chunk = ci / 8, kk = ci % 8, k = kk >> 1, sstep = kk & 1;
-      float* blk = u.data() + (size_t)chunk * 12288;
+      const int cog = co / 64, col = co % 64;
+      float* blk = u.data() + ((size_t)cog * nchunk + chunk) * 12288;
       for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 6; ++j) {
           double acc = 0.0;
           for (int ky = 0; ky < 3; ++ky)
             for (int kx = 0; kx < 3; ++kx) acc += G2[i][ky] * g[ky][kx] * G4[j][kx];
           const int pos = j * 4 + i, quad = pos >> 1, e = (pos & 1) * 2 + sstep;
-          blk[(size_t)(((quad * 4 + (co >> 4)) * 64 + k * 16 + (co & 15)) * 4) + e] = (float)acc;
+          blk[(size_t)(((quad * 4 + (col >> 4)) * 64 + k * 16 + (col & 15)) * 4) + e] = (float)acc;
         }
     }
   return u;
@@ -338,6 +340,7 @@ int make_conv(imx_handle_t h, ConvW& out, const std::map<std::string, HostTensor
   out.wu = upload(h, wino_transform(w, cin, cout));
   out.wu4 = upload(h, wino_transform(w, cin, cout, 1));
   out.wu6 = upload(h, wino_transform(w, cin, cout, 2));
+  out.wu24 = upload(h, wino24_transform(w, cin, cout));
   out.b = upload(h, b);
   out.cin = cin;
   out.cout = cout;
@@ -406,12 +409,6 @@ int finalize_superpoint(imx_handle_t h) {
   const int cin[8] = {1, 64, 64, 64, 64, 128, 128, 128}, cout[8] = {64, 64, 64, 64, 128, 128, 128, 128};
   for (int i = 1; i < 8; ++i)
     if (make_conv(h, h->conv[i - 1], raw, ck[i], bk[i], cin[i], cout[i])) return -1;
-  {   // conv1b again in the F(2x4,3x3) form of the fused first-layer kernel
-    std::vector<float> w((size_t)9 * 64 * 64), b(64);
-    put_conv3(raw, ck[1], bk[1], 64, 64, 64, 0, w, b);
-    h->conv[0].wu24 = upload(h, wino24_transform(w, 64, 64));
-    if (!h->conv[0].wu24) return fail(h, "weight upload failed (conv1b, F(2x4))");
-  }
   // heads: convPa | convDa merged into one 128 -> 512 convolution
   {
     std::vector<float> w((size_t)9 * 128 * 512), b(512);
@@ -421,6 +418,7 @@ int finalize_superpoint(imx_handle_t h) {
     h->conv[7].wu = upload(h, wino_transform(w, 128, 512));
     h->conv[7].wu4 = upload(h, wino_transform(w, 128, 512, 1));
     h->conv[7].wu6 = upload(h, wino_transform(w, 128, 512, 2));
+    h->conv[7].wu24 = upload(h, wino24_transform(w, 128, 512));
     h->conv[7].b = upload(h, b);
     h->conv[7].cin = 128;
     h->conv[7].cout = 512;
@@ -566,7 +564,7 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
     a.in = in; a.in2 = first ? img1 : nullptr; a.split = first ? split : 0;
     a.w = w.w; a.wu = w.wu; a.wu4 = w.wu4; a.wu6 = w.wu6; a.wu24 = w.wu24; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
     a.B = B; a.H = hh; a.W = ww; a.Cin = w.cin; a.Cout = w.cout; a.relu = 1; a.pool = pool ? 1 : 0; a.first = first ? 1 : 0;
-    RUN(name, (h->conv_mode == 4 && a.first && a.pool && h->conv1_f24) ? launch_conv1ab_wino24(a, s) : (h->conv_mode == 3 || (h->conv_mode == 4 && !a.first)) ? launch_conv3x3_wino6(a, s) : h->conv_mode == 2 ? launch_conv3x3_wino4(a, s) : h->conv_mode == 0 ? launch_conv3x3(a, s) : launch_conv3x3_wino(a, s));
+    RUN(name, (h->conv_mode == 4 && a.first && a.pool && h->conv1_f24) ? launch_conv1ab_wino24(a, s) : (h->conv_mode == 4 && !a.first && h->convn_f24) ? launch_conv3x3_wino24(a, s) : (h->conv_mode == 3 || (h->conv_mode == 4 && !a.first)) ? launch_conv3x3_wino6(a, s) : h->conv_mode == 2 ? launch_conv3x3_wino4(a, s) : h->conv_mode == 0 ? launch_conv3x3(a, s) : launch_conv3x3_wino(a, s));
     return 0;
   };
   if (conv("conv1ab_pool", h->conv[0], img0, a1, H, W, true, true)) return -1;
@@ -764,6 +762,7 @@ int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
   h->device = device_id;
   h->cfg = *cfg;
   if (const char* e = getenv("IMX_CONV1")) h->conv1_f24 = std::string(e) != "f22";
+  if (const char* e = getenv("IMX_CONVN")) h->convn_f24 = std::string(e) != "f22";
   if (const char* e = getenv("IMX_CONV")) h->conv_mode = std::string(e) == "direct" ? 0 : std::string(e) == "wino4" ? 2 : std::string(e) == "wino6" ? 3 : std::string(e) == "wino" ? 1 : 4;
   build_expected(h);
   *out = h;

@@ -173,7 +173,7 @@ def test_dense_forward_for_label_export_vs_reference_golden():
     util.assert_close(out["desc"], g["desc"], "desc")
 
 
-@pytest.mark.parametrize("mode", ["direct", "wino", "wino4", "wino6", "wino6-x1", "auto-f22"])
+@pytest.mark.parametrize("mode", ["direct", "wino", "wino4", "wino6", "wino6-x1", "auto-f22", "auto-f22n"])
 def test_every_conv_kernel_variant_vs_reference_golden(mode, monkeypatch):
     """The 3x3-conv layers have four implementations (IMX_CONV, read at imx_create): direct implicit GEMM, Winograd with
     two workgroups per CU, the 32x32x2 variant and the persistent producer/consumer form; the default mixes two of them.
@@ -182,6 +182,8 @@ def test_every_conv_kernel_variant_vs_reference_golden(mode, monkeypatch):
     monkeypatch.setenv("IMX_CONV", mode.split("-")[0])
     if mode.endswith("-f22"):           # default dispatch, but the fused first layer as F(2x2,3x3) (default: F(2x4,3x3))
         monkeypatch.setenv("IMX_CONV1", "f22")
+    if mode.endswith("-f22n"):          # default dispatch, but every later 3x3 layer as F(2x2,3x3) (default: F(2x4,3x3))
+        monkeypatch.setenv("IMX_CONVN", "f22")
     if mode.endswith("-x1"):            # the 8-channels-per-phase form of the persistent kernel (default: 16)
         monkeypatch.setenv("IMX_WINO6_X1", "1")
     for name in ("sp_ragged.npz", "sp_small.npz"):
