@@ -22,6 +22,9 @@
 // wave a batch of n costs ~11 + 4.5 n cycles of matrix-pipe time -- tools/ubench/mfma_valu.hip.)
 // LDS: V 2 x 13.5 KB, raw 2 x 7.5 KB, output staging tile 8.5 KB (pooled) / 36 KB (full resolution): 50.5 / 78 KB.
 #include "imx_kernels.h"
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
 
 namespace imx {
 
@@ -42,8 +45,18 @@ constexpr unsigned OOB = 0x7ffffff0u;          // byte offset beyond any image: 
 
 struct Item { int b, y0, x0, cob; };
 
-template <bool POOL, bool RELU>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x, int tiles_y, int nitems) {
+template <bool POOL, bool RELU, bool TRACE>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x, int tiles_y, int nitems, unsigned* trace) {
+  // TRACE: s_memtime deltas summed over the stream (bring-up instrumentation, IMX_WINO_TRACE=1)
+  unsigned tph[4] = {0, 0, 0, 0};
+  unsigned long long tprev = 0;
+  int nitem_done = 0;
+#define IMX_TS(i_)                                                   \
+  if constexpr (TRACE) {                                             \
+    const unsigned long long now = __builtin_readcyclecounter();     \
+    tph[i_] += (unsigned)(now - tprev);                              \
+    tprev = now;                                                     \
+  }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* V = smem;                  // [2][VSZ]
   float* raw = V + 2 * VSZ;         // [2][RAWC]
@@ -160,12 +173,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
   }
 
   f32x4 acc[24];
+#pragma unroll
+  for (int q = 0; q < 24; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int chunk = 0, par = 0;          // par = stream position & 1
   float bs = 0.f;                  // bias of this lane's output channel (current item)
 
+  if constexpr (TRACE) tprev = __builtin_readcyclecounter();
 #pragma unroll 1
   for (;;) {
     __syncthreads();               // V[par] and raw[par ^ 1] (position s+1) complete; the buffers written below are free
+    IMX_TS(0)
     {
       // B panel of position s+1: next chunk of this item, or chunk 0 of the next item's output block
       const bool last = chunk + 1 == nchunk;
@@ -179,19 +196,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
       f32x2 va[6], vb[6], o[6], T[6], e42, e31, f42, f31;
       f32x4 af[2];
       af[0] = *reinterpret_cast<const f32x4*>(vr);
-      const bool first = chunk == 0;
-      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < NQ; ++g) {
         const int cu = g & 1, nx = cu ^ 1;
         if (g + 1 < NQ) af[nx] = *reinterpret_cast<const f32x4*>(vr + (g + 1) * QSL * 4);
-        if (first) {                 // uniform: the item's first chunk starts from literal-zero accumulators
-          acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][0], bf[g][0], zero4, 0, 0, 0);
-          acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][2], bf[g][2], zero4, 0, 0, 0);
-        } else {
-          acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][0], bf[g][0], acc[2 * g], 0, 0, 0);
-          acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][2], bf[g][2], acc[2 * g + 1], 0, 0, 0);
-        }
+        acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][0], bf[g][0], acc[2 * g], 0, 0, 0);
+        acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][2], bf[g][2], acc[2 * g + 1], 0, 0, 0);
         acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][1], bf[g][1], acc[2 * g], 0, 0, 0);
         acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][3], bf[g][3], acc[2 * g + 1], 0, 0, 0);
         bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
@@ -223,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
       }
     }
     par ^= 1;
+    IMX_TS(1)
     if (++chunk < nchunk) continue;
 
     // ---- item done: output transform Y = A2^T M A4, bias, ReLU, (2x2 max-pool), LDS-staged float4 stores.
@@ -271,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
           }
       }
     }
+    IMX_TS(2)
     __syncthreads();
     if constexpr (POOL) {
       const int Ho = H >> 1, Wo = W >> 1;
@@ -295,9 +307,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
               *reinterpret_cast<const float4*>(Ot + (row * OWP + pxx) * OS + 4 * v4);
       }
     }
+#pragma unroll
+    for (int q = 0; q < 24; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    IMX_TS(3)
+    ++nitem_done;
     item_c += grid;
     if (item_c >= nitems) break;
     cur = nxt;
+  }
+#undef IMX_TS
+  if constexpr (TRACE) {
+    if (lane == 0 && blockIdx.x < 1024) {
+      unsigned* o = trace + (blockIdx.x * 4 + wave) * 8;
+      for (int i = 0; i < 4; ++i) o[i] = tph[i];
+      o[4] = (unsigned)nitem_done;
+    }
   }
 }
 
@@ -313,14 +337,37 @@ hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
     ncu = prop.multiProcessorCount;
   }
-  auto k = conv3x3_wino24<POOL, RELU>;
+  auto k = conv3x3_wino24<POOL, RELU, false>;
+  auto kt = conv3x3_wino24<POOL, RELU, true>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
   const dim3 grid((unsigned)(nitems < 2 * ncu ? nitems : 2 * ncu));
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, tiles_x, tiles_y, nitems);
+  if (getenv("IMX_WINO_TRACE")) {      // bring-up instrumentation: per-phase cycle counts, averaged over items and workgroups
+    static unsigned* dbuf = nullptr;
+    constexpr int NREC = 1024 * 4 * 8;
+    if (!dbuf) (void)hipMalloc(&dbuf, NREC * sizeof(unsigned));
+    (void)hipMemsetAsync(dbuf, 0, NREC * sizeof(unsigned), s);
+    hipLaunchKernelGGL(kt, grid, dim3(256), lds, s, a, tiles_x, tiles_y, nitems, dbuf);
+    (void)hipStreamSynchronize(s);
+    static unsigned host[NREC];
+    (void)hipMemcpy(host, dbuf, sizeof(host), hipMemcpyDeviceToHost);
+    const int n = grid.x < 1024 ? (int)grid.x : 1024;
+    double sum[4] = {0}, ni = 0;
+    for (int i = 0; i < n; ++i) {
+      for (int j = 0; j < 4; ++j) sum[j] += host[(i * 4 + 2) * 8 + j];
+      ni += host[(i * 4 + 2) * 8 + 4];
+    }
+    const int nchunk = a.Cin / CK;
+    fprintf(stderr, "[wino24n trace] H=%d W=%d Cin=%d Cout=%d pool=%d | per item: %d chunks x (barrier %.0f  phase %.0f)  epilogue transform %.0f  "
+                    "stores %.0f cycles  (%.0f items per workgroup)\n", a.H, a.W, a.Cin, a.Cout, (int)POOL, nchunk, sum[0] / ni / nchunk,
+            sum[1] / ni / nchunk, sum[2] / ni, sum[3] / ni, ni / n);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, tiles_x, tiles_y, nitems, (unsigned*)nullptr);
   return hipGetLastError();
 }
 }  // namespace

@@ -1,2 +1,3 @@
-python -m pytest tests/test_gpu_superpoint.py tests/test_gpu_matching.py -x -q 2>&1 | tail -3
-for m in f24 f22; do echo "IMX_CONVN=$m"; IMX_CONVN=$m bash tools/gpu_bench_only.sh; done
+python -m pytest tests/test_gpu_superpoint.py -x -q 2>&1 | tail -2
+IMX_WINO_TRACE=1 python tools/run_pairs.py --pairs 32 --iters 1 2>&1 | grep "wino24n trace" | head -2
+bash tools/gpu_bench_only.sh
