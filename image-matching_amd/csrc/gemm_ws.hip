@@ -1,0 +1,202 @@
+// gemm_ws.hip — weights-stationary, persistent fp32 GEMM for the tall-and-thin products of the path:
+//   out[r][n] = act( sum_k [a0|a1][r][k] * W[k][n] + bias[n] ) (+ res[r][n]),   rows = every keypoint of every pair of the
+// batch (10^5), K = 128..256, N = 128..384: the Conv1d(k=1) projections / MLPs of superglue_test.py:49-60,92-119,214-216 and
+// convDb of superpoint_test.py:83 (BatchNorm folded, torch.cat([x, message]) as a K split).  Same contract as launch_gemm.
+//
+// Why a second form: with K this short, a tiled GEMM re-stages a K x 128 weight panel through LDS for every 128 rows and
+// spends a third of its life in prologue/epilogue (gemm.hip: MFMA pipe 0.52-0.55 busy).  Here the WEIGHTS NEVER MOVE:
+// a workgroup (4 waves) owns 128 output columns, a wave 32 of them; its W fragments for the whole K (K/4 VGPRs per 16-column
+// block: 64 registers at K = 128, 128 at K = 256) are loaded once and stay in registers while the workgroup walks 64-row
+// tiles of the activations.  Only A streams: 64 rows x 64 k stages through LDS (double buffered, one barrier per stage),
+// fetched two stages ahead with buffer loads whose per-thread offsets are tile independent (tile and k offsets ride in the
+// SGPR offset; rows past M are out of range and come back as zeros).  K is permuted so that a lane's A operands of four
+// consecutive MFMAs are four consecutive k of its row: one ds_read_b128 feeds 4 x (columns blocks) MFMAs -- 16 LDS reads per
+// 128 v_mfma_f32_16x16x4_f32 per wave and stage.  Bias / ReLU / residual / stores go through an LDS staging tile as whole
+// float4 row segments.  LDS 2 x 17 KB + 33 KB, two workgroups per CU.
+#include "imx_kernels.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace imx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int RT = 64;            // rows per tile
+constexpr int KC = 64;            // k per stage
+constexpr int AS = KC + 4;        // A stage row stride (68: consecutive rows 4 banks apart, conflict-free b128 reads)
+constexpr int NTW = 128;          // columns per workgroup
+constexpr int OSN = NTW + 4;
+
+template <int K, bool RES>
+__global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg) {
+  constexpr int NC = K / KC;      // stages per tile
+  constexpr int NQ = K / 16;      // operand quads over K
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;               // [2][RT * AS]
+  float* Ot = smem + 2 * RT * AS; // [RT][OSN]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, kq = lane >> 4;
+  const int cg = (int)blockIdx.x % ncg, part = (int)blockIdx.x / ncg, nparts = (int)gridDim.x / ncg;
+  const int n0 = cg * NTW;
+  if (part >= ntile) return;
+
+  // ---- this wave's weights, resident for the whole kernel: bq[cbk][quad t][j] = W[16 t + 4 kq + j][n0 + 32 wave + 16 cbk + n]
+  f32x4 bq[2][NQ];
+#pragma unroll
+  for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+    for (int t = 0; t < NQ; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bq[cbk][t][j] = p.w[(size_t)(16 * t + 4 * kq + j) * p.Npad + n0 + 32 * wave + 16 * cbk + n];
+
+  // ---- loader: a stage is 64 rows x 16 float4; thread -> rows tid/16 + 16 it (it = 0..3), float4 tid % 16
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a0, 0, p.M * p.lda0 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a1 ? p.a1 : p.a0), 0, p.M * (p.a1 ? p.lda1 : p.lda0) * 4, 0x00020000);
+  int vo0[4], vo1[4], ld_dst[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = (tid >> 4) + 16 * it, v4 = tid & 15;
+    vo0[it] = (row * p.lda0 + 4 * v4) * 4;
+    vo1[it] = (row * (p.a1 ? p.lda1 : p.lda0) + 4 * v4) * 4;
+    ld_dst[it] = row * AS + 4 * v4;
+  }
+  f32x4 lr[4];
+  int ltile = part, lc = 0;        // loader cursor (tile, stage)
+  auto issue_load = [&]() {
+    const int kb = lc * KC;
+    const bool second = kb >= p.K0;
+    const int so = __builtin_amdgcn_readfirstlane((ltile * RT * (second ? (p.a1 ? p.lda1 : p.lda0) : p.lda0) + (second ? kb - p.K0 : kb)) * 4);
+    const __amdgpu_buffer_rsrc_t rs = second ? rs1 : rs0;      // branch-free: every issue is exactly four loads (exact vmcnt bookkeeping)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) lr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, second ? vo1[it] : vo0[it], so, 0));
+    if (++lc == NC) { lc = 0; ltile += nparts; }       // past the last tile the offsets run out of range: zeros, never used
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(As + buf * (RT * AS) + ld_dst[it]) = lr[it];
+  };
+
+  // epilogue: thread -> column quad tid % 32 (fixed), rows tid/32 + 8 i.  Residual loads and stores are buffer operations
+  // over M rows: rows past M read zeros / are dropped by the hardware, so the epilogue is branch free too
+  const int c4 = (tid & 31) * 4, erow = tid >> 5;
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.M * p.ldo * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? p.res : p.out), 0, p.M * (RES ? p.ldr : p.ldo) * 4, 0x00020000);
+  int eo[8], er[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    eo[i] = ((erow + 8 * i) * p.ldo + n0 + c4) * 4;
+    er[i] = ((erow + 8 * i) * (RES ? p.ldr : p.ldo) + n0 + c4) * 4;
+  }
+  const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + c4);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- pipeline fill
+  issue_load();
+  store_stage(0);
+  issue_load();
+  __builtin_amdgcn_s_waitcnt(0x0F70);       // drain: the loop's waitcnt bookkeeping then sees only its own in-order loads
+  int par = 0;
+  const int aoff = n * AS + 4 * kq;          // A operand of row block rb, quad t: As[(16 rb + n) * AS + 16 t + 4 kq]
+
+  for (int tile = part; tile < ntile; tile += nparts) {
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int cbk = 0; cbk < 2; ++cbk) acc[rb][cbk] = zero4;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      __syncthreads();             // stage `par` complete; the other buffer's readers are done
+      const float* ab = As + par * (RT * AS) + aoff;
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int t = 0; t < KC / 16; ++t) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(ab + rb * 16 * AS + 16 * t);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[rb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bq[0][c * (KC / 16) + t][j], acc[rb][0], 0, 0, 0);
+            acc[rb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bq[1][c * (KC / 16) + t][j], acc[rb][1], 0, 0, 0);
+          }
+          if (rb == 0 && t == 1) {   // the next stage: registers -> the idle buffer, then fetch the stage after it
+            store_stage(par ^ 1);
+            issue_load();
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      par ^= 1;
+    }
+    // ---- tile done: stage the 64 x 128 result, then bias / ReLU / residual on whole float4 row segments.
+    //      acc[rb][cbk][r]: row 16 rb + 4 kq + r, column 32 wave + 16 cbk + n.
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ot[(16 * rb + 4 * kq + r) * OSN + 32 * wave + 16 * cbk + n] = acc[rb][cbk][r];
+    __syncthreads();
+    {
+      const int oso = __builtin_amdgcn_readfirstlane(tile * RT * p.ldo * 4);
+      const int rso = __builtin_amdgcn_readfirstlane(tile * RT * (RES ? p.ldr : p.ldo) * 4);
+      f32x4 v[8], rv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if constexpr (RES) rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, er[i], rso, 0));
+        v[i] = *reinterpret_cast<const f32x4*>(Ot + (erow + 8 * i) * OSN + c4);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        f32x4 o = v[i] + bias4;
+        if (p.relu) o = __builtin_elementwise_max(o, zero4);
+        if constexpr (RES) o = rv[i] + o;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), ors, eo[i], oso, 0);
+      }
+    }
+  }
+}
+
+template <int K, bool RES>
+hipError_t launch_k(const GemmArgs& a, hipStream_t s) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    ncu = prop.multiProcessorCount;
+  }
+  const int ntile = (a.M + RT - 1) / RT, ncg = a.Npad / NTW;
+  int nparts = 2 * ncu / ncg;
+  if (nparts > ntile) nparts = ntile;
+  if (nparts < 1) nparts = 1;
+  const size_t lds = (size_t)(2 * RT * AS + RT * OSN) * sizeof(float);
+  auto k = gemm_ws<K, RES>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)(nparts * ncg)), dim3(256), lds, s, a, ntile, ncg);
+  return hipGetLastError();
+}
+}  // namespace
+
+bool gemm_ws_supported(const GemmArgs& a) {
+  const int K = a.K0 + a.K1;
+  if (K != 128 && K != 256) return false;
+  if (a.K0 % KC || a.K1 % KC || a.Npad % NTW || a.N != a.Npad || !a.bias) return false;
+  if ((a.ldo & 3) || (a.res && (a.ldr & 3)) || (a.lda0 & 3) || (a.a1 && (a.lda1 & 3))) return false;
+  const int ldmax = std::max(std::max(a.lda0, a.a1 ? a.lda1 : 0), std::max(a.ldo, a.res ? a.ldr : 0));
+  if ((size_t)a.M * (size_t)ldmax * 4 >= 0x7fffffffull) return false;    // 31-bit buffer offsets
+  return a.M > 0;
+}
+
+hipError_t launch_gemm_ws(const GemmArgs& a, hipStream_t s) {
+  if (!gemm_ws_supported(a)) return hipErrorInvalidValue;
+  if (a.K0 + a.K1 == 128) return a.res ? launch_k<128, true>(a, s) : launch_k<128, false>(a, s);
+  return a.res ? launch_k<256, true>(a, s) : launch_k<256, false>(a, s);
+}
+
+}  // namespace imx

@@ -533,7 +533,10 @@ int gemm(imx_handle_t h, hipStream_t s, const char* name, const GemmW& W, const 
          int lda1, int K1, const float* res, int ldr, float* out, int ldo, int M, bool relu) {
   if (K0 + K1 != W.K) return fail(h, "internal: gemm '%s' K mismatch (%d+%d vs %d)", name, K0, K1, W.K);
   GemmArgs g{a0, lda0, K0, a1, lda1, K1, W.w, W.b, res, ldr, out, ldo, M, W.N, W.Npad, relu ? 1 : 0};
-  RUN(name, launch_gemm(g, s));
+  // IMX_GEMM=tiled keeps every product on the tiled kernels of gemm.hip (read per call so tests can switch)
+  const char* ge = getenv("IMX_GEMM");
+  const bool ws = gemm_ws_supported(g) && !(ge && (ge[0] == 't' || ge[0] == '1' || ge[0] == '3'));
+  RUN(name, ws ? launch_gemm_ws(g, s) : launch_gemm(g, s));
   return 0;
 }
 

@@ -50,6 +50,9 @@ struct GemmArgs {
 };
 // (K0, K1) % 32 == 0.
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+// weights-stationary persistent form (gemm_ws.hip): K in {128, 256}, N == Npad, Npad % 128 == 0, float4-aligned leading dims
+bool gemm_ws_supported(const GemmArgs& a);
+hipError_t launch_gemm_ws(const GemmArgs& a, hipStream_t s);
 
 // scores[b][i][j] = scale * sum_k m0[b][i][k] * m1[b][j][k]   ("NT" GEMM, per pair)
 struct ScoreArgs {

@@ -178,3 +178,11 @@ def test_full_size_transport_marginals(name):
     np.testing.assert_allclose(P[:, :K].sum(0), 1.0, rtol=3e-4)
     np.testing.assert_allclose(P[:, K].sum(), float(K), rtol=3e-4)
     assert np.all(P[:K].sum(1) > 0.5) and np.all(P[:K].sum(1) < 1.5)
+
+
+def test_tiled_gemm_form_matches_bit_exact(monkeypatch):
+    """IMX_GEMM=tiled keeps every 1x1-conv product on the tiled kernels of gemm.hip (the default sends K in {128, 256},
+    N % 128 == 0 to the weights-stationary persistent form, gemm_ws.hip).  Both must give the reference's matches."""
+    monkeypatch.setenv("IMX_GEMM", "tiled")
+    for name in ("c3_pair_s59.npz", "c5_pair_s19.npz"):
+        test_full_size_matches_bit_exact_vs_reference_golden(name)
