@@ -278,11 +278,15 @@ def main():
                             "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": name,
                             "avg_launch_ms": round(ms / launches, 4), "share_of_gpu_time": round(ms / tot_ms, 4)}
         if bound == "mfma" and name.startswith("conv") and name not in ("convPb", "convDb") \
-                and os.environ.get("IMX_CONV", "auto") != "direct":
-            # the 3x3 layers run as Winograd F(2x2,3x3): the matrix cores execute 2.25x fewer multiplies than the
-            # algorithmic (direct-form) count `achieved` is defined on -- report the executed rate next to it
-            line["roofline"]["executed"] = {"tflops": round(achieved / 2.25, 3), "frac": round(achieved / 2.25 / peak, 4),
-                                            "note": "Winograd F(2x2,3x3): 36 multiplies per 16 outputs instead of 144"}
+                and os.environ.get("IMX_CONV", "auto") == "auto":
+            # the 3x3 layers run as Winograd F(2x4,3x3) (IMX_CONV1 / IMX_CONVN = f22: F(2x2,3x3)): the matrix cores execute
+            # 3x (2.25x) fewer multiplies than the algorithmic (direct-form) count `achieved` is defined on -- report the
+            # executed rate next to it
+            f22 = os.environ.get("IMX_CONV1" if name == "conv1ab_pool" else "IMX_CONVN", "") == "f22"
+            red = 2.25 if f22 else 3.0
+            line["roofline"]["executed"] = {"tflops": round(achieved / red, 3), "frac": round(achieved / red / peak, 4),
+                                            "note": ("Winograd F(2x2,3x3): 16 multiplies per 4 outputs instead of 36" if f22 else
+                                                     "Winograd F(2x4,3x3): 24 multiplies per 8 outputs instead of 72")}
         # whole-pair view: algorithmic dense FLOPs of the step / measured step time vs the fp32 MFMA peak
         per_step = {r[0]: r[1] / args.steps for r in rows}          # launches per step
         flops_step = sum(u * per_step.get(k, 0.0) for k, (bd, u) in work.items() if bd == "mfma")
