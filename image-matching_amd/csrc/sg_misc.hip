@@ -4,6 +4,7 @@
 //   log-domain Sinkhorn with implicit dustbins           superglue_test.py:141-170
 //   mutual-nearest-neighbour match extraction            superglue_test.py:268-285
 #include "imx_kernels.h"
+#include <cstdlib>
 #include <math.h>
 
 namespace imx {
@@ -144,8 +145,10 @@ __global__ __launch_bounds__(1024) void sinkhorn_cols(SinkhornArgs a) {
 // (:146), so S is read from HBM/L2 once per iteration instead of twice.  Both passes hold their operands in
 // registers, so each log-sum-exp is two-pass (exact max, then one fma + v_exp per element).  A second, small kernel merges
 // the per-slab partials into v.  Slab `m / R` also owns the dustbin row i = m.
-template <int R>
-__global__ __launch_bounds__(1024) void sinkhorn_slab(SinkhornArgs a, float* __restrict__ part, int nslab_max) {
+// NW = waves per workgroup: 16 (a row split over 16/R waves) or, when a row fits one wave's batch (N1p <= 1024), 8 -- twice
+// as many workgroups resident per CU to cover each other's load latency and barriers.
+template <int R, int NW>
+__global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* __restrict__ part, int nslab_max) {
   extern __shared__ float sm[];
   float* tile = sm;                       // [R][N1p]
   float* vs = tile + R * a.N1p;           // [N1p + 1]
@@ -156,13 +159,13 @@ __global__ __launch_bounds__(1024) void sinkhorn_slab(SinkhornArgs a, float* __r
   counts(a, b, m, n);
   if (m == 0 || n == 0 || i0 > m) return;
   const float* v = a.v + (size_t)b * (a.N1p + 1);
-  for (int j = tid; j <= n; j += 1024) vs[j] = v[j];
+  for (int j = tid; j <= n; j += 64 * NW) vs[j] = v[j];
   __syncthreads();
   const float norm = -logf((float)(m + n));
   // Row pass: all 16 waves work whatever R is -- a row is split over W = 16/R waves (segments of N1p/W <= 1024
   // columns, one batch of four float4 loads per lane); their partial (max, sum) pairs are merged through LDS.
-  constexpr int W = 16 / R;
-  __shared__ float pm[16], ps[16];
+  constexpr int W = NW / R;
+  __shared__ float pm[NW], ps[NW];
   {
     const int r = wave / W, seg = wave % W, i = i0 + r;
     const int seglen = a.N1p / W, jlo = seg * seglen, jhi = jlo + seglen;     // N1p % 32 == 0: float4-aligned segments
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_slab(SinkhornArgs a, float* __r
   __syncthreads();
   const int rows = min(R, m + 1 - i0);      // rows of this slab, the last may be the dustbin row
   float2* pb = reinterpret_cast<float2*>(part + ((size_t)b * nslab_max + slab) * (a.N1p + 1) * 2);
-  for (int j = tid; j <= n; j += 1024) {
+  for (int j = tid; j <= n; j += 64 * NW) {
     float t[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) t[r] = tile[r * a.N1p + j];          // rows beyond `rows` hold stale data, masked below
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(256) void match_finalize(MatchArgs a) {
 }  // namespace
 
 // rows per LDS slab (R * N1p floats <= 64 KB); 0 = use the two-pass kernels
-int sinkhorn_slab_rows(int N1p) { return N1p <= 2048 ? 8 : N1p <= 4096 ? 4 : 0; }   // 8 rows even when 16 fit: 4 workgroups per CU (36 KB) hide the load latency better
+int sinkhorn_slab_rows(int N1p) { return N1p <= 2048 ? 8 : N1p <= 4096 ? 4 : 0; }   // 16-row slabs measured slower (3.19 vs 2.36 ms at N = 1024)   // 8 rows even when 16 fit: 4 workgroups per CU (36 KB) hide the load latency better
 
 hipError_t launch_kenc0(const Kenc0Args& a, hipStream_t s) {
   long total = (long)a.B * a.Np * a.C1;
@@ -409,15 +412,26 @@ hipError_t launch_gather_desc(const float* src, int64_t sb, int64_t sc, int64_t 
   return hipGetLastError();
 }
 
-template <int R>
-static void launch_slab_iter(const SinkhornArgs& a, int nslab_max, hipStream_t s) {
+template <int R, int NW>
+static void launch_slab_k(const SinkhornArgs& a, int nslab_max, hipStream_t s) {
   const size_t lds = ((size_t)R * a.N1p + a.N1p + 1) * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_slab<R>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_slab<R, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(sinkhorn_slab<R>, dim3((unsigned)nslab_max, (unsigned)a.B), dim3(1024), lds, s, a, a.part, nslab_max);
+  hipLaunchKernelGGL((sinkhorn_slab<R, NW>), dim3((unsigned)nslab_max, (unsigned)a.B), dim3(64 * NW), lds, s, a, a.part, nslab_max);
+}
+
+template <int R>
+static void launch_slab_iter(const SinkhornArgs& a, int nslab_max, hipStream_t s) {
+  static const int forced = getenv("IMX_SINKHORN_WAVES") ? atoi(getenv("IMX_SINKHORN_WAVES")) : 0;
+  if constexpr (R == 8) {
+    if (forced == 8 || (forced != 16 && a.N1p <= 1024)) launch_slab_k<8, 8>(a, nslab_max, s);
+    else launch_slab_k<8, 16>(a, nslab_max, s);
+  } else {
+    launch_slab_k<R, 16>(a, nslab_max, s);
+  }
   hipLaunchKernelGGL(sinkhorn_vmerge, dim3((unsigned)((a.N1p + 1 + 63) / 64), (unsigned)a.B), dim3(1024), 0, s, a, a.part, nslab_max, R);
 }
 
