@@ -372,9 +372,13 @@ hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
 }
 }  // namespace
 
+bool conv3x3_wino24_supported(const ConvArgs& a) {
+  if (a.first || a.Cin % 32 || a.Cout % NT || !a.wu24) return false;
+  return (size_t)a.H * a.W * a.Cin * 4 < (size_t)OOB;      // per-image byte offsets are 31-bit
+}
+
 hipError_t launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s) {
-  if (a.first || a.Cin % 32 || a.Cout % NT || !a.wu24) return hipErrorInvalidValue;
-  if ((size_t)a.H * a.W * a.Cin * 4 >= (size_t)OOB) return hipErrorInvalidValue;     // per-image byte offsets are 31-bit
+  if (!conv3x3_wino24_supported(a)) return hipErrorInvalidValue;
   if (a.pool) return a.relu ? launch_t<true, true>(a, s) : launch_t<true, false>(a, s);
   return a.relu ? launch_t<false, true>(a, s) : launch_t<false, false>(a, s);
 }

@@ -567,7 +567,7 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
     a.in = in; a.in2 = first ? img1 : nullptr; a.split = first ? split : 0;
     a.w = w.w; a.wu = w.wu; a.wu4 = w.wu4; a.wu6 = w.wu6; a.wu24 = w.wu24; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
     a.B = B; a.H = hh; a.W = ww; a.Cin = w.cin; a.Cout = w.cout; a.relu = 1; a.pool = pool ? 1 : 0; a.first = first ? 1 : 0;
-    RUN(name, (h->conv_mode == 4 && a.first && a.pool && h->conv1_f24) ? launch_conv1ab_wino24(a, s) : (h->conv_mode == 4 && !a.first && h->convn_f24) ? launch_conv3x3_wino24(a, s) : (h->conv_mode == 3 || (h->conv_mode == 4 && !a.first)) ? launch_conv3x3_wino6(a, s) : h->conv_mode == 2 ? launch_conv3x3_wino4(a, s) : h->conv_mode == 0 ? launch_conv3x3(a, s) : launch_conv3x3_wino(a, s));
+    RUN(name, (h->conv_mode == 4 && a.first && a.pool && h->conv1_f24) ? launch_conv1ab_wino24(a, s) : (h->conv_mode == 4 && !a.first && h->convn_f24 && conv3x3_wino24_supported(a)) ? launch_conv3x3_wino24(a, s) : (h->conv_mode == 3 || (h->conv_mode == 4 && !a.first)) ? launch_conv3x3_wino6(a, s) : h->conv_mode == 2 ? launch_conv3x3_wino4(a, s) : h->conv_mode == 0 ? launch_conv3x3(a, s) : launch_conv3x3_wino(a, s));
     return 0;
   };
   if (conv("conv1ab_pool", h->conv[0], img0, a1, H, W, true, true)) return -1;

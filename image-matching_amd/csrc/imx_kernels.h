@@ -34,6 +34,7 @@ hipError_t launch_conv3x3_wino6(const ConvArgs& a, hipStream_t s); // Winograd F
 // first && pool, Cin == Cout == 64.
 hipError_t launch_conv1ab_wino24(const ConvArgs& a, hipStream_t s); // fused conv1a + conv1b (Winograd F(2x4,3x3)) + pool
 // Cin % 32 == 0, Cout % 64 == 0, not first.
+bool conv3x3_wino24_supported(const ConvArgs& a);                   // false (e.g. an image of >= 2 GB per layer): callers fall back to wino6
 hipError_t launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s); // Winograd F(2x4,3x3), persistent, in-stream transform
 
 // ---------------------------------------------------------------- GEMM (MFMA fp32): 1x1 conv / linear
