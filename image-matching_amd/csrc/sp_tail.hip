@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ scor
 // supp_scores copy (scores are >= 0): for an un-suppressed pixel the window maximum is its own
 // score either way, so `supp_scores == max_pool(supp_scores) & ~supp` is unchanged.
 template <int R>
-__global__ __launch_bounds__(1024) void nms_fast_kernel(const float* __restrict__ scores, float* __restrict__ out,
+__global__ __launch_bounds__(1024, 8) void nms_fast_kernel(const float* __restrict__ scores, float* __restrict__ out,
                                                         int H, int W) {
   // 32 x 64 output tile: the 5R halo (five dependent pools) costs (72*104)/(32*64) = 3.7x redundant area, 5.1x at 32 x 32
   constexpr int TY = 32, TX = 64, HALO = 5 * R, ST = 8;
@@ -174,24 +174,35 @@ __global__ __launch_bounds__(1024) void nms_fast_kernel(const float* __restrict_
   constexpr int NSX = SX / ST, NSY = SY / ST;
   static_assert(SY * NSX <= 1024 && SX * NSY <= 1024, "strip grid exceeds the workgroup");
   extern __shared__ float sm[];
-  float* S = sm;          // scores, -inf outside the image and in the margin
-  float* M = S + N;       // max_mask as 0/1
-  float* X = M + N;       // supp_scores (-1 where suppressed)
-  float* P = X + N;       // pooling scratch (in place)
+  float* P = sm;          // the ONE array in LDS: pooling scratch (in place), -inf in the margin
   const int tid = threadIdx.x;
   const int b = blockIdx.z, gy0 = blockIdx.y * TY - HALO, gx0 = blockIdx.x * TX - HALO;
   const float* img = scores + (size_t)b * H * W;
   const float NEG = -INFINITY;
 
+  // Everything that is only ever touched element-wise -- the scores, max_mask and supp_scores of a pixel -- lives in the
+  // registers of the thread that owns the pixel (NE pixels per thread, same mapping in every pass); LDS holds only the
+  // array being pooled.  36 KB instead of 145 KB per workgroup: two workgroups (2 x 16 waves) fit a CU and cover each
+  // other's barriers, and the element-wise passes touch LDS once per pixel instead of three or four times.
+  constexpr int NE = (SY * SX + 1023) / 1024;
+  float sv[NE];
+  unsigned mkb = 0, supb = 0;   // max_mask / supp_mask of the thread's pixels, one bit each (supp_scores = supp ? -1 : score)
+  auto pidx = [&](int k) -> int {        // LDS index of pixel k (recomputed: registers are what limits two workgroups per CU)
+    const int e = tid + k * 1024;
+    return e < SY * SX ? (e / SX + R) * PITCH + e % SX + R : -1;
+  };
   for (int e = tid; e < N; e += 1024) {
     const int py = e / PITCH, px = e - py * PITCH;
-    const int gy = gy0 + py - R, gx = gx0 + px - R;
-    const bool in_region = py >= R && py < R + SY && px >= R && px < R + SX;
-    const float v = (in_region && gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : NEG;
-    S[e] = v;
-    P[e] = v;
-    X[e] = NEG;
-    M[e] = 0.f;
+    if (!(py >= R && py < R + SY && px >= R && px < R + SX)) P[e] = NEG;      // margin, written once
+  }
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const int e = tid + k * 1024;
+    const bool own = e < SY * SX;
+    const int ry = own ? e / SX : 0, rx = own ? e % SX : 0;
+    const int gy = gy0 + ry, gx = gx0 + rx;
+    sv[k] = (own && gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : NEG;
+    if (own) P[(ry + R) * PITCH + rx + R] = sv[k];
   }
   __syncthreads();
 
@@ -251,41 +262,50 @@ __global__ __launch_bounds__(1024) void nms_fast_kernel(const float* __restrict_
 
   // max_mask = scores == max_pool(scores)                                              (:16)
   pool_inplace();
-  for (int e = tid; e < SY * SX; e += 1024) {
-    const int i = (e / SX + R) * PITCH + e % SX + R;
-    const float sv = S[i];
-    const float mk = (sv > NEG && sv == P[i]) ? 1.f : 0.f;
-    M[i] = mk;
-    P[i] = mk;
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const int i = pidx(k);
+    if (i >= 0) {
+      const bool mx = sv[k] > NEG && sv[k] == P[i];
+      mkb |= mx ? 1u << k : 0u;
+      P[i] = mx ? 1.f : 0.f;
+    }
   }
   __syncthreads();
   for (int it = 0; it < 2; ++it) {                                                      // (:17-21)
     pool_inplace();                            // P = max_pool(max_mask) ; supp_mask = P > 0
-    for (int e = tid; e < SY * SX; e += 1024) {
-      const int i = (e / SX + R) * PITCH + e % SX + R;
-      const float sv = S[i];
-      const float x = sv > NEG ? (P[i] > 0.f ? -1.f : sv) : NEG;
-      X[i] = x;
-      P[i] = x;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int i = pidx(k);
+      if (i >= 0) {
+        const bool sp = P[i] > 0.f;
+        supb = (supb & ~(1u << k)) | (sp ? 1u << k : 0u);
+        P[i] = sv[k] > NEG ? (sp ? -1.f : sv[k]) : NEG;
+      }
     }
     __syncthreads();
     pool_inplace();                            // P = max_pool(supp_scores)
-    for (int e = tid; e < SY * SX; e += 1024) {
-      const int i = (e / SX + R) * PITCH + e % SX + R;
-      const float x = X[i];
-      const float mk = (M[i] > 0.f || (x >= 0.f && x == P[i])) ? 1.f : 0.f;
-      M[i] = mk;
-      P[i] = mk;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int i = pidx(k);
+      if (i >= 0) {
+        const float x = sv[k] > NEG ? (((supb >> k) & 1u) ? -1.f : sv[k]) : NEG;
+        const bool mx = ((mkb >> k) & 1u) || (x >= 0.f && x == P[i]);
+        mkb |= mx ? 1u << k : 0u;
+        P[i] = mx ? 1.f : 0.f;
+      }
     }
     __syncthreads();
   }
   float* o = out + (size_t)b * H * W;
-  for (int e = tid; e < TY * TX; e += 1024) {
-    const int ty = e / TX, tx = e - ty * TX;
-    const int gy = blockIdx.y * TY + ty, gx = blockIdx.x * TX + tx;
-    if (gy < H && gx < W) {
-      const int i = (ty + HALO + R) * PITCH + tx + HALO + R;
-      o[(size_t)gy * W + gx] = M[i] > 0.f ? S[i] : 0.f;                                 // (:22)
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const int e = tid + k * 1024;
+    if (e < SY * SX) {
+      const int ry = e / SX - HALO, rx = e % SX - HALO;          // position inside the output tile
+      const int gy = blockIdx.y * TY + ry, gx = blockIdx.x * TX + rx;
+      if (ry >= 0 && ry < TY && rx >= 0 && rx < TX && gy < H && gx < W)
+        o[(size_t)gy * W + gx] = ((mkb >> k) & 1u) ? sv[k] : 0.f;                               // (:22)
     }
   }
 }
@@ -294,7 +314,7 @@ template <int R>
 hipError_t launch_nms_fast(const float* scores, float* out, int B, int H, int W, hipStream_t s) {
   constexpr int TY = 32, TX = 64, SY = ((TY + 10 * R + 7) / 8) * 8, SX = ((TX + 10 * R + 7) / 8) * 8;
   constexpr int PY = SY + 2 * R, PX = SX + 2 * R, PITCH = PX | 1;
-  const size_t lds = (size_t)4 * PY * PITCH * sizeof(float);
+  const size_t lds = (size_t)PY * PITCH * sizeof(float);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_fast_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
