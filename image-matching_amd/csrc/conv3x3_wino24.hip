@@ -8,8 +8,8 @@
 // Persistent: 2 workgroups per CU walk work items (8x16-pixel tile, 64-channel output block), item i -> workgroup i % grid, so
 // that at any moment the chip works on neighbouring tiles and every output block of a tile (input patches and the current U
 // panels stay in L2).  Workgroup = 4 waves; wave = 16 output channels x the 16 wtiles x 24 positions = 24 accumulators of 4
-// VGPRs; the D layout of the 16x16 MFMA gives a lane one channel and one row of four wtiles with all 24 positions, so the
-// output transform, bias, ReLU and the 2x2 max-pool are in-lane.
+// VGPRs; with U as the MFMA's A operand the 16x16 D layout gives a lane one wtile and four consecutive channels with all 24
+// positions, so the output transform, bias, ReLU and the 2x2 max-pool are in-lane and every result leaves as a 16-byte store.
 // The K loop is ONE continuous stream of 8-channel chunks across items, one barrier per chunk.  During the MFMA phase of
 // stream position s (48 MFMAs per wave, A operands one ds_read_b128 per quad of four, B operands registers refilled in place
 // with position s+1's U panel right behind the MFMAs that consumed them), the same instruction stream carries:
@@ -20,7 +20,7 @@
 //     the image get an out-of-range offset and come back as the zero padding.
 // (Why in-stream: beside a saturated MFMA stream another wave's VALU instruction issues once per ~41 cycles; inside the MFMA
 // wave a batch of n costs ~11 + 4.5 n cycles of matrix-pipe time -- tools/ubench/mfma_valu.hip.)
-// LDS: V 2 x 13.5 KB, raw 2 x 7.5 KB, output staging tile 8.5 KB (pooled) / 36 KB (full resolution): 50.5 / 78 KB.
+// LDS: V 2 x 13.5 KB, raw 2 x 7.5 KB = 42 KB (no output staging: see the epilogue).
 #include "imx_kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -39,8 +39,7 @@ constexpr int RAWC = 192 * RSC;                // 180 pixels + pad
 constexpr int KS = 18, QSL = 4 * KS, NQ = 12;  // V: [12 quads][4 k][18 slots][4]
 constexpr int VSZ = NQ * QSL * 4;              // 3456
 constexpr int UCH = NQ * 4 * 64 * 4;           // 12288 floats of U per (64 co, 8 ci)
-constexpr int CK = 8, NT = 64, OS = NT + 4;
-constexpr int OWP = OW + 1;                    // full-resolution staging tile: row pitch 17 pixels (wtile rows 8 banks apart)
+constexpr int CK = 8, NT = 64;
 constexpr unsigned OOB = 0x7ffffff0u;          // byte offset beyond any image: buffer loads return 0
 
 struct Item { int b, y0, x0, cob; };
@@ -60,7 +59,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* V = smem;                  // [2][VSZ]
   float* raw = V + 2 * VSZ;         // [2][RAWC]
-  float* Ot = raw + 2 * RAWC;       // output staging tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cb = wave;
@@ -176,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
 #pragma unroll
   for (int q = 0; q < 24; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int chunk = 0, par = 0;          // par = stream position & 1
-  float bs = 0.f;                  // bias of this lane's output channel (current item)
+  f32x4 bs4 = {0.f, 0.f, 0.f, 0.f};   // bias of this lane's four output channels (current item)
 
   if constexpr (TRACE) tprev = __builtin_readcyclecounter();
 #pragma unroll 1
@@ -188,8 +186,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
       const bool last = chunk + 1 == nchunk;
       const int ncb = last ? nxt.cob : cur.cob, nch = last ? 0 : chunk + 1;
       const int uoff = __builtin_amdgcn_readfirstlane((ncb * nchunk + nch) * (UCH * 4));
-      bs = p.bias[cur.cob * NT + cb * 16 + (lane & 15)];      // every phase (one dword): an unconditional load keeps the vmcnt
-      const float* vr = vrd + par * VSZ;                       // bookkeeping exact, and the epilogue never waits for it
+      bs4 = *reinterpret_cast<const f32x4*>(p.bias + cur.cob * NT + cb * 16 + 4 * (lane >> 4));      // every phase: an unconditional
+      const float* vr = vrd + par * VSZ;                       // load keeps the vmcnt bookkeeping exact; the epilogue never waits for it
       float* vw = vwr + (par ^ 1) * VSZ;
       const float* pa = rpa + (par ^ 1) * RAWC;
       const float* pb = rpb + (par ^ 1) * RAWC;
@@ -200,10 +198,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
       for (int g = 0; g < NQ; ++g) {
         const int cu = g & 1, nx = cu ^ 1;
         if (g + 1 < NQ) af[nx] = *reinterpret_cast<const f32x4*>(vr + (g + 1) * QSL * 4);
-        acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][0], bf[g][0], acc[2 * g], 0, 0, 0);
-        acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][2], bf[g][2], acc[2 * g + 1], 0, 0, 0);
-        acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][1], bf[g][1], acc[2 * g], 0, 0, 0);
-        acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cu][3], bf[g][3], acc[2 * g + 1], 0, 0, 0);
+        acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][0], af[cu][0], acc[2 * g], 0, 0, 0);
+        acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][2], af[cu][2], acc[2 * g + 1], 0, 0, 0);
+        acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][1], af[cu][1], acc[2 * g], 0, 0, 0);
+        acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][3], af[cu][3], acc[2 * g + 1], 0, 0, 0);
         bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
         if (g == 0) {
 #pragma unroll
@@ -236,11 +234,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
     IMX_TS(1)
     if (++chunk < nchunk) continue;
 
-    // ---- item done: output transform Y = A2^T M A4, bias, ReLU, (2x2 max-pool), LDS-staged float4 stores.
-    //      acc[j*4 + i][r]: wtile (row lane>>4, column r), channel cob*64 + cb*16 + (lane&15).
+    // ---- item done: output transform Y = A2^T M A4, bias, ReLU, (2x2 max-pool), stores straight from registers.
+    //      The MFMAs take U as their A operand and V as B, so D is [channel][wtile]: acc[j*4 + i][r] belongs to wtile
+    //      n = lane&15 (row n>>2, column n&3) and channel cob*64 + cb*16 + 4*(lane>>4) + r -- a lane's four registers are
+    //      four CONSECUTIVE CHANNELS of one pixel, i.e. one 16-byte store each (four lanes cover 64 contiguous bytes, the
+    //      four waves the pixel's 256), with no LDS staging tile and no barrier.  Buffer stores through a per-image
+    //      descriptor: pixels outside the image get an out-of-range offset and are dropped by the hardware.
     chunk = 0;
     {
-      const int col = cb * 16 + (lane & 15);
       f32x4 s0[6], s1[6];
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
@@ -257,18 +258,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
         y[r][2] = a12 + 4.f * c34;
         y[r][3] = b12 + 8.f * d34 + m[5];
       }
-      const f32x4 bs4 = {bs, bs, bs, bs}, zero4 = {0.f, 0.f, 0.f, 0.f};
-      const int wr = lane >> 4;
+      IMX_TS(2)
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      const int wr = (lane & 15) >> 2, wc = lane & 3;
+      const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
+      const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)cur.b * Ho * Wo * Cout), 0, Ho * Wo * Cout * 4, 0x00020000);
+      const int choff = (cur.cob * NT + cb * 16 + 4 * (lane >> 4)) * 4;
+      typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
       if constexpr (POOL) {
-        f32x4 pooled[2];
-        pooled[0] = __builtin_elementwise_max(__builtin_elementwise_max(y[0][0], y[0][1]), __builtin_elementwise_max(y[1][0], y[1][1]));
-        pooled[1] = __builtin_elementwise_max(__builtin_elementwise_max(y[0][2], y[0][3]), __builtin_elementwise_max(y[1][2], y[1][3]));
+        const int oy = (cur.y0 >> 1) + wr;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          f32x4 v = pooled[hh] + bs4;
+          f32x4 v = __builtin_elementwise_max(__builtin_elementwise_max(y[0][2 * hh], y[0][2 * hh + 1]), __builtin_elementwise_max(y[1][2 * hh], y[1][2 * hh + 1])) + bs4;
           if (RELU) v = __builtin_elementwise_max(v, zero4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Ot[(wr * (OW / 2) + 2 * r + hh) * OS + col] = v[r];
+          const int ox = (cur.x0 >> 1) + 2 * wc + hh;
+          const unsigned off = (oy < Ho && ox < Wo) ? (unsigned)((oy * Wo + ox) * Cout * 4 + choff) : OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (int)off, 0, 0);
         }
       } else {
 #pragma unroll
@@ -277,34 +282,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
           for (int x = 0; x < 4; ++x) {
             f32x4 v = y[r][x] + bs4;
             if (RELU) v = __builtin_elementwise_max(v, zero4);
-#pragma unroll
-            for (int wc = 0; wc < 4; ++wc) Ot[((2 * wr + r) * OWP + 4 * wc + x) * OS + col] = v[wc];
+            const int oy = cur.y0 + 2 * wr + r, ox = cur.x0 + 4 * wc + x;
+            const unsigned off = (oy < Ho && ox < Wo) ? (unsigned)((oy * Wo + ox) * Cout * 4 + choff) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (int)off, 0, 0);
           }
-      }
-    }
-    IMX_TS(2)
-    __syncthreads();
-    if constexpr (POOL) {
-      const int Ho = H >> 1, Wo = W >> 1;
-#pragma unroll
-      for (int it = 0; it < (OH / 2) * (OW / 2) * (NT / 4) / 256; ++it) {
-        const int e = tid + it * 256;
-        const int pix = e / (NT / 4), v4 = e % (NT / 4);
-        const int oy = (cur.y0 >> 1) + pix / (OW / 2), ox = (cur.x0 >> 1) + pix % (OW / 2);
-        if (oy < Ho && ox < Wo)
-          *reinterpret_cast<float4*>(p.out + ((size_t)(cur.b * Ho + oy) * Wo + ox) * Cout + cur.cob * NT + 4 * v4) =
-              *reinterpret_cast<const float4*>(Ot + pix * OS + 4 * v4);
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < OH * OW * (NT / 4) / 256; ++it) {
-        const int e = tid + it * 256;
-        const int pix = e / (NT / 4), v4 = e % (NT / 4);
-        const int row = pix / OW, pxx = pix % OW;
-        const int oy = cur.y0 + row, ox = cur.x0 + pxx;
-        if (oy < H && ox < W)
-          *reinterpret_cast<float4*>(p.out + ((size_t)(cur.b * H + oy) * W + ox) * Cout + cur.cob * NT + 4 * v4) =
-              *reinterpret_cast<const float4*>(Ot + (row * OWP + pxx) * OS + 4 * v4);
       }
     }
 #pragma unroll
@@ -329,7 +310,7 @@ template <bool POOL, bool RELU>
 hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = (a.W + OW - 1) / OW, tiles_y = (a.H + OH - 1) / OH;
   const int nitems = tiles_x * tiles_y * a.B * (a.Cout / NT);
-  const size_t lds = (size_t)(2 * VSZ + 2 * RAWC + (POOL ? (OH / 2) * (OW / 2) * OS : OH * OWP * OS)) * sizeof(float);
+  const size_t lds = (size_t)(2 * VSZ + 2 * RAWC) * sizeof(float);
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
