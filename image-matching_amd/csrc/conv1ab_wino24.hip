@@ -5,20 +5,21 @@
 // 1.33x fewer than F(2x2,3x3); fp32 throughout, error measured in the parity tests).  Summed over input channels as 24
 // independent GEMMs  M_p[wtile][co] = sum_ci V_p[wtile][ci] U_p[ci][co]  on v_mfma_f32_16x16x4_f32.
 //
-// Workgroup = 256 threads (4 waves) -> 8x16 output pixels = 4x4 wtiles x 64 output channels; wave = 16 channels x the 16
-// wtiles x 24 positions = 24 accumulators of 4 VGPRs.  The 16x16 D layout gives a lane one channel and one ROW of four
-// wtiles with all 24 positions: output transform, bias, ReLU and the 2x2 max-pool (one wtile = 1x2 pooled pixels) are
-// in-lane.
-// conv1a (1 -> 64, K = 9) is evaluated once per workgroup for the 10x18 halo patch into LDS (packed over channel pairs).
-// K loop: 8 input channels per chunk, two barriers per chunk.
-//   input transform: ONE wave per chunk (wave ch & 3; the others wait at the barrier and leave their SIMD to the
-//     co-resident workgroup's MFMAs): lane = (wtile, channel PAIR), patch read as 24 ds_read_b64, every operation of both
-//     passes is one packed (v_pk_*_f32) instruction over the pair, results leave as 12 ds_write_b128;
+// Persistent, 2 workgroups per CU.  Workgroup = 256 threads (4 waves) -> 8x16 output pixels = 4x4 wtiles x 64 output channels;
+// wave = 16 channels x the 16 wtiles x 24 positions = 24 accumulators of 4 VGPRs.  U is the MFMA's A operand, so the 16x16 D
+// layout gives a lane one wtile and FOUR CONSECUTIVE CHANNELS with all 24 positions: output transform, bias, ReLU and the
+// 2x2 max-pool (one wtile = 1x2 pooled pixels) are in-lane and every result leaves as one 16-byte store.
+// conv1a (1 -> 64, K = 9 + bias tap) runs on the matrix cores once per tile for the 10x18 halo patch, into LDS.
+// K loop: 8 input channels per chunk, ONE barrier per chunk:
+//   the next chunk's input transform rides inside the MFMA phase, split over the four waves by transformed row: lane =
+//     (wtile, channel PAIR), 12 ds_read_b64, every operation one packed (v_pk_*_f32) instruction over the pair (6 + 12 in three
+//     dense batches), 6 ds_write_b64; V is double buffered;
 //   V layout [12 quads][4 k][18][4]: a quad = two positions x the two channels of a pair.  The chunk's two MFMA k-steps
-//     take the even / odd channels of the four pairs, so a lane's A operands of four MFMAs are ONE ds_read_b128
-//     (12 LDS reads per chunk for 48 MFMAs), and the B operands (U = G2 g G4^T, transformed at weight load, laid out
-//     [chunk][quad][co-block][lane][4]) ONE buffer_load_dwordx4, issued before the chunk barrier: U never touches LDS.
-// LDS 62 KB, 2 workgroups per CU.
+//     take the even / odd channels of the four pairs, so a lane's V operands of four MFMAs are ONE ds_read_b128
+//     (12 LDS reads per chunk for 48 MFMAs), and its U operands (U = G2 g G4^T, transformed at weight load, laid out
+//     [chunk][quad][co-block][lane][4]) ONE buffer_load_dwordx4, refilled in place right behind the MFMAs that consumed
+//     them: U never touches LDS.
+// LDS 79 KB (V 2 x 13.5, conv1a patch 49.5, image patch 1).
 #include "imx_kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -39,7 +40,7 @@ constexpr int QSL = 4 * KS;                    // slots per quad
 constexpr int NQ = 12;                         // quads per chunk: 24 positions x 2 k-steps / 4
 constexpr int VSZ = NQ * QSL * 4;              // 3456
 constexpr int UCH = NQ * 4 * 64 * 4;           // 12288 floats of U per (64 co, 8 ci)
-constexpr int CK = 8, NT = 64, OS = NT + 4;
+constexpr int CK = 8;
 
 template <bool TRACE>
 __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x, int tiles_y, int ntiles, unsigned* trace) {
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
     gpx[j] = pc % RW;
   }
   int ntile_done = 0;
-  const float bs = p.bias[cb * 16 + (lane & 15)];      // conv1b bias of this lane's output channel
+  const f32x4 bs4 = *reinterpret_cast<const f32x4*>(p.bias + cb * 16 + 4 * (lane >> 4));      // conv1b bias of this lane's four output channels
   f32x4 bf[NQ];                  // B operands of the coming chunk (chunk 0 here; refilled in place from then on)
 #pragma unroll
   for (int g = 0; g < NQ; ++g) bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, g * 4096, 0));
@@ -221,10 +222,10 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
         for (int g = 0; g < NQ; ++g) {
           const int cur = g & 1, nxt = cur ^ 1;
           if (g + 1 < NQ) af[nxt] = *reinterpret_cast<const f32x4*>(vr + (g + 1) * QSL * 4);
-          acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][0], bf[g][0], acc[2 * g], 0, 0, 0);
-          acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][2], bf[g][2], acc[2 * g + 1], 0, 0, 0);
-          acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][1], bf[g][1], acc[2 * g], 0, 0, 0);
-          acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][3], bf[g][3], acc[2 * g + 1], 0, 0, 0);
+          acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][0], af[cur][0], acc[2 * g], 0, 0, 0);
+          acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][2], af[cur][2], acc[2 * g + 1], 0, 0, 0);
+          acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][1], af[cur][1], acc[2 * g], 0, 0, 0);
+          acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][3], af[cur][3], acc[2 * g + 1], 0, 0, 0);
           bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
           if (g == 0) {
 #pragma unroll
@@ -252,52 +253,43 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
       IMX_TS(3)
     }
 
-    // ---- output transform Y = A2^T M A4, 2x2 max-pool, bias, ReLU (max-pool commutes with both), LDS-staged float4 stores.
-    //      acc[j*4 + i][r]: wtile (row lane>>4, column r), channel cb*16 + (lane&15).
-    float* Ot = smem;
-    __syncthreads();          // every wave is done with V (the staging tile aliases it)
+    // ---- output transform Y = A2^T M A4, 2x2 max-pool, bias, ReLU (max-pool commutes with both), stores straight from
+    //      registers.  The conv1b MFMAs take U as their A operand and V as B, so D is [channel][wtile]: acc[j*4 + i][r]
+    //      belongs to wtile n = lane&15 (row n>>2, column n&3) and channel cb*16 + 4*(lane>>4) + r -- a lane's four registers
+    //      are four consecutive channels of one pixel = one 16-byte store (no LDS staging tile, no barrier); buffer stores
+    //      through a per-image descriptor drop the pixels outside the image.
     {
-      const int col = cb * 16 + (lane & 15);
       f32x4 s0[6], s1[6];
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         s0[j] = acc[j * 4 + 0] + acc[j * 4 + 1] + acc[j * 4 + 2];
         s1[j] = acc[j * 4 + 1] - acc[j * 4 + 2] - acc[j * 4 + 3];
       }
-      f32x4 pooled[2];
-      {
-        f32x4 y[2][4];
+      f32x4 y[2][4];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const f32x4* m = r ? s1 : s0;
-          const f32x4 a12 = m[1] + m[2], b12 = m[1] - m[2], c34 = m[3] + m[4], d34 = m[3] - m[4];
-          y[r][0] = m[0] + a12 + c34;
-          y[r][1] = b12 + 2.f * d34;
-          y[r][2] = a12 + 4.f * c34;
-          y[r][3] = b12 + 8.f * d34 + m[5];
-        }
-        pooled[0] = __builtin_elementwise_max(__builtin_elementwise_max(y[0][0], y[0][1]), __builtin_elementwise_max(y[1][0], y[1][1]));
-        pooled[1] = __builtin_elementwise_max(__builtin_elementwise_max(y[0][2], y[0][3]), __builtin_elementwise_max(y[1][2], y[1][3]));
+      for (int r = 0; r < 2; ++r) {
+        const f32x4* m = r ? s1 : s0;
+        const f32x4 a12 = m[1] + m[2], b12 = m[1] - m[2], c34 = m[3] + m[4], d34 = m[3] - m[4];
+        y[r][0] = m[0] + a12 + c34;
+        y[r][1] = b12 + 2.f * d34;
+        y[r][2] = a12 + 4.f * c34;
+        y[r][3] = b12 + 8.f * d34 + m[5];
       }
-      const f32x4 bs4 = {bs, bs, bs, bs}, zero4 = {0.f, 0.f, 0.f, 0.f};
-      const int wr = lane >> 4;
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      const int wr = (lane & 15) >> 2, wc = lane & 3;
+      const int Ho = H >> 1, Wo = W >> 1;
+      const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)bcur * Ho * Wo * Cout), 0, Ho * Wo * Cout * 4, 0x00020000);
+      const int choff = (cb * 16 + 4 * (lane >> 4)) * 4;
+      typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+      const int oy = (y0 >> 1) + wr;
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        const f32x4 v = __builtin_elementwise_max(pooled[hh] + bs4, zero4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Ot[(wr * (OW / 2) + 2 * r + hh) * OS + col] = v[r];
+        const f32x4 v = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_max(y[0][2 * hh], y[0][2 * hh + 1]),
+                                                                            __builtin_elementwise_max(y[1][2 * hh], y[1][2 * hh + 1])) + bs4, zero4);
+        const int ox = (x0 >> 1) + 2 * wc + hh;
+        const unsigned off = (oy < Ho && ox < Wo) ? (unsigned)((oy * Wo + ox) * Cout * 4 + choff) : 0x7ffffff0u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (int)off, 0, 0);
       }
-    }
-    __syncthreads();
-    const int Ho = H >> 1, Wo = W >> 1;
-#pragma unroll
-    for (int it = 0; it < (OH / 2) * (OW / 2) * (NT / 4) / 256; ++it) {
-      const int e = tid + it * 256;
-      const int pix = e / (NT / 4), v4 = e % (NT / 4);
-      const int oy = (y0 >> 1) + pix / (OW / 2), ox = (x0 >> 1) + pix % (OW / 2);
-      if (oy < Ho && ox < Wo)
-        *reinterpret_cast<float4*>(p.out + ((size_t)(bcur * Ho + oy) * Wo + ox) * Cout + 4 * v4) =
-            *reinterpret_cast<const float4*>(Ot + pix * OS + 4 * v4);
     }
     IMX_TS(5)
     ++ntile_done;
