@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
     if (tid < IMG_H * IMG_W) img[tid] = pre;
     if (++tx == tiles_x) { tx = 0; if (++ty == tiles_y) { ty = 0; ++b; } }      // -> next tile
     pre = fetch_px(tx, ty, b, t + 1 < t_end);
-    __syncthreads();             // image patch visible; the previous tile's epilogue is done with the staging tile
+    __syncthreads();             // image patch visible
+    IMX_TS(6)
 
     // ---- conv1a + folded BN + ReLU for all 64 channels of the 10x18 halo patch ON THE MATRIX CORES (the packed-FMA form
     //      cost ~470 instructions per wave, each ~20 cycles beside the co-resident workgroup's MFMA stream):
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
       unsigned* o = trace + (blockIdx.x * 4 + wave) * 8;
       for (int i = 0; i < 6; ++i) o[i] = tph[i];
       o[6] = (unsigned)ntile_done;
+      o[7] = tph[6];
     }
   }
 }
@@ -328,11 +330,13 @@ hipError_t launch_conv1ab_wino24(const ConvArgs& a, hipStream_t s) {
     (void)hipMemcpy(host, dbuf, sizeof(host), hipMemcpyDeviceToHost);
     const int n = grid.x < 1024 ? (int)grid.x : 1024;
     for (int w = 0; w < 4; ++w) {
-      double sum[6] = {0}, nt = 0;
+      double sum[6] = {0}, nt = 0, b0 = 0;
       for (int i = 0; i < n; ++i) {
         for (int j = 0; j < 6; ++j) sum[j] += host[(i * 4 + w) * 8 + j];
         nt += host[(i * 4 + w) * 8 + 6];
+        b0 += host[(i * 4 + w) * 8 + 7];
       }
+      fprintf(stderr, "[wino24 trace] wave %d | image patch + first barrier %.0f of the prologue\n", w, b0 / nt);
       fprintf(stderr, "[wino24 trace] wave %d | per tile: prologue %.0f  chunks 8 x (barrier1 %.0f  transform %.0f  barrier2 %.0f  mfma %.0f)  "
                       "epilogue %.0f cycles  (%.0f tiles per workgroup)\n", w, sum[4] / nt, sum[0] / nt / 8, sum[1] / nt / 8, sum[2] / nt / 8,
               sum[3] / nt / 8, sum[5] / nt, nt / n);
