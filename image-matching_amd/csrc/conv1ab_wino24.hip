@@ -163,7 +163,10 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
           f32x4 d = zero4;
 #pragma unroll
           for (int ks = 0; ks < 3; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cbk][ks], bv[ks], d, 0, 0, 0);
-          d = __builtin_elementwise_max(d, zero4);
+          // ReLU on the bit pattern (a negative float is a negative int): one v_max_i32 per value; the float maximum of an MFMA
+          // result costs a canonicalising v_max x,x first (IEEE mode) -- 48 instructions per tile and wave
+          typedef int i32x4 __attribute__((ext_vector_type(4)));
+          d = __builtin_bit_cast(f32x4, __builtin_elementwise_max(__builtin_bit_cast(i32x4, d), (i32x4){0, 0, 0, 0}));
           float* o = raw + pp * RS + cbk * 16 + 4 * kq;
           *reinterpret_cast<f32x2*>(o) = (f32x2){d[0], d[1]};
           *reinterpret_cast<f32x2*>(o + 2) = (f32x2){d[2], d[3]};
