@@ -23,6 +23,7 @@
 #include "imx_kernels.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace imx {
 
@@ -175,8 +176,6 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
     }
 
     f32x4 acc[24];
-#pragma unroll
-    for (int q = 0; q < 24; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     IMX_TS(4)
 
     // ---- transform of chunk 0 (the later ones ride inside the MFMA phases)
@@ -199,8 +198,9 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
     }
     IMX_TS(1)
 
-#pragma unroll 1
-    for (int ch = 0; ch < nchunk; ++ch) {
+    const f32x4 zero4c = {0.f, 0.f, 0.f, 0.f};
+    auto phase = [&](int ch, auto first_tag) __attribute__((always_inline)) {
+      constexpr bool FIRST = decltype(first_tag)::value;
       __syncthreads();               // V[ch & 1] complete; the other buffer's readers (chunk ch-1) are done
       IMX_TS(2)
       // ---- 24 positions x 2 k-steps of v_mfma_f32_16x16x4_f32 in 12 quads (A operands: one ds_read_b128 per quad, one
@@ -226,8 +226,9 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
         for (int g = 0; g < NQ; ++g) {
           const int cur = g & 1, nxt = cur ^ 1;
           if (g + 1 < NQ) af[nxt] = *reinterpret_cast<const f32x4*>(vr + (g + 1) * QSL * 4);
-          acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][0], af[cur][0], acc[2 * g], 0, 0, 0);
-          acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][2], af[cur][2], acc[2 * g + 1], 0, 0, 0);
+          // the tile's first chunk starts from literal-zero accumulators (no 96-register clear in the prologue)
+          acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][0], af[cur][0], FIRST ? zero4c : acc[2 * g], 0, 0, 0);
+          acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][2], af[cur][2], FIRST ? zero4c : acc[2 * g + 1], 0, 0, 0);
           acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][1], af[cur][1], acc[2 * g], 0, 0, 0);
           acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][3], af[cur][3], acc[2 * g + 1], 0, 0, 0);
           bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
@@ -255,7 +256,10 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
         }
       }
       IMX_TS(3)
-    }
+    };
+    phase(0, std::true_type{});
+#pragma unroll 1
+    for (int ch = 1; ch < nchunk; ++ch) phase(ch, std::false_type{});
 
     // ---- output transform Y = A2^T M A4, 2x2 max-pool, bias, ReLU (max-pool commutes with both), stores straight from
     //      registers.  The conv1b MFMAs take U as their A operand and V as B, so D is [channel][wtile]: acc[j*4 + i][r]
