@@ -21,6 +21,7 @@
 //     them: U never touches LDS.
 // LDS 79 KB (V 2 x 13.5, conv1a patch 49.5, image patch 1).
 #include "imx_kernels.h"
+#include "wino24_pk.h"
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
   const int ra = wave == 0 ? 0 : wave == 2 ? 2 : 1, rb = wave == 0 ? 2 : wave == 1 ? 2 : wave == 2 ? 1 : 3;
   const float sg = wave == 1 ? 1.f : -1.f;
   const f32x2 sg2 = {sg, sg};
+  const f32x2 m5 = {-5.f, -5.f};
   const float* rpa = rbase + ra * RW * RS;
   const float* rpb = rbase + rb * RW * RS;
   float* vwr = V + (tk * KS + tw) * 4 + (wave >> 1) * QSL * 4 + (wave & 1) * 2;
@@ -187,12 +189,10 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
       for (int bb = 0; bb < 6; ++bb) { va[bb] = *reinterpret_cast<const f32x2*>(rpa + bb * RS); vb[bb] = *reinterpret_cast<const f32x2*>(rpb + bb * RS); }
       f32x2 o[6];
 #pragma unroll
-      for (int bb = 0; bb < 6; ++bb) o[bb] = __builtin_elementwise_fma(sg2, vb[bb], va[bb]);
-      const f32x2 e42 = o[4] - 4.f * o[2], e31 = o[3] - 4.f * o[1], f42 = o[4] - o[2], f31 = o[3] - o[1];
+      for (int bb = 0; bb < 6; ++bb) o[bb] = pk_fma(sg2, vb[bb], va[bb]);
+      const W24Half hb = w24_batch_a(o, m5);
       f32x2 T[6];
-      T[0] = 4.f * o[0] - 5.f * o[2] + o[4];
-      T[1] = e42 + e31; T[2] = e42 - e31; T[3] = f42 + 2.f * f31; T[4] = f42 - 2.f * f31;
-      T[5] = 4.f * o[1] - 5.f * o[3] + o[5];
+      w24_batch_b(o, hb, T);
 #pragma unroll
       for (int jj = 0; jj < 6; ++jj) *reinterpret_cast<f32x2*>(vwr + (2 * jj) * QSL * 4) = T[jj];
     }
@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
         const float* pa = rpa + (ch + 1) * CK;
         const float* pb = rpb + (ch + 1) * CK;
         const int uoff = __builtin_amdgcn_readfirstlane(((ch + 1) & (nchunk - 1)) * (UCH * 4));
-        f32x2 va[6], vb[6], o[6], T[6], e42, e31, f42, f31;
+        f32x2 va[6], vb[6], o[6], T[6];
+        W24Half hb;
         f32x4 af[2];
         af[0] = *reinterpret_cast<const f32x4*>(vr);
 #pragma unroll
@@ -238,15 +239,13 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
           }
           if (g == 3) {
 #pragma unroll
-            for (int bb = 0; bb < 6; ++bb) o[bb] = __builtin_elementwise_fma(sg2, vb[bb], va[bb]);   // down the rows: F(2,3), row i
+            for (int bb = 0; bb < 6; ++bb) o[bb] = pk_fma(sg2, vb[bb], va[bb]);   // down the rows: F(2,3), row i
           }
           if (g == 5) {                                                                          // along the columns: F(4,3)
-            e42 = o[4] - 4.f * o[2]; e31 = o[3] - 4.f * o[1]; f42 = o[4] - o[2]; f31 = o[3] - o[1];
-            T[0] = 4.f * o[0] - 5.f * o[2] + o[4];
+            hb = w24_batch_a(o, m5);
           }
           if (g == 7) {
-            T[1] = e42 + e31; T[2] = e42 - e31; T[3] = f42 + 2.f * f31; T[4] = f42 - 2.f * f31;
-            T[5] = 4.f * o[1] - 5.f * o[3] + o[5];
+            w24_batch_b(o, hb, T);
           }
           if (g == 9) {
 #pragma unroll

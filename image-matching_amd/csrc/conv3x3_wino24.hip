@@ -22,6 +22,7 @@
 // wave a batch of n costs ~11 + 4.5 n cycles of matrix-pipe time -- tools/ubench/mfma_valu.hip.)
 // LDS: V 2 x 13.5 KB, raw 2 x 7.5 KB = 42 KB (no output staging: see the epilogue).
 #include "imx_kernels.h"
+#include "wino24_pk.h"
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
   const int ra = wave == 0 ? 0 : wave == 2 ? 2 : 1, rb = wave == 0 ? 2 : wave == 1 ? 2 : wave == 2 ? 1 : 3;
   const float sg = wave == 1 ? 1.f : -1.f;
   const f32x2 sg2 = {sg, sg};
+  const f32x2 m5 = {-5.f, -5.f};
   const float* rpa = raw + ((2 * twr + ra) * RW + 4 * twc) * RSC + 2 * tk;
   const float* rpb = raw + ((2 * twr + rb) * RW + 4 * twc) * RSC + 2 * tk;
   float* vwr = V + (tk * KS + tw) * 4 + (wave >> 1) * QSL * 4 + (wave & 1) * 2;
@@ -161,11 +163,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
 #pragma unroll
     for (int bb = 0; bb < 6; ++bb)
       o[bb] = __builtin_elementwise_fma(sg2, *reinterpret_cast<const f32x2*>(rpb + bb * RSC), *reinterpret_cast<const f32x2*>(rpa + bb * RSC));
-    const f32x2 e42 = o[4] - 4.f * o[2], e31 = o[3] - 4.f * o[1], f42 = o[4] - o[2], f31 = o[3] - o[1];
+    const W24Half hb = w24_batch_a(o, m5);
     f32x2 T[6];
-    T[0] = 4.f * o[0] - 5.f * o[2] + o[4];
-    T[1] = e42 + e31; T[2] = e42 - e31; T[3] = f42 + 2.f * f31; T[4] = f42 - 2.f * f31;
-    T[5] = 4.f * o[1] - 5.f * o[3] + o[5];
+    w24_batch_b(o, hb, T);
 #pragma unroll
     for (int jj = 0; jj < 6; ++jj) *reinterpret_cast<f32x2*>(vwr + (2 * jj) * QSL * 4) = T[jj];
   }
@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
       float* vw = vwr + (par ^ 1) * VSZ;
       const float* pa = rpa + (par ^ 1) * RAWC;
       const float* pb = rpb + (par ^ 1) * RAWC;
-      f32x2 va[6], vb[6], o[6], T[6], e42, e31, f42, f31;
+      f32x2 va[6], vb[6], o[6], T[6];
+        W24Half hb;
       f32x4 af[2];
       af[0] = *reinterpret_cast<const f32x4*>(vr);
 #pragma unroll
@@ -213,15 +214,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
         }
         if (g == 3) {
 #pragma unroll
-          for (int bb = 0; bb < 6; ++bb) o[bb] = __builtin_elementwise_fma(sg2, vb[bb], va[bb]);   // down the rows: F(2,3), row i
+          for (int bb = 0; bb < 6; ++bb) o[bb] = pk_fma(sg2, vb[bb], va[bb]);   // down the rows: F(2,3), row i
         }
         if (g == 5) {                                                                          // along the columns: F(4,3)
-          e42 = o[4] - 4.f * o[2]; e31 = o[3] - 4.f * o[1]; f42 = o[4] - o[2]; f31 = o[3] - o[1];
-          T[0] = 4.f * o[0] - 5.f * o[2] + o[4];
+          hb = w24_batch_a(o, m5);
         }
         if (g == 7) {
-          T[1] = e42 + e31; T[2] = e42 - e31; T[3] = f42 + 2.f * f31; T[4] = f42 - 2.f * f31;
-          T[5] = 4.f * o[1] - 5.f * o[3] + o[5];
+          w24_batch_b(o, hb, T);
         }
         if (g == 9) {
 #pragma unroll
