@@ -28,7 +28,7 @@ constexpr int AS = KC + 4;        // A stage row stride (68: consecutive rows 4 
 constexpr int NTW = 128;          // columns per workgroup
 constexpr int OSN = NTW + 4;
 
-template <int K, bool RES>
+template <int K, bool RES, bool RELU>
 __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg) {
   constexpr int NC = K / KC;      // stages per tile
   constexpr int NQ = K / 16;      // operand quads over K
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         f32x4 o = v[i] + bias4;
-        if (p.relu) o = __builtin_elementwise_max(o, zero4);
+        if constexpr (RELU) o = __builtin_elementwise_max(o, zero4);      // compile-time: a run-time flag costs a v_cndmask per value
         if constexpr (RES) o = rv[i] + o;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), ors, eo[i], oso, 0);
       }
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
   }
 }
 
-template <int K, bool RES>
+template <int K, bool RES, bool RELU>
 hipError_t launch_k(const GemmArgs& a, hipStream_t s) {
   static int ncu = 0;
   if (!ncu) {
@@ -172,7 +172,7 @@ hipError_t launch_k(const GemmArgs& a, hipStream_t s) {
   if (nparts > ntile) nparts = ntile;
   if (nparts < 1) nparts = 1;
   const size_t lds = (size_t)(2 * RT * AS + RT * OSN) * sizeof(float);
-  auto k = gemm_ws<K, RES>;
+  auto k = gemm_ws<K, RES, RELU>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -195,8 +195,17 @@ bool gemm_ws_supported(const GemmArgs& a) {
 
 hipError_t launch_gemm_ws(const GemmArgs& a, hipStream_t s) {
   if (!gemm_ws_supported(a)) return hipErrorInvalidValue;
-  if (a.K0 + a.K1 == 128) return a.res ? launch_k<128, true>(a, s) : launch_k<128, false>(a, s);
-  return a.res ? launch_k<256, true>(a, s) : launch_k<256, false>(a, s);
+  const int sel = (a.K0 + a.K1 == 128 ? 0 : 4) + (a.res ? 2 : 0) + (a.relu ? 1 : 0);
+  switch (sel) {
+    case 0: return launch_k<128, false, false>(a, s);
+    case 1: return launch_k<128, false, true>(a, s);
+    case 2: return launch_k<128, true, false>(a, s);
+    case 3: return launch_k<128, true, true>(a, s);
+    case 4: return launch_k<256, false, false>(a, s);
+    case 5: return launch_k<256, false, true>(a, s);
+    case 6: return launch_k<256, true, false>(a, s);
+    default: return launch_k<256, true, true>(a, s);
+  }
 }
 
 }  // namespace imx
