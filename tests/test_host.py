@@ -224,3 +224,25 @@ def test_superglue_checkpoint_formats(tmp_path):
         assert all(torch.equal(got[k], sd[k]) for k in sd)
     with pytest.raises(KeyError):       # default 'weights': 'indoor' is truthy but the user's dict has no key (:222)
         SuperGlue({"descriptor_dim": 128, "keypoint_encoder": [32, 64, 128]})
+
+
+def test_winograd_f2x4_matrices_reproduce_the_direct_convolution():
+    """The 3x3 layers run as Winograd F(2x4,3x3) (conv1ab_wino24.hip, conv3x3_wino24.hip; U = G2 g G4^T is built in
+    imx_api.cpp).  The transform matrices those files use must satisfy  Y = A2^T [(G2 g G4^T) (.) (B2^T d B4)] A4  ==  the
+    direct 3x3 correlation of a 4x6 patch, exactly in float64 (F.conv2d semantics: no kernel flip)."""
+    rng = np.random.default_rng(0)
+    BT2 = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64)
+    G2 = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
+    AT2 = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
+    BT4 = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0],
+                    [0, 4, 0, -5, 0, 1]], dtype=np.float64)
+    G4 = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                   [0, 0, 1]], dtype=np.float64)
+    AT4 = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=np.float64)
+    for _ in range(8):
+        g, d = rng.standard_normal((3, 3)), rng.standard_normal((4, 6))
+        U = G2 @ g @ G4.T                       # 4 x 6
+        V = BT2 @ d @ BT4.T                     # 4 x 6
+        Y = AT2 @ (U * V) @ AT4.T               # 2 x 4
+        ref = np.array([[(g * d[y:y + 3, x:x + 3]).sum() for x in range(4)] for y in range(2)])
+        np.testing.assert_allclose(Y, ref, rtol=0, atol=1e-12)
