@@ -125,6 +125,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
     const int so = __builtin_amdgcn_readfirstlane(lchunk * (CK * 4));
     r0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)goff[0], so, 0));
     r1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)goff[1], so, 0));
+  };
+  auto advance_loader = [&]() {      // kept out of the MFMA stream: a branch there ends the scheduling region
     if (++lchunk == nchunk) {        // the loader moves on to this workgroup's next item (at most one item ahead of the MFMAs)
       lchunk = 0;
       litem += grid;
@@ -144,11 +146,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
 
   // ---- pipeline fill: positions 0 and 1 into raw[0] / raw[1], position 2 in flight, B panel of position 0, V[0]
   loader_item(cur, true);
-  issue_load();
+  issue_load(); advance_loader();
   store_raw(0);
-  issue_load();
+  issue_load(); advance_loader();
   store_raw(1);
-  issue_load();
+  issue_load(); advance_loader();
   f32x4 bf[NQ];
   {
     const int uoff = __builtin_amdgcn_readfirstlane(cur.cob * nchunk * (UCH * 4));
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    advance_loader();
     par ^= 1;
     IMX_TS(1)
     if (++chunk < nchunk) continue;
