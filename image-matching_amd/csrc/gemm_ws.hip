@@ -1,6 +1,6 @@
 // gemm_ws.hip — weights-stationary, persistent fp32 GEMM for the tall-and-thin products of the path:
 //   out[r][n] = act( sum_k [a0|a1][r][k] * W[k][n] + bias[n] ) (+ res[r][n]),   rows = every keypoint of every pair of the
-// batch (10^5), K = 128..256, N = 128..384: the Conv1d(k=1) projections / MLPs of superglue_test.py:49-60,92-119,214-216 and
+// batch (10^5), K = 128..512, N = 128..768: the Conv1d(k=1) projections / MLPs of superglue_test.py:49-60,92-119,214-216 and
 // convDb of superpoint_test.py:83 (BatchNorm folded, torch.cat([x, message]) as a K split).  Same contract as launch_gemm.
 //
 // Why a second form: with K this short, a tiled GEMM re-stages a K x 128 weight panel through LDS for every 128 rows and
@@ -25,11 +25,14 @@ namespace {
 constexpr int RT = 64;            // rows per tile
 constexpr int KC = 64;            // k per stage
 constexpr int AS = KC + 4;        // A stage row stride (68: consecutive rows 4 banks apart, conflict-free b128 reads)
-constexpr int NTW = 128;          // columns per workgroup
-constexpr int OSN = NTW + 4;
 
-template <int K, bool RES, bool RELU>
+// CBW = 16-column blocks per wave: 2 (128 columns per workgroup) for K <= 256; 1 (64 columns) for K = 512, where a wave's
+// weights already fill 128 registers.
+template <int K, bool RES, bool RELU, int CBW>
 __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg) {
+  constexpr int NTW = 64 * CBW;   // columns per workgroup
+  constexpr int OSN = NTW + 4;
+  constexpr int EIT = RT * (NTW / 4) / 256;      // float4 row segments per thread in the epilogue: 8 / 4
   constexpr int NC = K / KC;      // stages per tile
   constexpr int NQ = K / 16;      // operand quads over K
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -43,14 +46,14 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
   if (part >= ntile) return;
 
   // ---- this wave's weights, resident for the whole kernel: bq[cbk][quad t][j] = W[16 t + 4 kq + j][n0 + 32 wave + 16 cbk + n]
-  f32x4 bq[2][NQ];
+  f32x4 bq[CBW][NQ];
 #pragma unroll
-  for (int cbk = 0; cbk < 2; ++cbk)
+  for (int cbk = 0; cbk < CBW; ++cbk)
 #pragma unroll
     for (int t = 0; t < NQ; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        bq[cbk][t][j] = p.w[(size_t)(16 * t + 4 * kq + j) * p.Npad + n0 + 32 * wave + 16 * cbk + n];
+        bq[cbk][t][j] = p.w[(size_t)(16 * t + 4 * kq + j) * p.Npad + n0 + 16 * CBW * wave + 16 * cbk + n];
 
   // ---- loader: a stage is 64 rows x 16 float4; thread -> rows tid/16 + 16 it (it = 0..3), float4 tid % 16
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a0, 0, p.M * p.lda0 * 4, 0x00020000);
@@ -81,14 +84,15 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
 
   // epilogue: thread -> column quad tid % 32 (fixed), rows tid/32 + 8 i.  Residual loads and stores are buffer operations
   // over M rows: rows past M read zeros / are dropped by the hardware, so the epilogue is branch free too
-  const int c4 = (tid & 31) * 4, erow = tid >> 5;
+  const int c4 = (tid % (NTW / 4)) * 4, erow = tid / (NTW / 4);
+  constexpr int ERS = 256 / (NTW / 4);           // rows per epilogue pass: 8 / 16
   const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.M * p.ldo * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? p.res : p.out), 0, p.M * (RES ? p.ldr : p.ldo) * 4, 0x00020000);
-  int eo[8], er[8];
+  int eo[EIT], er[EIT];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    eo[i] = ((erow + 8 * i) * p.ldo + n0 + c4) * 4;
-    er[i] = ((erow + 8 * i) * (RES ? p.ldr : p.ldo) + n0 + c4) * 4;
+  for (int i = 0; i < EIT; ++i) {
+    eo[i] = ((erow + ERS * i) * p.ldo + n0 + c4) * 4;
+    er[i] = ((erow + ERS * i) * (RES ? p.ldr : p.ldo) + n0 + c4) * 4;
   }
   const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + c4);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -102,11 +106,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
   const int aoff = n * AS + 4 * kq;          // A operand of row block rb, quad t: As[(16 rb + n) * AS + 16 t + 4 kq]
 
   for (int tile = part; tile < ntile; tile += nparts) {
-    f32x4 acc[4][2];
+    f32x4 acc[4][CBW];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-      for (int cbk = 0; cbk < 2; ++cbk) acc[rb][cbk] = zero4;
+      for (int cbk = 0; cbk < CBW; ++cbk) acc[rb][cbk] = zero4;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       __syncthreads();             // stage `par` complete; the other buffer's readers are done
@@ -117,10 +121,10 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
         for (int t = 0; t < KC / 16; ++t) {
           const f32x4 a4 = *reinterpret_cast<const f32x4*>(ab + rb * 16 * AS + 16 * t);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc[rb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bq[0][c * (KC / 16) + t][j], acc[rb][0], 0, 0, 0);
-            acc[rb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bq[1][c * (KC / 16) + t][j], acc[rb][1], 0, 0, 0);
-          }
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int cbk = 0; cbk < CBW; ++cbk)
+              acc[rb][cbk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bq[cbk][c * (KC / 16) + t][j], acc[rb][cbk], 0, 0, 0);
           if (rb == 0 && t == 1) {   // the next stage: registers -> the idle buffer, then fetch the stage after it
             store_stage(par ^ 1);
             issue_load();
@@ -134,21 +138,21 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-      for (int cbk = 0; cbk < 2; ++cbk)
+      for (int cbk = 0; cbk < CBW; ++cbk)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ot[(16 * rb + 4 * kq + r) * OSN + 32 * wave + 16 * cbk + n] = acc[rb][cbk][r];
+        for (int r = 0; r < 4; ++r) Ot[(16 * rb + 4 * kq + r) * OSN + 16 * CBW * wave + 16 * cbk + n] = acc[rb][cbk][r];
     __syncthreads();
     {
       const int oso = __builtin_amdgcn_readfirstlane(tile * RT * p.ldo * 4);
       const int rso = __builtin_amdgcn_readfirstlane(tile * RT * (RES ? p.ldr : p.ldo) * 4);
-      f32x4 v[8], rv[8];
+      f32x4 v[EIT], rv[EIT];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < EIT; ++i) {
         if constexpr (RES) rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, er[i], rso, 0));
-        v[i] = *reinterpret_cast<const f32x4*>(Ot + (erow + 8 * i) * OSN + c4);
+        v[i] = *reinterpret_cast<const f32x4*>(Ot + (erow + ERS * i) * OSN + c4);
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < EIT; ++i) {
         f32x4 o = v[i] + bias4;
         if constexpr (RELU) o = __builtin_elementwise_max(o, zero4);      // compile-time: a run-time flag costs a v_cndmask per value
         if constexpr (RES) o = rv[i] + o;
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
   }
 }
 
-template <int K, bool RES, bool RELU>
+template <int K, bool RES, bool RELU, int CBW>
 hipError_t launch_k(const GemmArgs& a, hipStream_t s) {
   static int ncu = 0;
   if (!ncu) {
@@ -167,12 +171,13 @@ hipError_t launch_k(const GemmArgs& a, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
     ncu = prop.multiProcessorCount;
   }
+  constexpr int NTW = 64 * CBW, OSN = NTW + 4;
   const int ntile = (a.M + RT - 1) / RT, ncg = a.Npad / NTW;
   int nparts = 2 * ncu / ncg;
   if (nparts > ntile) nparts = ntile;
   if (nparts < 1) nparts = 1;
   const size_t lds = (size_t)(2 * RT * AS + RT * OSN) * sizeof(float);
-  auto k = gemm_ws<K, RES, RELU>;
+  auto k = gemm_ws<K, RES, RELU, CBW>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -185,8 +190,8 @@ hipError_t launch_k(const GemmArgs& a, hipStream_t s) {
 
 bool gemm_ws_supported(const GemmArgs& a) {
   const int K = a.K0 + a.K1;
-  if (K != 128 && K != 256) return false;
-  if (a.K0 % KC || a.K1 % KC || a.Npad % NTW || a.N != a.Npad || !a.bias) return false;
+  if (K != 128 && K != 256 && K != 512) return false;
+  if (a.K0 % KC || a.K1 % KC || a.Npad % (K == 512 ? 64 : 128) || a.N != a.Npad || !a.bias) return false;
   if ((a.ldo & 3) || (a.res && (a.ldr & 3)) || (a.lda0 & 3) || (a.a1 && (a.lda1 & 3))) return false;
   const int ldmax = std::max(std::max(a.lda0, a.a1 ? a.lda1 : 0), std::max(a.ldo, a.res ? a.ldr : 0));
   if ((size_t)a.M * (size_t)ldmax * 4 >= 0x7fffffffull) return false;    // 31-bit buffer offsets
@@ -195,17 +200,18 @@ bool gemm_ws_supported(const GemmArgs& a) {
 
 hipError_t launch_gemm_ws(const GemmArgs& a, hipStream_t s) {
   if (!gemm_ws_supported(a)) return hipErrorInvalidValue;
-  const int sel = (a.K0 + a.K1 == 128 ? 0 : 4) + (a.res ? 2 : 0) + (a.relu ? 1 : 0);
-  switch (sel) {
-    case 0: return launch_k<128, false, false>(a, s);
-    case 1: return launch_k<128, false, true>(a, s);
-    case 2: return launch_k<128, true, false>(a, s);
-    case 3: return launch_k<128, true, true>(a, s);
-    case 4: return launch_k<256, false, false>(a, s);
-    case 5: return launch_k<256, false, true>(a, s);
-    case 6: return launch_k<256, true, false>(a, s);
-    default: return launch_k<256, true, true>(a, s);
+  const int K = a.K0 + a.K1, sel = (a.res ? 2 : 0) + (a.relu ? 1 : 0);
+#define IMX_WS(K_, CBW_)                                                  \
+  switch (sel) {                                                          \
+    case 0: return launch_k<K_, false, false, CBW_>(a, s);                \
+    case 1: return launch_k<K_, false, true, CBW_>(a, s);                 \
+    case 2: return launch_k<K_, true, false, CBW_>(a, s);                 \
+    default: return launch_k<K_, true, true, CBW_>(a, s);                 \
   }
+  if (K == 128) { IMX_WS(128, 2) }
+  if (K == 256) { IMX_WS(256, 2) }
+  IMX_WS(512, 1)
+#undef IMX_WS
 }
 
 }  // namespace imx

@@ -51,7 +51,8 @@ struct GemmArgs {
 };
 // (K0, K1) % 32 == 0.
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
-// weights-stationary persistent form (gemm_ws.hip): K in {128, 256}, N == Npad, Npad % 128 == 0, float4-aligned leading dims
+// weights-stationary persistent form (gemm_ws.hip): K in {128, 256} with Npad % 128 == 0 or K == 512 with Npad % 64 == 0; N == Npad,
+// float4-aligned leading dimensions
 bool gemm_ws_supported(const GemmArgs& a);
 hipError_t launch_gemm_ws(const GemmArgs& a, hipStream_t s);
 
