@@ -319,6 +319,8 @@ __global__ __launch_bounds__(1024) void sinkhorn_vmerge(SinkhornArgs a, const fl
   counts(a, b, m, n);
   if (m == 0 || n == 0) return;
   const int nslab = m / R + 1;
+  // two-pass merges: the maximum of the (max, sum) pairs first, then ONE exp per pair -- a chain of pairwise lse_merge()
+  // spends two exps (quarter-rate instructions) and two selects per pair
   LSE t{-INFINITY, 0.f};
   if (j <= n) {
     const float2* pb = reinterpret_cast<const float2*>(part + (size_t)b * nslab_max * (a.N1p + 1) * 2) + j;
@@ -329,16 +331,28 @@ __global__ __launch_bounds__(1024) void sinkhorn_vmerge(SinkhornArgs a, const fl
         const int sl = s0 + 16 * k;
         q[k] = sl < nslab ? pb[(size_t)sl * (a.N1p + 1)] : make_float2(-INFINITY, 0.f);
       }
+      const float nm = fmaxf(fmaxf(t.m, fmaxf(q[0].x, q[1].x)), fmaxf(q[2].x, q[3].x));
+      if (nm > -INFINITY) {
+        const float ml = -nm * LOG2E;
+        float sum = t.s * __builtin_amdgcn_exp2f(fmaf(t.m, LOG2E, ml));          // exp2(-inf) = 0 for an empty accumulator
 #pragma unroll
-      for (int k = 0; k < 4; ++k) t = lse_merge(t, LSE{q[k].x, q[k].y});
+        for (int k = 0; k < 4; ++k) sum = fmaf(q[k].y, __builtin_amdgcn_exp2f(fmaf(q[k].x, LOG2E, ml)), sum);
+        t = LSE{nm, sum};
+      }
     }
   }
   pm[g][c] = t.m;
   ps[g][c] = t.s;
   __syncthreads();
   if (g == 0 && j <= n) {
+    float nm = pm[0][c];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) t = lse_merge(t, LSE{pm[k][c], ps[k][c]});
+    for (int k = 1; k < 16; ++k) nm = fmaxf(nm, pm[k][c]);
+    const float ml = -nm * LOG2E;                                                  // finite: slab 0 always contributes
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum = fmaf(ps[k][c], __builtin_amdgcn_exp2f(fmaf(pm[k][c], LOG2E, ml)), sum);
+    t = LSE{nm, sum};
     const float norm = -logf((float)(m + n));
     const float log_nu = j < n ? norm : logf((float)m) + norm;
     a.v[(size_t)b * (a.N1p + 1) + j] = log_nu - lse_value(t);
