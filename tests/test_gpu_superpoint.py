@@ -196,3 +196,16 @@ def test_every_conv_kernel_variant_vs_reference_golden(mode, monkeypatch):
                        [g["descriptors0"], g["descriptors1"]])
         util.assert_close(_nchw(eng.fetch("x4")), g["x4"], f"x4 ({mode})")
         util.assert_close(_nchw(eng.fetch("semi")), g["semi"], f"semi ({mode})")
+
+
+@pytest.mark.parametrize("radius", [1, 2, 3, 4, 6])
+def test_nms_every_radius_bit_exact_vs_oracle(radius):
+    """simple_nms is compare-only, so the kernels (register-strip form for radius <= 4, generic form above) must reproduce
+    the oracle bit for bit on the reference's own score map, for every --nms_radius, on partial tiles too."""
+    from oracle import superpoint_ref
+    g = util.golden("sp_ragged.npz")
+    eng, L = _engine(128, -1)
+    sm = torch.from_numpy(g["score_map"])
+    out = eng.op_nms(sm, radius).cpu().numpy()
+    ref = superpoint_ref.simple_nms(sm, radius).numpy()
+    assert np.array_equal(out, ref), f"radius {radius}: {(out != ref).sum()} pixels differ"
