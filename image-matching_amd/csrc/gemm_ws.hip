@@ -41,7 +41,19 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, kq = lane >> 4;
-  const int cg = (int)blockIdx.x % ncg, part = (int)blockIdx.x / ncg, nparts = (int)gridDim.x / ncg;
+  // XCD-aware placement: workgroups are dispatched round-robin over the 8 XCDs.  The ncg column groups of one row partition
+  // stream the same A rows, so they sit on ONE XCD (same L2), next to each other in dispatch order: A is fetched from HBM once
+  // instead of ncg times (nparts is a multiple of 8 whenever it is at least 8)
+  const int nparts = (int)gridDim.x / ncg;
+  int cg, part;
+  if ((nparts & 7) == 0) {
+    const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+    cg = q % ncg;
+    part = (q / ncg) * 8 + xcd;
+  } else {
+    cg = (int)blockIdx.x % ncg;
+    part = (int)blockIdx.x / ncg;
+  }
   const int n0 = cg * NTW;
   if (part >= ntile) return;
 
@@ -175,6 +187,7 @@ hipError_t launch_k(const GemmArgs& a, hipStream_t s) {
   const int ntile = (a.M + RT - 1) / RT, ncg = a.Npad / NTW;
   int nparts = 2 * ncu / ncg;
   if (nparts > ntile) nparts = ntile;
+  if (nparts >= 8) nparts &= ~7;             // multiple of 8: XCD-aware placement (see the kernel)
   if (nparts < 1) nparts = 1;
   const size_t lds = (size_t)(2 * RT * AS + RT * OSN) * sizeof(float);
   auto k = gemm_ws<K, RES, RELU, CBW>;
