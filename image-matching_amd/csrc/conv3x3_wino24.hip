@@ -66,7 +66,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
   const int H = p.H, W = p.W, Cin = p.Cin, Cout = p.Cout;
   const int nchunk = Cin / CK, ncob = Cout / NT;
   const int grid = (int)gridDim.x;
-  if ((int)blockIdx.x >= nitems) return;
+  // XCD-aware start index: workgroups are dispatched round-robin over the 8 XCDs; virtual index vb makes consecutive items
+  // (the output blocks of one tile, neighbouring tiles) land on ONE XCD in adjacent dispatch slots, so a tile's input patch is
+  // fetched from HBM once and re-read from that L2 by its other output blocks
+  const int vb = (grid & 7) == 0 ? ((int)blockIdx.x & 7) * (grid >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  if (vb >= nitems) return;
   const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.wu24, 0, ncob * nchunk * UCH * 4, 0x00020000);
   const int voff = (cb * 64 + lane) * 16;
   const int img_bytes = H * W * Cin * 4;
@@ -106,8 +110,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
     r.b = tile / (tiles_x * tiles_y);
     return r;
   };
-  Item cur = decode((int)blockIdx.x), nxt = cur;
-  int item_c = (int)blockIdx.x;
+  Item cur = decode(vb), nxt = cur;
+  int item_c = vb;
   // loader cursor
   int litem = item_c, lchunk = 0;
   __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
