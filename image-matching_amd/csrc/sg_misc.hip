@@ -177,19 +177,19 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
       // The segment (<= 1024 columns) is one batch of four float4 per lane, so the row's values sit in registers and the
       // log-sum-exp can be the two-pass form (exact maximum first, then ONE fma + v_exp per element) instead of the
       // online form's ~8 VALU per element; the maximum is wave-wide, as in torch.logsumexp.
-      if (W == 1 && a.N1p == 1024 && n == 1024) {
-        // Fast path (uniform): the row is exactly one wave batch with every column real (the saturated max_keypoints case):
+      if (seglen == 1024 && n == a.N1p) {
+        // Fast path (uniform): this wave's segment is exactly one batch with every column real (the saturated max_keypoints case):
         // no bounds or count masks, and the adds / fmas / partial sums as packed f32x4 operations -- on this SIMD every VALU
         // instruction costs matrix-pipe-free but real issue time, and the masked form spends a third of its instructions on
         // compares and selects.
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4 x[4], t4[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = *reinterpret_cast<const f32x4*>(Srow + k * 256 + lane * 4);
+        for (int k = 0; k < 4; ++k) x[k] = *reinterpret_cast<const f32x4*>(Srow + jlo + k * 256 + lane * 4);
         float mx = -INFINITY;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int j = k * 256 + lane * 4;
+          const int j = jlo + k * 256 + lane * 4;
           *reinterpret_cast<f32x4*>(trow + j) = x[k];
           t4[k] = x[k] + *reinterpret_cast<const f32x4*>(vs + j);
           mx = fmaxf(fmaxf(mx, fmaxf(t4[k][0], t4[k][1])), fmaxf(t4[k][2], t4[k][3]));
@@ -265,17 +265,19 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
   __syncthreads();
   const int rows = min(R, m + 1 - i0);      // rows of this slab, the last may be the dustbin row
   float2* pb = reinterpret_cast<float2*>(part + ((size_t)b * nslab_max + slab) * (a.N1p + 1) * 2);
-  if (rows == R && a.N1p == 1024 && n == 1024) {
-    // Fast path (uniform): a full slab of real rows over 1024 real columns -- no masks; the dustbin column (j = n) is left to
+  const bool fastcol = rows == R && n == a.N1p;
+  if (fastcol) {
+    // Fast path (uniform): a full slab of real rows, every column real -- no masks; the dustbin column (j = n) is left to
     // the generic loop below, which then runs for one thread only
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     static_assert(R % 4 == 0, "slab rows in groups of four");
-    for (int j = tid; j < 1024; j += 64 * NW) {
+    const int ld = a.N1p;
+    for (int j = tid; j < n; j += 64 * NW) {
       f32x4 t4[R / 4];
       float mx = -INFINITY;
 #pragma unroll
       for (int q = 0; q < R / 4; ++q) {
-        t4[q] = (f32x4){tile[(4 * q + 0) * 1024 + j], tile[(4 * q + 1) * 1024 + j], tile[(4 * q + 2) * 1024 + j], tile[(4 * q + 3) * 1024 + j]} +
+        t4[q] = (f32x4){tile[(4 * q + 0) * ld + j], tile[(4 * q + 1) * ld + j], tile[(4 * q + 2) * ld + j], tile[(4 * q + 3) * ld + j]} +
                 (f32x4){uu[4 * q + 0], uu[4 * q + 1], uu[4 * q + 2], uu[4 * q + 3]};
         mx = fmaxf(fmaxf(mx, fmaxf(t4[q][0], t4[q][1])), fmaxf(t4[q][2], t4[q][3]));
       }
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
       pb[j] = make_float2(mx, (s4[0] + s4[1]) + (s4[2] + s4[3]));
     }
   }
-  for (int j = (rows == R && a.N1p == 1024 && n == 1024) ? n + tid : tid; j <= n; j += 64 * NW) {
+  for (int j = fastcol ? n + tid : tid; j <= n; j += 64 * NW) {
     float t[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) t[r] = tile[r * a.N1p + j];          // rows beyond `rows` hold stale data, masked below
