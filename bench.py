@@ -12,11 +12,17 @@ Workload = BASELINE.json configs[2]/[3] shape ("C3"): 640x480 grayscale, d=128, 
 30 Sinkhorn iterations, synthetic BN-calibrated weights (no trained weights exist: LFS pointers).
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
-  "roofline":     dominant kernel's achieved algorithmic FLOP/s (or B/s) vs the gfx950 peak, from
-                  per-launch HIP events on the launch stream over a second, instrumented pass of
-                  the same K steps;
+  "roofline":     the dominant kernel against the gfx950 peak, from per-launch HIP events on the launch stream
+                  over a second, instrumented pass of the same K steps.  `achieved`/`frac` are the rate the
+                  matrix cores actually EXECUTE (never above 1); where a kernel executes fewer multiplies than
+                  the reference's direct-form count (Winograd F(2x4,3x3): 3x fewer) the algorithmic rate is
+                  reported next to it under `algorithmic`.  `executed_pair_frac` is the whole-pair view.
+                  `traffic` comes from rocprofv3 PMC passes (profiles/r02_pmc_traffic.json) and is dropped when
+                  that file was measured on a different library build than the one being timed;
+  "latency_b1_ms":          Matching.forward on ONE pair (BASELINE configs[2]), median of 50 synchronised calls;
+  "pcie_inclusive_pairs_s": the same step fed from uint8 frames in pinned host memory (never `value`);
   "cpu_baseline": the oracle (CPU restatement of the reference, torch CPU ops) timed on this
-                  host's cores on a bounded sample of the same workload.
+                  host's cores on a bounded sample of the same workload, best of a thread-count sweep.
 """
 import argparse
 import json
@@ -85,6 +91,36 @@ def algorithmic_work(B, H, W, d, K, kenc, iters, n_layers=18):
     return w
 
 
+def executed_work(B, H, W, d, K, kenc, iters, n_layers=18):
+    """FLOPs the matrix cores EXECUTE per launch (MFMA kernels only), as the kernels are written:
+      3x3 layers     Winograd F(2x4,3x3): 24 multiplies per 8 outputs (direct: 72) over whole 8x16-pixel tiles;
+      conv1a         inside the fused first layer, as a GEMM on the matrix cores over each tile's halo: 144
+                     v_mfma_f32_16x16x4 (2048 FLOP each) per 8x16-pixel tile (36 per wave, conv1ab_wino24.hip);
+      1x1 convs      output columns padded to 64 (convPb: 65 -> 128);
+      gnn_mlp1       attn.merge is folded into mlp.0's weights at load: its d*d product is not executed;
+      attention      as counted (N is a multiple of the 128-query block at C3/C5)."""
+    I = 2 * B
+    R = 2 * B * K
+    up = lambda a, b: (a + b - 1) // b
+    tiles = lambda h, w: up(h, 8) * up(w, 16)
+    conv = lambda h, w, cin, cout: 2.0 * I * tiles(h, w) * 128 * 9 * cin * cout / 3.0
+    H2, W2, H4, W4, Hc, Wc = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8
+    pad64 = lambda n: up(n, 64) * 64
+    ex = {
+        "conv1ab_pool": conv(H, W, 64, 64) + I * tiles(H, W) * 144 * 2048.0,
+        "conv2a": conv(H2, W2, 64, 64), "conv2b_pool": conv(H2, W2, 64, 64),
+        "conv3a": conv(H4, W4, 64, 128), "conv3b_pool": conv(H4, W4, 128, 128),
+        "conv4a": conv(Hc, Wc, 128, 128), "conv4b": conv(Hc, Wc, 128, 128), "convPaDa": conv(Hc, Wc, 128, 512),
+        "convPb": 2.0 * I * Hc * Wc * 256 * pad64(65), "convDb": 2.0 * I * Hc * Wc * 256 * pad64(d),
+        "qkv_proj": 2.0 * R * d * 3 * d, "attention": 2.0 * 2 * B * 2 * K * K * d,
+        "gnn_mlp1": 2.0 * R * 2 * d * 2 * d, "gnn_mlp2": 2.0 * R * 2 * d * d,
+        "final_proj": 2.0 * R * d * d, "score_gemm": 2.0 * B * K * K * d,
+    }
+    ch = list(kenc) + [d]
+    ex["kenc"] = 2.0 * R * sum(ch[i] * ch[i + 1] for i in range(len(ch) - 1)) / (len(ch) - 1)
+    return ex
+
+
 def build_matching(wl, device):
     d, K = wl["d"], wl["K"]
     kenc, iters, thr = synth.SG_CONFIGS[d]
@@ -100,31 +136,97 @@ def build_matching(wl, device):
     return m, cfg, sd_sp, sd_sg
 
 
-def cpu_baseline(wl, cfg, sd_sp, sd_sg, budget_s=20.0, max_pairs=16):
-    """The oracle (port of the reference's PyTorch CPU forward) on this host's cores."""
+def cpu_baseline(wl, cfg, sd_sp, sd_sg, budget_s=30.0):
+    """The oracle (port of the reference's PyTorch CPU forward) on this host's cores.  More threads are not better
+    for this model (128 threads: 0.32 pairs/s in round 1, slower than 8 threads in the survey container), so the
+    thread count is swept and the best one is reported: per count one warm-up pair + the median of up to 3 pairs,
+    ~30 s in total."""
     from oracle import matching_ref            # checker code: used here only as the CPU baseline leg
     try:
         avail = len(os.sched_getaffinity(0))       # cores this process may run on (cgroup/affinity aware)
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, torch.get_num_threads()))
-    torch.set_num_threads(cores)
-    times = []
-    t_all = time.perf_counter()
-    for i in range(max_pairs + 1):
-        im0, im1 = synth.synth_pair(1000 + i, wl["H"], wl["W"])
-        x0, x1 = torch.from_numpy(im0)[None, None], torch.from_numpy(im1)[None, None]
-        t = time.perf_counter()
-        matching_ref.matching_forward({"image0": x0, "image1": x1}, sd_sp, sd_sg, cfg)
-        dt = time.perf_counter() - t
-        if i > 0:                              # first pair = warm-up
-            times.append(dt)
-        if time.perf_counter() - t_all > budget_s and len(times) >= 3:
+    counts = sorted({c for c in (8, 16, 32, 64, avail) if c <= avail} or {avail})
+    pairs = [tuple(torch.from_numpy(a)[None, None] for a in synth.synth_pair(1000 + i, wl["H"], wl["W"])) for i in range(4)]
+    t_all, sweep, best = time.perf_counter(), {}, None
+    for c in counts:
+        torch.set_num_threads(c)
+        times = []
+        for i, (x0, x1) in enumerate(pairs):
+            t = time.perf_counter()
+            matching_ref.matching_forward({"image0": x0, "image1": x1}, sd_sp, sd_sg, cfg)
+            if i > 0:                              # first pair at this thread count = warm-up
+                times.append(time.perf_counter() - t)
+            if time.perf_counter() - t_all > budget_s and times:
+                break
+        med = float(np.median(times))
+        sweep[str(c)] = round(1.0 / med, 4)
+        if best is None or med < best[1]:
+            best = (c, med, len(times))
+        if time.perf_counter() - t_all > budget_s:
             break
-    med = float(np.median(times))
-    return {"value": round(1.0 / med, 4), "unit": "image-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"median of {len(times)} pairs after 1 warm-up, {wl['H']}x{wl['W']}, torch {torch.__version__} CPU, "
-                      f"{torch.get_num_threads()} threads"}
+    c, med, n = best
+    return {"value": round(1.0 / med, 4), "unit": "image-pairs/s", "cores": c, "kind": "port",
+            "sample": f"best of a thread sweep {sweep} (pairs/s by thread count; {avail} cores available); median of {n} pairs "
+                      f"after 1 warm-up per count, {wl['H']}x{wl['W']}, torch {torch.__version__} CPU"}
+
+
+def latency_b1(matching, wl, device, n=50):
+    """BASELINE configs[2] ("single pair"): the drop-in Matching.forward on ONE pair, host-synchronised per call."""
+    im0, im1 = synth.synth_pair(7, wl["H"], wl["W"])
+    data = {"image0": torch.from_numpy(im0)[None, None].to(device), "image1": torch.from_numpy(im1)[None, None].to(device)}
+    for _ in range(5):
+        matching(data)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        t = time.perf_counter()
+        matching(data)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t)
+    return round(1e3 * float(np.median(ts)), 4)
+
+
+def pcie_inclusive(matching, wl, B, steps=6, scale=0.5):
+    """The step fed across PCIe: decoded uint8 frames (2x the network resolution, resize_scale 0.5 as in
+    datasets/SSHIDataset.py:19-27) sit in the pinned staging buffers of IngestPipeline; per step they are copied
+    host->device on a side stream, resized + /255 on the GPU (imx_ingest_resize_u8) and matched.  Reported, never `value`."""
+    from image_matching_amd import hostops
+    from image_matching_amd.ingest import IngestPipeline
+    H, W = wl["H"], wl["W"]
+    Hs, Ws = int(round(H / scale)), int(round(W / scale))
+    eng = matching._shared.get_engine([0, 1])
+    pipes = [IngestPipeline(eng, B, (Hs, Ws), (H, W)) for _ in range(2)]
+    frames = [[], []]
+    for i in range(min(B, 8)):                    # 8 distinct pairs, tiled over the batch (host-side synthesis is slow)
+        im = synth.synth_pair(2000 + i, H, W)
+        for s in range(2):
+            frames[s].append(hostops.resize_linear_u8((im[s] * 255).astype(np.uint8), (Ws, Hs)))
+    for s in range(2):
+        stack = torch.from_numpy(np.stack([frames[s][i % len(frames[s])] for i in range(B)]))
+        for slot in pipes[s].slots:
+            slot["pinned"].copy_(stack)
+
+    def ship():
+        pipes[0].staging(), pipes[1].staging()
+        return pipes[0].submit_staged(B), pipes[1].submit_staged(B)
+
+    def run(n):
+        t = ship()
+        for k in range(n):             # match(k) is enqueued before batch k+1 is shipped: the copy overlaps the match
+            out = matching.match_batch(pipes[0].take(t[0]), pipes[1].take(t[1]))
+            pipes[0].release(t[0]), pipes[1].release(t[1])
+            t = ship() if k + 1 < n else None
+        torch.cuda.synchronize()
+        return out
+    run(2)
+    t0 = time.perf_counter()
+    out = run(steps)
+    dt = time.perf_counter() - t0
+    assert int((out["matches0"] > -1).sum()) > 0
+    return {"value": round(B * steps / dt, 3), "unit": "image-pairs/s", "frame": [Hs, Ws], "resize_scale": scale,
+            "pairs_per_step": B, "steps": steps, "h2d_GBps": round(2 * B * Hs * Ws * steps / dt / 1e9, 3),
+            "note": "uint8 frames already in pinned staging buffers -> async H2D + GPU resize/255 -> imx_match_pairs"}
 
 
 def log(msg):
@@ -141,6 +243,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-pass", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip latency_b1_ms / pcie_inclusive_pairs_s")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,8 +288,9 @@ def main():
             kp, sc, ds, cnt = eng.superpoint_batch(img01)
             return {"counts0": cnt[:B], "counts1": cnt[B:], "matches0": cnt.new_zeros(1) + 1}, torch.zeros(world * B, 1)
         out = matching.match_batch(img0, img1)
-        rec = shard.pack_records(pair_ids, out)
-        return out, shard.gather_records(rec, force=use_pg)
+        rec = shard.pack_records(pair_ids, out, pad_to=shard.shard_rows(world * B, world))
+        # the ONE collective of the path: RCCL gather of the records to rank 0 (shards equal by construction: check=False)
+        return out, shard.gather_records(rec, force=use_pg, check=False)
 
     def barrier():
         if use_pg:
@@ -218,9 +322,9 @@ def main():
     # harness checks: every image yields exactly K keypoints; the gather holds every pair once
     c0, c1 = out["counts0"].cpu().numpy(), out["counts1"].cpu().numpy()
     assert (c0 == K).all() and (c1 == K).all(), f"keypoint counts != {K}: {c0} {c1}"
-    if not sp_only:
+    if not sp_only and rank == 0:
         assert rec.shape == (world * B, shard.record_width(K))
-        assert sorted(rec[:, 0].long().cpu().tolist()) == list(range(world * B))
+        assert sorted(shard.pair_ids_of(rec).cpu().tolist()) == list(range(world * B))
     n_matches = int((out["matches0"] > -1).sum().item())
     assert n_matches > 0
 
@@ -234,7 +338,7 @@ def main():
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B,
-                   "parallelism": f"pair-sharded x{world}" + (" + RCCL all_gather of match records" if world > 1 else ""),
+                   "parallelism": f"pair-sharded x{world}" + (" + RCCL gather of match records to rank 0" if world > 1 else ""),
                    "weights": "synthetic, BN-calibrated (synth.py seeds 123/456)", "matches_per_pair": round(n_matches / B, 1)},
     }
 
@@ -258,40 +362,64 @@ def main():
     if rows:
         kenc, iters, _ = synth.SG_CONFIGS[d]
         work = algorithmic_work(B, H, W, d, K, kenc, iters)
+        exe = executed_work(B, H, W, d, K, kenc, iters)
+        direct = os.environ.get("IMX_CONV", "") == "direct"
+        if direct:                      # A/B run on the direct-form kernels: executed == algorithmic for the 3x3 layers
+            exe.update({k: v[1] for k, v in work.items() if k.startswith("conv") and k not in ("convPb", "convDb")})
         tot_ms = sum(r[2] for r in rows)
         name, launches, ms = max(rows, key=lambda r: r[2])
         bound, units = work[name]
         avg_s = ms / launches * 1e-3
+        lib_build = matching._shared.engine.lib.imx_version().decode()
         if bound == "mfma":
-            achieved, peak, unit = units / avg_s / 1e12, PEAK_MFMA_F32_TFLOPS, "TFLOP/s"
+            algorithmic, peak, unit = units / avg_s / 1e12, PEAK_MFMA_F32_TFLOPS, "TFLOP/s"
+            achieved = exe[name] / avg_s / 1e12          # what the matrix cores execute: the rate the MFMA roofline bounds
         else:
-            achieved, peak, unit = units / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
-        traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (offline; profiles/r01_pmc_traffic.json)
+            algorithmic, peak, unit = units / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
+            achieved = algorithmic
+        traffic, traffic_note = None, None   # HBM bytes per launch from rocprofv3 PMC passes (tools/pmc_traffic.py -> profiles/)
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
-            if args.workload == "c3" and name in pmc["kernels"]:      # measured at pmc["pairs_per_gpu"]; the kernel's traffic is
-                traffic = pmc["kernels"][name]["traffic_bytes"] * B / pmc["pairs_per_gpu"]      # per image: linear in B
+            if pmc.get("build") != lib_build:
+                traffic_note = f"dropped: PMC passes were taken on build {pmc.get('build')!r}, this run is {lib_build!r}"
+            elif args.workload == "c3" and name in pmc["kernels"]:     # measured at pmc["pairs_per_gpu"]; per-image work: linear in B
+                traffic = pmc["kernels"][name]["traffic_bytes"] * B / pmc["pairs_per_gpu"]
         except (OSError, ValueError, KeyError):
-            pass
+            traffic_note = "no PMC traffic file for this round"
         line["roofline"] = {"bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
                             "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": name,
-                            "avg_launch_ms": round(ms / launches, 4), "share_of_gpu_time": round(ms / tot_ms, 4)}
-        if bound == "mfma" and name.startswith("conv") and name not in ("convPb", "convDb") \
-                and os.environ.get("IMX_CONV", "auto") == "auto":
-            # the 3x3 layers run as Winograd F(2x4,3x3) (IMX_CONV1 / IMX_CONVN = f22: F(2x2,3x3)): the matrix cores execute
-            # 3x (2.25x) fewer multiplies than the algorithmic (direct-form) count `achieved` is defined on -- report the
-            # executed rate next to it
-            f22 = os.environ.get("IMX_CONV1" if name == "conv1ab_pool" else "IMX_CONVN", "") == "f22"
-            red = 2.25 if f22 else 3.0
-            line["roofline"]["executed"] = {"tflops": round(achieved / red, 3), "frac": round(achieved / red / peak, 4),
-                                            "note": ("Winograd F(2x2,3x3): 16 multiplies per 4 outputs instead of 36" if f22 else
-                                                     "Winograd F(2x4,3x3): 24 multiplies per 8 outputs instead of 72")}
-        # whole-pair view: algorithmic dense FLOPs of the step / measured step time vs the fp32 MFMA peak
+                            "avg_launch_ms": round(ms / launches, 4), "share_of_gpu_time": round(ms / tot_ms, 4), "build": lib_build}
+        if traffic_note:
+            line["roofline"]["traffic_note"] = traffic_note
+        if abs(algorithmic - achieved) > 1e-9:
+            line["roofline"]["algorithmic"] = {
+                "rate": round(algorithmic, 3), "ratio_to_peak": round(algorithmic / peak, 4),
+                "note": "reference direct-form FLOPs / launch time; the kernel executes fewer multiplies (Winograd F(2x4,3x3)), "
+                        "so this ratio may exceed 1 and is NOT a utilisation"}
+        # whole-pair view: FLOPs the matrix cores execute per step / measured step time vs the fp32 MFMA peak
         per_step = {r[0]: r[1] / args.steps for r in rows}          # launches per step
-        flops_step = sum(u * per_step.get(k, 0.0) for k, (bd, u) in work.items() if bd == "mfma")
-        line["roofline"]["pair_mfma_frac"] = round(flops_step / (dt / args.steps) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)
-        line["roofline"]["kernels"] = {r[0]: {"launches": r[1], "ms_per_step": round(r[2] / args.steps, 4)} for r in rows}
+        step_s = dt / args.steps
+        exe_step = sum(u * per_step.get(k, 0.0) for k, u in exe.items())
+        alg_step = sum(u * per_step.get(k, 0.0) for k, (bd, u) in work.items() if bd == "mfma")
+        line["roofline"]["executed_pair_frac"] = round(exe_step / step_s / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)
+        line["roofline"]["algorithmic_pair_ratio"] = round(alg_step / step_s / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)
+        kern = {}
+        for r in rows:
+            k = {"launches": r[1], "ms_per_step": round(r[2] / args.steps, 4)}
+            if r[0] in exe:
+                k["executed_frac"] = round(exe[r[0]] / (r[2] / r[1] * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)
+            elif r[0] in work:
+                k["hbm_frac"] = round(work[r[0]][1] / (r[2] / r[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+            kern[r[0]] = k
+        line["roofline"]["kernels"] = kern
+    if rank == 0 and world == 1 and not sp_only and not args.no_extras:
+        log("single-pair latency (Matching.forward, B = 1)")
+        line["latency_b1_ms"] = latency_b1(matching, wl, device)
+        log("PCIe-inclusive rate (IngestPipeline)")
+        pc = pcie_inclusive(matching, wl, B)
+        line["pcie_inclusive_pairs_s"] = pc["value"]
+        line["pcie_inclusive"] = pc
     if use_pg:
         barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not sp_only:

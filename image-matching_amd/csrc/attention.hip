@@ -48,9 +48,13 @@ __device__ __forceinline__ AttnBlock attn_block() {
 template <int HD, bool DEEP, int TK = 32>
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale) {
   constexpr int KS = HD + 4;          // K tile row stride: rows 16-byte aligned, 8 lanes of a b128 read cover all 32 banks
-  constexpr int OB = HD / 32;         // output blocks of 32 dims
+  // HD = 16 (descriptor_dim 64, reference README.md:134-140): the P.V product still runs on the 32x32x2 MFMA, whose output
+  // block is 32 dims wide -- the V tile is staged 32 columns wide with columns 16..31 zero (written once), and only the
+  // first 16 output dims are stored.  Half of that product is padding; the configuration is a quarter of C3's work anyway.
+  constexpr int HV = HD < 32 ? 32 : HD;   // V tile row width
+  constexpr int OB = HV / 32;         // output blocks of 32 dims
   __shared__ __attribute__((aligned(16))) float Kt[2][TK * KS];
-  __shared__ __attribute__((aligned(16))) float Vt[2][TK * HD];
+  __shared__ __attribute__((aligned(16))) float Vt[2][TK * HV];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
   const AttnBlock blk = attn_block();
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
     const int e = tid + it * 256, key = e / V4, v4 = e % V4;                                   \
     float* kd = &Kt[buf_][key * KS + 4 * v4];                                                  \
     *reinterpret_cast<f32x4*>(kd) = kreg[set_][it];                                            \
-    *reinterpret_cast<f32x4*>(&Vt[buf_][key * HD + 4 * v4]) = vreg[set_][it];                  \
+    *reinterpret_cast<f32x4*>(&Vt[buf_][key * HV + 4 * v4]) = vreg[set_][it];                  \
   }
 
   // one key tile: S^T = K.Q^T, online softmax, O^T = O^T*alpha + V^T.P^T
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
     if (wave_active) {
       // ---- fetch this tile's K and V fragments from LDS up front (V lands during the S MFMAs)
       const float* kp = &Kt[buf][(sub * 32 + l31) * KS + hi * (HD / 2)];
-      const float* vp = &Vt[buf][(sub * 32 + 4 * hi) * HD + l31];
+      const float* vp = &Vt[buf][(sub * 32 + 4 * hi) * HV + l31];
       float kf[HD / 2], vf[OB][16];
 #pragma unroll
       for (int t = 0; t < HD / 2; t += 4) {           // a lane's HD/2 values of its key row are contiguous: b128 reads
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
 #pragma unroll
       for (int o = 0; o < OB; ++o)
 #pragma unroll
-        for (int st = 0; st < 16; ++st) vf[o][st] = vp[((st & 3) + 8 * (st >> 2)) * HD + o * 32];
+        for (int st = 0; st < 16; ++st) vf[o][st] = vp[((st & 3) + 8 * (st >> 2)) * HV + o * 32];
       __builtin_amdgcn_sched_barrier(0);
       // ---- S^T = K . Q^T
       // (the first MFMA takes a literal zero accumulator: no 16-register clear per tile)
@@ -192,6 +196,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
     }
   };
 
+  if constexpr (HV != HD) {                 // zero columns HD..HV-1 of both V buffers, never written again
+    for (int e = tid; e < 2 * TK * (HV - HD); e += 256) {
+      const int row = e / (HV - HD), c = HD + e % (HV - HD);
+      (&Vt[0][0])[row * HV + c] = 0.f;
+    }
+  }
   if constexpr (!DEEP) {
     if (nt > 0) { IMX_GLOAD(0, 0) IMX_LSTORE(0, 0) }
     __syncthreads();
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
 #pragma unroll
     for (int o = 0; o < OB; ++o)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < (HD < 32 ? HD / 8 : 4); ++g) {      // accumulator registers 4g..4g+3 = dims 8g + 4hi ..
         float4 v = make_float4(O[o][4 * g] * inv, O[o][4 * g + 1] * inv, O[o][4 * g + 2] * inv, O[o][4 * g + 3] * inv);
         *reinterpret_cast<float4*>(op + o * 32 + 8 * g + 4 * hi) = v;
       }
@@ -238,207 +248,6 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
 #undef IMX_GLOAD
 #undef IMX_LSTORE
 
-// ---------------------------------------------------------------------------------------------------------------
-// Software-pipelined form (default).  Same arithmetic, same per-key pairing; what changes is the ORDER inside a wave:
-// iteration t issues the score MFMAs of tile t+1, then the P.V MFMAs of tile t with the softmax VALU work of tile
-// t+1 interleaved between them (independent chains: S(t+1) -> P(t+1) vs O += V(t).P(t)), so the exponentials no longer
-// sit in series with the matrix pipe.  K/V tiles live in a ring of three LDS buffers (tile t's V and tile t+1's K are
-// needed together while tile t+2 is being staged); still one barrier per tile.  The running-max rescale of O and l is
-// skipped when no lane of the wave saw a larger maximum (alpha == 1 exactly; common after the first tiles).
-template <int HD>
-__global__ __launch_bounds__(256) void attention2_kernel(AttnArgs p, float scale) {
-  constexpr int KS = HD + 1;          // K tile row stride (odd: conflict-free column reads)
-  constexpr int OB = HD / 32;         // output blocks of 32 dims
-  __shared__ __attribute__((aligned(16))) float Kt[3][32 * KS];
-  __shared__ __attribute__((aligned(16))) float Vt[3][32 * HD];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-  const AttnBlock blk = attn_block();
-  const int head = blk.y;
-  const int side = blk.z / p.B, b = blk.z % p.B;
-  const int kside = p.cross ? 1 - side : side;
-  const int Nqp = side ? p.N1p : p.N0p, Nkp = kside ? p.N1p : p.N0p;
-  const int q0 = blk.x * 128;
-  if (q0 >= Nqp) return;
-  const int nq = side ? (p.n1 ? p.n1[b] : p.N1) : (p.n0 ? p.n0[b] : p.N0);
-  const int nk = kside ? (p.n1 ? p.n1[b] : p.N1) : (p.n0 ? p.n0[b] : p.N0);
-  const size_t qbase = (side ? (size_t)p.B * p.N0p : 0) + (size_t)b * Nqp;
-  const size_t kbase = (kside ? (size_t)p.B * p.N0p : 0) + (size_t)b * Nkp;
-  const int ld = 3 * p.d;
-  const int qrow = q0 + 32 * wave + l31;
-  const bool wave_active = (q0 + 32 * wave) < Nqp;
-
-  float q[HD / 2];
-  if (wave_active) {
-    const float* qp = p.qkv + (qbase + qrow) * ld + head * HD + hi * (HD / 2);
-#pragma unroll
-    for (int t = 0; t < HD / 2; t += 4) {
-      float4 v = *reinterpret_cast<const float4*>(qp + t);
-      q[t] = v.x * scale; q[t + 1] = v.y * scale; q[t + 2] = v.z * scale; q[t + 3] = v.w * scale;
-    }
-  } else {
-#pragma unroll
-    for (int t = 0; t < HD / 2; ++t) q[t] = 0.f;
-  }
-
-  f32x16 O[OB];
-#pragma unroll
-  for (int o = 0; o < OB; ++o)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) O[o][r] = 0.f;
-  float m = -INFINITY, l = 0.f;
-
-  const int nt = (nk + 31) / 32;
-  constexpr int V4 = HD / 4;
-  constexpr int ITER = (32 * V4) / 256;
-  f32x4 kreg[ITER], vreg[ITER];
-#define IMX_GLOAD(kt_)                                                                         \
-  _Pragma("unroll") for (int it = 0; it < ITER; ++it) {                                        \
-    const int e = tid + it * 256, key = e / V4, v4 = e % V4;                                   \
-    const float* base = p.qkv + (kbase + (size_t)(kt_) * 32 + key) * ld + head * HD + 4 * v4;  \
-    kreg[it] = *reinterpret_cast<const f32x4*>(base + p.d);                                   \
-    vreg[it] = *reinterpret_cast<const f32x4*>(base + 2 * p.d);                               \
-  }
-#define IMX_LSTORE(buf_)                                                                       \
-  _Pragma("unroll") for (int it = 0; it < ITER; ++it) {                                        \
-    const int e = tid + it * 256, key = e / V4, v4 = e % V4;                                   \
-    float* kd = &Kt[buf_][key * KS + 4 * v4];                                                  \
-    kd[0] = kreg[it][0]; kd[1] = kreg[it][1]; kd[2] = kreg[it][2]; kd[3] = kreg[it][3];            \
-    *reinterpret_cast<f32x4*>(&Vt[buf_][key * HD + 4 * v4]) = vreg[it];                       \
-  }
-  // scores of one tile: S^T = K.Q^T, masked past nk (tile index tile_)
-#define IMX_SCORES(S_, slot_, tile_)                                                           \
-  {                                                                                            \
-    const float* kp = &Kt[slot_][l31 * KS + hi * (HD / 2)];                                    \
-    float kf[HD / 2];                                                                          \
-    _Pragma("unroll") for (int t = 0; t < HD / 2; ++t) kf[t] = kp[t];                          \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) S_[r] = 0.f;                                \
-    _Pragma("unroll") for (int t = 0; t < HD / 2; ++t)                                         \
-        S_ = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], q[t], S_, 0, 0, 0);                   \
-  }
-  // online softmax of a tile's scores (log2 domain): S_ -> probabilities, updates m, l; alpha_ = rescale of the past.
-  // Branch-free (keys >= lim_ are masked by select, lim_ = 0 turns the whole tile into a no-op: alpha 1, P 0) so the
-  // whole thing can be scheduled between the P.V MFMAs of the previous tile.
-#define IMX_SOFTMAX(S_, tile_, lim_, alpha_)                                                   \
-  {                                                                                            \
-    float mx = -INFINITY;                                                                      \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                           \
-      const int key = (tile_) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;                          \
-      const float sv = key < (lim_) ? S_[r] : -INFINITY;                                       \
-      S_[r] = sv;                                                                              \
-      mx = fmaxf(mx, sv);                                                                      \
-    }                                                                                          \
-    mx = fmaxf(mx, __shfl_xor(mx, 32));                                                        \
-    const float mn = fmaxf(m, mx);                                                             \
-    alpha_ = __builtin_amdgcn_exp2f(m - mn);                                                   \
-    float rs = 0.f;                                                                            \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                           \
-      const float pr = __builtin_amdgcn_exp2f(S_[r] - mn);                                     \
-      S_[r] = pr;                                                                              \
-      rs += pr;                                                                                \
-    }                                                                                          \
-    rs += __shfl_xor(rs, 32);                                                                  \
-    l = l * alpha_ + rs;                                                                       \
-    m = mn;                                                                                    \
-  }
-
-  if (nt > 0) { IMX_GLOAD(0) IMX_LSTORE(0) }
-  if (nt > 1) { IMX_GLOAD(1) IMX_LSTORE(1) }
-  __syncthreads();
-
-  f32x16 P, Sn;            // probabilities of the current tile, scores -> probabilities of the next one
-  float alpha = 1.f;       // rescale that P's maximum imposed on everything accumulated before it
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { P[r] = 0.f; Sn[r] = 0.f; }
-  if (wave_active && nt > 0) {
-    IMX_SCORES(P, 0, 0)
-    IMX_SOFTMAX(P, 0, nk, alpha)
-  }
-  int s0 = 0;              // ring slot of tile kt
-  for (int kt = 0; kt < nt; ++kt) {
-    const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-    const int lim = kt + 1 < nt ? nk : 0;      // past the last tile the look-ahead softmax is a no-op
-    { IMX_GLOAD(kt + 2 < nt ? kt + 2 : kt) }   // branch-free prefetch (the tail re-fetches an old tile, never consumed)
-    if (wave_active) {
-      // rescale by this tile's alpha only if some lane's maximum moved (alpha == 1 exactly otherwise)
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
-#pragma unroll
-        for (int o = 0; o < OB; ++o)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) O[o][r] *= alpha;
-      }
-      // ---- one straight-line block: scores of tile kt+1, then O^T += V^T . P^T of tile kt with tile kt+1's softmax
-      //      scheduled into the MFMA shadows
-      const float* vp = &Vt[s0][(4 * hi) * HD + l31];
-      float vf[OB][16];
-#pragma unroll
-      for (int o = 0; o < OB; ++o)
-#pragma unroll
-        for (int st = 0; st < 16; ++st) vf[o][st] = vp[((st & 3) + 8 * (st >> 2)) * HD + o * 32];
-      IMX_SCORES(Sn, s1, kt + 1)
-      __builtin_amdgcn_sched_barrier(0);
-      // P.V MFMAs of tile kt, with tile kt+1's softmax hand-sliced between them (the order is pinned with scheduling
-      // fences: left alone, the compiler issues all MFMAs back to back and the exponentials after them).
-      //   MFMAs 0-3: masked maximum (4 elements each) | after 3: cross-half max, new maximum, alpha
-      //   MFMAs 4-11: exponentials (2 elements each)  | after 11: cross-half sum, l, m
-      float mx = -INFINITY, rs = 0.f, mn = m, alpha_n = 1.f;
-#pragma unroll
-      for (int st = 0; st < 16; ++st) {
-#pragma unroll
-        for (int o = 0; o < OB; ++o) O[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[o][st], P[st], O[o], 0, 0, 0);
-        if (st < 4) {
-#pragma unroll
-          for (int r = 4 * st; r < 4 * st + 4; ++r) {
-            const int key = (kt + 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float sv = key < lim ? Sn[r] : -INFINITY;
-            Sn[r] = sv;
-            mx = fmaxf(mx, sv);
-          }
-          if (st == 3) {
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            mn = fmaxf(m, mx);
-            alpha_n = __builtin_amdgcn_exp2f(m - mn);
-          }
-        } else if (st < 12) {
-#pragma unroll
-          for (int r = 2 * (st - 4); r < 2 * (st - 4) + 2; ++r) {
-            const float pr = __builtin_amdgcn_exp2f(Sn[r] - mn);
-            Sn[r] = pr;
-            rs += pr;
-          }
-          if (st == 11) {
-            rs += __shfl_xor(rs, 32);
-            l = l * alpha_n + rs;
-            m = mn;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      alpha = alpha_n;
-      P = Sn;
-    }
-    { IMX_LSTORE(s2) }
-    __syncthreads();
-    s0 = s1;
-  }
-
-  if (wave_active) {
-    const float inv = (l > 0.f && qrow < nq) ? 1.0f / l : 0.f;
-    float* op = p.out + (qbase + qrow) * p.d + head * HD;
-#pragma unroll
-    for (int o = 0; o < OB; ++o)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 v = make_float4(O[o][4 * g] * inv, O[o][4 * g + 1] * inv, O[o][4 * g + 2] * inv, O[o][4 * g + 3] * inv);
-        *reinterpret_cast<float4*>(op + o * 32 + 8 * g + 4 * hi) = v;
-      }
-  }
-}
-
-#undef IMX_GLOAD
-#undef IMX_LSTORE
-#undef IMX_SCORES
-#undef IMX_SOFTMAX
 }  // namespace
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
@@ -446,22 +255,24 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   const int nmax = a.N0p > a.N1p ? a.N0p : a.N1p;
   dim3 grid((unsigned)((nmax + 127) / 128), (unsigned)a.heads, (unsigned)(2 * a.B));
   const float scale = (float)(1.4426950408889634 / sqrt((double)hd));   // log2(e)/sqrt(HD)
-  // A/B switch IMX_ATTN: 1 = one K/V tile in flight, 2 = software-pipelined softmax (attention2_kernel), 3 = two tiles in
-  // flight (default).  Measured on MI355X, whole step, C3 (HD=32, 64 pairs) / C5 (HD=64, 8 pairs), pairs/s:
-  // 1: 1172 / 203.1, 2: 1163 / 203.6, 3: 1185 / 207.6 -- VALU work placed between MFMAs is not free (in-order issue),
-  // so the pipelined form gains nothing; keeping two tiles of K/V in flight hides the L2 latency of the staging loads.
-  const char* env = getenv("IMX_ATTN");        // read per launch (tests switch it within one process)
+  // A/B switch IMX_ATTN (read per launch: tests switch it within one process): 1 = one K/V tile in flight, 3 = two tiles
+  // in flight (default), 4 = 64-key staged tiles.  Round-1 measurements (whole step, pairs/s, C3 HD=32 / C5 HD=64):
+  // 1: 1172 / 203.1, 3: 1185 / 207.6, 4: = 3; a software-pipelined softmax form (exponentials sliced between the P.V
+  // MFMAs) measured 1163 / 203.6 and was removed -- VALU work placed between MFMAs is not free (in-order issue).
+  const char* env = getenv("IMX_ATTN");
   const int mode = env ? atoi(env) : 3;
   if (hd == 32) {
     if (mode == 1) hipLaunchKernelGGL((attention_kernel<32, false>), grid, dim3(256), 0, s, a, scale);
-    else if (mode == 2) hipLaunchKernelGGL(attention2_kernel<32>, grid, dim3(256), 0, s, a, scale);
     else if (mode == 4) hipLaunchKernelGGL((attention_kernel<32, true, 64>), grid, dim3(256), 0, s, a, scale);
     else hipLaunchKernelGGL((attention_kernel<32, true>), grid, dim3(256), 0, s, a, scale);
   } else if (hd == 64) {
     if (mode == 1) hipLaunchKernelGGL((attention_kernel<64, false>), grid, dim3(256), 0, s, a, scale);
-    else if (mode == 2) hipLaunchKernelGGL(attention2_kernel<64>, grid, dim3(256), 0, s, a, scale);
     else if (mode == 4) hipLaunchKernelGGL((attention_kernel<64, true, 64>), grid, dim3(256), 0, s, a, scale);
     else hipLaunchKernelGGL((attention_kernel<64, true>), grid, dim3(256), 0, s, a, scale);
+  } else if (hd == 16) {
+    // 64-key staged tiles: 64 keys x 4 float4 = one float4 of K and of V per thread and tile
+    if (mode == 1) hipLaunchKernelGGL((attention_kernel<16, false, 64>), grid, dim3(256), 0, s, a, scale);
+    else hipLaunchKernelGGL((attention_kernel<16, true, 64>), grid, dim3(256), 0, s, a, scale);
   } else {
     return hipErrorInvalidValue;
   }

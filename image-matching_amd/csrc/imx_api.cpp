@@ -12,7 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <map>
+#include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -32,11 +35,8 @@ struct DevBuf {
   size_t bytes = 0;
 };
 struct ConvW {
-  float* w = nullptr;    // direct form  [9][Cin][Cout]
-  float* wu = nullptr;   // Winograd F(2x2,3x3) form (conv3x3_wino.hip layout)
-  float* wu4 = nullptr;  // Winograd F(2x2,3x3) form (conv3x3_wino4.hip layout)
-  float* wu6 = nullptr;  // Winograd F(2x2,3x3) form (conv3x3_wino6.hip layout: four positions per lane = one dwordx4)
-  float* wu24 = nullptr; // Winograd F(2x4,3x3) form (conv1ab_wino24.hip layout), conv1b only
+  float* w = nullptr;    // direct form  [9][Cin][Cout] (conv3x3.hip: IMX_CONV=direct, and the fallback for shapes wino24 rejects)
+  float* wu24 = nullptr; // Winograd F(2x4,3x3) form (conv1ab_wino24.hip / conv3x3_wino24.hip layout)
   float* b = nullptr;
   int cin = 0, cout = 0;
 };
@@ -73,7 +73,8 @@ struct imx_handle_s {
   std::map<std::string, std::vector<int64_t>> expected[2];
   std::map<std::string, HostTensor> raw[2];
   bool finalized[2] = {false, false};
-  std::vector<void*> weight_allocs;
+  std::vector<void*> weight_allocs[2];   // per net: freed when that net's weights are finalized again
+  int upload_net = 0;                    // net whose finalize is running (upload() files allocations under it)
   // SuperPoint
   float *w1 = nullptr, *b1 = nullptr;
   ConvW conv[8];   // conv1b, 2a, 2b, 3a, 3b, 4a, 4b, heads (convPa | convDa)
@@ -91,10 +92,8 @@ struct imx_handle_s {
   int det_B = 0, det_H = 0, det_W = 0, det_Hc = 0, det_Wc = 0, det_Ksel = 0;
   // debug / timing
   bool debug = false, timing = false;
-  bool convn_f24 = true;  // every other 3x3 layer as Winograd F(2x4,3x3) (conv3x3_wino24.hip); IMX_CONVN=f22 keeps the F(2x2,3x3) kernel
-  bool conv1_f24 = true;  // fused first layer: conv1b as Winograd F(2x4,3x3) (conv1ab_wino24.hip); IMX_CONV1=f22 keeps the F(2x2,3x3) kernel
-  int conv_mode = 4;      // 3x3 conv kernel: 4 auto (conv1a+1b fused: wino, all other layers: wino6), 0 direct (IMX_CONV=direct),
-                          // 1 Winograd 16x16x4 (wino), 2 Winograd 32x32x2 pipelined (wino4), 3 persistent producer/consumer (wino6)
+  bool conv_direct = false;  // IMX_CONV=direct: every 3x3 layer on the direct implicit-GEMM kernel (A/B reference); default:
+                             // Winograd F(2x4,3x3) (conv1ab_wino24 / conv3x3_wino24), direct only for shapes those reject
   std::map<std::string, Tap> taps;
   std::vector<TimedEvent> events;
   std::vector<TimingRow> report;
@@ -228,7 +227,7 @@ float* upload(imx_handle_t h, const std::vector<float>& v) {
     (void)hipFree(p);
     return nullptr;
   }
-  h->weight_allocs.push_back(p);
+  h->weight_allocs[h->upload_net].push_back(p);
   return static_cast<float*>(p);
 }
 
@@ -266,43 +265,6 @@ void put_conv3(const std::map<std::string, HostTensor>& raw, const std::string& 
   }
 }
 
-// Winograd F(2x2,3x3) weight transform U = G g G^T of folded direct-form weights w[tap][ci][co]
-// (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), laid out per (64-channel output group, 8-channel
-// input chunk) as conv3x3_wino.hip's MFMA B fragments read it: [16 pos][ci>>2 (k-step)][co>>4][ci&3][16 co],
-// i.e. one wave load = 256 contiguous bytes.
-std::vector<float> wino_transform(const std::vector<float>& w, int cin, int cout, int layout = 0) {
-  const int nchunk = cin / 8, ncog = cout / 64;
-  std::vector<float> u((size_t)ncog * nchunk * 8192, 0.f);
-  for (int co = 0; co < cout; ++co)
-    for (int ci = 0; ci < cin; ++ci) {
-      double g[3][3], gg[4][3], uu[4][4];
-      for (int ky = 0; ky < 3; ++ky)
-        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((size_t)(ky * 3 + kx) * cin + ci) * cout + co];
-      for (int kx = 0; kx < 3; ++kx) {
-        gg[0][kx] = g[0][kx];
-        gg[1][kx] = 0.5 * (g[0][kx] + g[1][kx] + g[2][kx]);
-        gg[2][kx] = 0.5 * (g[0][kx] - g[1][kx] + g[2][kx]);
-        gg[3][kx] = g[2][kx];
-      }
-      for (int r = 0; r < 4; ++r) {
-        uu[r][0] = gg[r][0];
-        uu[r][1] = 0.5 * (gg[r][0] + gg[r][1] + gg[r][2]);
-        uu[r][2] = 0.5 * (gg[r][0] - gg[r][1] + gg[r][2]);
-        uu[r][3] = gg[r][2];
-      }
-      const int cog = co / 64, col = co % 64, chunk = ci / 8, k = ci % 8;
-      float* blk = u.data() + ((size_t)cog * nchunk + chunk) * 8192;
-      for (int q = 0; q < 16; ++q) {
-        const size_t idx = layout == 0 ? (size_t)((((q * 2 + (k >> 2)) * 4 + (col >> 4)) * 4 + (k & 3)) * 16) + (col & 15)
-                           : layout == 1 ? (size_t)(q * 8 + k) * 64 + col     // conv3x3_wino4.hip: [pos][ci][co]
-                                         // conv3x3_wino6.hip: [k-step][pos>>2][co-block][lane = (ci&3)*16 + co&15][pos&3]
-                                         : (size_t)(((((k >> 2) * 4 + (q >> 2)) * 4 + (col >> 4)) * 64 + (k & 3) * 16 + (col & 15)) * 4) + (q & 3);
-        blk[idx] = (float)uu[q / 4][q % 4];
-      }
-    }
-  return u;
-}
-
 // U = G2 g G4^T (4 x 6 per (co, ci); F(2,3) down the rows, F(4,3) along the columns), laid out as conv1ab_wino24.hip's MFMA
 // B fragments read it: [chunk of 8 ci][quad = position pair][co-block][lane = (ci pair)*16 + co%16][(position parity)*2 + ci%2],
 // position p = j*4 + i: a lane's four B registers of a quad are one buffer_load_dwordx4.
@@ -337,14 +299,11 @@ int make_conv(imx_handle_t h, ConvW& out, const std::map<std::string, HostTensor
   std::vector<float> w((size_t)9 * cin * cout), b(cout);
   put_conv3(raw, conv, bn, cin, cout, cout, 0, w, b);
   out.w = upload(h, w);
-  out.wu = upload(h, wino_transform(w, cin, cout));
-  out.wu4 = upload(h, wino_transform(w, cin, cout, 1));
-  out.wu6 = upload(h, wino_transform(w, cin, cout, 2));
   out.wu24 = upload(h, wino24_transform(w, cin, cout));
   out.b = upload(h, b);
   out.cin = cin;
   out.cout = cout;
-  return (out.w && out.wu && out.b) ? 0 : fail(h, "weight upload failed (%s)", conv.c_str());
+  return (out.w && out.wu24 && out.b) ? 0 : fail(h, "weight upload failed (%s)", conv.c_str());
 }
 
 // linear weight (N,K[,1[,1]]) -> W[k_perm(k)][n_perm(n)] padded to Npad columns, folded BN
@@ -415,14 +374,11 @@ int finalize_superpoint(imx_handle_t h) {
     put_conv3(raw, "convPa", bn ? "bnPa" : "", 128, 256, 512, 0, w, b);
     put_conv3(raw, "convDa", bn ? "bnDa" : "", 128, 256, 512, 256, w, b);
     h->conv[7].w = upload(h, w);
-    h->conv[7].wu = upload(h, wino_transform(w, 128, 512));
-    h->conv[7].wu4 = upload(h, wino_transform(w, 128, 512, 1));
-    h->conv[7].wu6 = upload(h, wino_transform(w, 128, 512, 2));
     h->conv[7].wu24 = upload(h, wino24_transform(w, 128, 512));
     h->conv[7].b = upload(h, b);
     h->conv[7].cin = 128;
     h->conv[7].cout = 512;
-    if (!h->conv[7].w || !h->conv[7].wu || !h->conv[7].b) return fail(h, "weight upload failed (heads)");
+    if (!h->conv[7].w || !h->conv[7].wu24 || !h->conv[7].b) return fail(h, "weight upload failed (heads)");
   }
   if (make_gemm(h, h->pb, raw, "convPb", bn ? "bnPb" : "", 256, 65)) return -1;
   if (make_gemm(h, h->db, raw, "convDb", bn ? "bnDb" : "", 256, d)) return -1;
@@ -433,8 +389,8 @@ int finalize_superglue(imx_handle_t h) {
   const auto& raw = h->raw[IMX_NET_SUPERGLUE];
   const imx_config_t& c = h->cfg;
   const int d = c.descriptor_dim;
-  if (d % (HEADS * 32) != 0 || (d / HEADS != 32 && d / HEADS != 64))
-    return fail(h, "SuperGlue needs descriptor_dim/4 in {32,64} (got descriptor_dim=%d)", d);
+  if (d % HEADS != 0 || (d / HEADS != 16 && d / HEADS != 32 && d / HEADS != 64))
+    return fail(h, "SuperGlue needs descriptor_dim/4 in {16,32,64} (got descriptor_dim=%d)", d);
   h->bin_score = raw.at("bin_score").data[0];
   std::vector<int> ch = {3};
   for (int i = 0; i < c.kenc_n; ++i) ch.push_back(c.kenc_channels[i]);
@@ -565,9 +521,11 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   auto conv = [&](const char* name, const ConvW& w, const float* in, float* out, int hh, int ww, bool pool, bool first) -> int {
     ConvArgs a{};
     a.in = in; a.in2 = first ? img1 : nullptr; a.split = first ? split : 0;
-    a.w = w.w; a.wu = w.wu; a.wu4 = w.wu4; a.wu6 = w.wu6; a.wu24 = w.wu24; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
+    a.w = w.w; a.wu24 = w.wu24; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
     a.B = B; a.H = hh; a.W = ww; a.Cin = w.cin; a.Cout = w.cout; a.relu = 1; a.pool = pool ? 1 : 0; a.first = first ? 1 : 0;
-    RUN(name, (h->conv_mode == 4 && a.first && a.pool && h->conv1_f24) ? launch_conv1ab_wino24(a, s) : (h->conv_mode == 4 && !a.first && h->convn_f24 && conv3x3_wino24_supported(a)) ? launch_conv3x3_wino24(a, s) : (h->conv_mode == 3 || (h->conv_mode == 4 && !a.first)) ? launch_conv3x3_wino6(a, s) : h->conv_mode == 2 ? launch_conv3x3_wino4(a, s) : h->conv_mode == 0 ? launch_conv3x3(a, s) : launch_conv3x3_wino(a, s));
+    const bool fused1 = a.first && a.pool && !h->conv_direct;
+    const bool wino = !a.first && !h->conv_direct && conv3x3_wino24_supported(a);
+    RUN(name, fused1 ? launch_conv1ab_wino24(a, s) : wino ? launch_conv3x3_wino24(a, s) : launch_conv3x3(a, s));
     return 0;
   };
   if (conv("conv1ab_pool", h->conv[0], img0, a1, H, W, true, true)) return -1;
@@ -744,108 +702,154 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   return 0;
 }
 
+// Nothing may throw across the C ABI (include/imx.h): every entry point runs inside this guard.  The handle owns
+// std::string / std::map / std::vector state, so std::bad_alloc (or any other exception) is possible in principle;
+// it becomes an error code + imx_last_error text.  Recording the text must not throw either.
+int fail_nothrow(imx_handle_t h, const char* where, const char* what) noexcept {
+  try {
+    return fail(h, "%s: exception: %s", where, what);
+  } catch (...) {
+    return -1;
+  }
+}
+template <class F>
+int guarded(imx_handle_t h, const char* where, F&& f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return fail_nothrow(h, where, "out of host memory (std::bad_alloc)");
+  } catch (const std::exception& e) {
+    return fail_nothrow(h, where, e.what());
+  } catch (...) {
+    return fail_nothrow(h, where, "unknown C++ exception");
+  }
+}
+
 }  // namespace
 
 // =============================================================================== C ABI
 extern "C" {
 
-const char* imx_version(void) { return "imx 0.1 gfx950 hip-7.2 fp32-mfma"; }
+#ifndef IMX_BUILD_ID
+#define IMX_BUILD_ID "dev"
+#endif
+const char* imx_version(void) { return "imx 0.2 gfx950 hip-7.2 fp32-mfma build " IMX_BUILD_ID; }
 
 int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
-  if (!cfg || !out) return fail(nullptr, "imx_create: null argument");
-  if (cfg->num_gnn_layers < 0 || cfg->num_gnn_layers > IMX_MAX_GNN_LAYERS) return fail(nullptr, "imx_create: bad num_gnn_layers %d", cfg->num_gnn_layers);
-  if (cfg->kenc_n < 1 || cfg->kenc_n > IMX_MAX_KENC) return fail(nullptr, "imx_create: bad keypoint_encoder length %d", cfg->kenc_n);
-  if (cfg->descriptor_dim <= 0 || cfg->descriptor_dim % 32) return fail(nullptr, "imx_create: descriptor_dim must be a positive multiple of 32 (got %d)", cfg->descriptor_dim);
-  if (cfg->nms_radius < 0 || cfg->nms_radius > 8) return fail(nullptr, "imx_create: nms_radius must be in [0,8] (got %d)", cfg->nms_radius);
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "imx_create: no HIP device available (this library has no CPU path)");
-  if (device_id < 0 || device_id >= ndev) return fail(nullptr, "imx_create: device %d out of range (%d devices)", device_id, ndev);
-  if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, "imx_create: hipSetDevice(%d) failed", device_id);
-  imx_handle_s* h = new imx_handle_s();
-  h->device = device_id;
-  h->cfg = *cfg;
-  if (const char* e = getenv("IMX_CONV1")) h->conv1_f24 = std::string(e) != "f22";
-  if (const char* e = getenv("IMX_CONVN")) h->convn_f24 = std::string(e) != "f22";
-  if (const char* e = getenv("IMX_CONV")) h->conv_mode = std::string(e) == "direct" ? 0 : std::string(e) == "wino4" ? 2 : std::string(e) == "wino6" ? 3 : std::string(e) == "wino" ? 1 : 4;
-  build_expected(h);
-  *out = h;
-  return 0;
+  return guarded(nullptr, "imx_create", [&]() -> int {
+    if (!cfg || !out) return fail(nullptr, "imx_create: null argument");
+    if (cfg->num_gnn_layers < 0 || cfg->num_gnn_layers > IMX_MAX_GNN_LAYERS) return fail(nullptr, "imx_create: bad num_gnn_layers %d", cfg->num_gnn_layers);
+    if (cfg->kenc_n < 1 || cfg->kenc_n > IMX_MAX_KENC) return fail(nullptr, "imx_create: bad keypoint_encoder length %d", cfg->kenc_n);
+    if (cfg->descriptor_dim <= 0 || cfg->descriptor_dim % 32) return fail(nullptr, "imx_create: descriptor_dim must be a positive multiple of 32 (got %d)", cfg->descriptor_dim);
+    if (cfg->nms_radius < 0 || cfg->nms_radius > 8) return fail(nullptr, "imx_create: nms_radius must be in [0,8] (got %d)", cfg->nms_radius);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "imx_create: no HIP device available (this library has no CPU path)");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, "imx_create: device %d out of range (%d devices)", device_id, ndev);
+    if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, "imx_create: hipSetDevice(%d) failed", device_id);
+    std::unique_ptr<imx_handle_s> h(new imx_handle_s());      // released only once nothing below can throw
+    h->device = device_id;
+    h->cfg = *cfg;
+    if (const char* e = getenv("IMX_CONV")) h->conv_direct = std::string(e) == "direct";
+    build_expected(h.get());
+    *out = h.release();
+    return 0;
+  });
 }
 
 int imx_destroy(imx_handle_t h) {
-  if (!h) return 0;
-  (void)hipSetDevice(h->device);
-  (void)hipDeviceSynchronize();
-  for (void* p : h->weight_allocs) (void)hipFree(p);
-  for (auto& kv : h->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
-  for (auto& e : h->events) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
-  delete h;
-  return 0;
+  return guarded(h, "imx_destroy", [&]() -> int {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (auto& va : h->weight_allocs) for (void* p : va) (void)hipFree(p);
+    for (auto& kv : h->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& e : h->events) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+    delete h;
+    return 0;
+  });
 }
 
-const char* imx_last_error(imx_handle_t h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+const char* imx_last_error(imx_handle_t h) { return h ? h->err.c_str() : g_create_error.c_str(); }   // c_str() does not throw
 
 int imx_load_weight(imx_handle_t h, int net, const char* name, const float* host, int ndim, const int64_t* shape) {
-  if (!h) return -1;
-  if (net != IMX_NET_SUPERPOINT && net != IMX_NET_SUPERGLUE) return fail(h, "imx_load_weight: bad net id %d", net);
-  if (!name || !host) return fail(h, "imx_load_weight: null argument");
-  std::string key = name;
-  if (ends_with(key, "num_batches_tracked")) return 0;
-  auto it = h->expected[net].find(key);
-  if (it == h->expected[net].end()) return fail(h, "imx_load_weight: unexpected key '%s' for %s", name, net ? "SuperGlue" : "SuperPoint");
-  int64_t want = 1, got = 1;
-  for (int64_t v : it->second) want *= v;
-  for (int i = 0; i < ndim; ++i) got *= shape[i];
-  bool same = (size_t)ndim == it->second.size();
-  for (int i = 0; same && i < ndim; ++i) same = shape[i] == it->second[i];
-  if (!same && !(want == got && want == 1)) {
-    std::string ws_, gs_;
-    for (int64_t v : it->second) ws_ += std::to_string(v) + ",";
-    for (int i = 0; i < ndim; ++i) gs_ += std::to_string(shape[i]) + ",";
-    return fail(h, "imx_load_weight: size mismatch for %s: expected (%s) got (%s)", name, ws_.c_str(), gs_.c_str());
-  }
-  HostTensor t;
-  t.data.assign(host, host + got);
-  t.shape.assign(shape, shape + ndim);
-  h->raw[net][key] = std::move(t);
-  h->finalized[net] = false;
-  return 0;
+  return guarded(h, "imx_load_weight", [&]() -> int {
+    if (!h) return -1;
+    if (net != IMX_NET_SUPERPOINT && net != IMX_NET_SUPERGLUE) return fail(h, "imx_load_weight: bad net id %d", net);
+    if (!name || !host) return fail(h, "imx_load_weight: null argument");
+    std::string key = name;
+    if (ends_with(key, "num_batches_tracked")) return 0;
+    auto it = h->expected[net].find(key);
+    if (it == h->expected[net].end()) return fail(h, "imx_load_weight: unexpected key '%s' for %s", name, net ? "SuperGlue" : "SuperPoint");
+    int64_t want = 1, got = 1;
+    for (int64_t v : it->second) want *= v;
+    for (int i = 0; i < ndim; ++i) got *= shape[i];
+    bool same = (size_t)ndim == it->second.size();
+    for (int i = 0; same && i < ndim; ++i) same = shape[i] == it->second[i];
+    if (!same && !(want == got && want == 1)) {
+      std::string ws_, gs_;
+      for (int64_t v : it->second) ws_ += std::to_string(v) + ",";
+      for (int i = 0; i < ndim; ++i) gs_ += std::to_string(shape[i]) + ",";
+      return fail(h, "imx_load_weight: size mismatch for %s: expected (%s) got (%s)", name, ws_.c_str(), gs_.c_str());
+    }
+    HostTensor t;
+    t.data.assign(host, host + got);
+    t.shape.assign(shape, shape + ndim);
+    h->raw[net][key] = std::move(t);
+    h->finalized[net] = false;
+    return 0;
+  });
 }
 
 int imx_finalize_weights(imx_handle_t h, int net) {
-  if (!h) return -1;
-  if (net != IMX_NET_SUPERPOINT && net != IMX_NET_SUPERGLUE) return fail(h, "imx_finalize_weights: bad net id %d", net);
-  HIP_OK(h, hipSetDevice(h->device));
-  for (auto& kv : h->expected[net])
-    if (!h->raw[net].count(kv.first)) return fail(h, "Missing key in state_dict: \"%s\"", kv.first.c_str());
-  int rc = net == IMX_NET_SUPERPOINT ? finalize_superpoint(h) : finalize_superglue(h);
-  if (rc) return rc;
-  h->finalized[net] = true;
-  return 0;
+  return guarded(h, "imx_finalize_weights", [&]() -> int {
+    if (!h) return -1;
+    if (net != IMX_NET_SUPERPOINT && net != IMX_NET_SUPERGLUE) return fail(h, "imx_finalize_weights: bad net id %d", net);
+    HIP_OK(h, hipSetDevice(h->device));
+    for (auto& kv : h->expected[net])
+      if (!h->raw[net].count(kv.first)) return fail(h, "Missing key in state_dict: \"%s\"", kv.first.c_str());
+    // a second load_state_dict (checkpoint sweeps): the previous uploads of THIS net are released first
+    if (!h->weight_allocs[net].empty()) {
+      HIP_OK(h, hipDeviceSynchronize());
+      for (void* p : h->weight_allocs[net]) (void)hipFree(p);
+      h->weight_allocs[net].clear();
+    }
+    h->finalized[net] = false;
+    h->upload_net = net;
+    int rc = net == IMX_NET_SUPERPOINT ? finalize_superpoint(h) : finalize_superglue(h);
+    if (rc) return rc;
+    h->finalized[net] = true;
+    return 0;
+  });
 }
 
 int imx_superpoint_detect(imx_handle_t h, const float* img_dev, int B, int H, int W, int32_t* counts_dev, void* stream) {
-  if (!h) return -1;
-  HIP_OK(h, hipSetDevice(h->device));
-  return sp_detect(h, img_dev, nullptr, B, B, H, W, counts_dev, as_stream(stream));
+  return guarded(h, "imx_superpoint_detect", [&]() -> int {
+    if (!h) return -1;
+    HIP_OK(h, hipSetDevice(h->device));
+    return sp_detect(h, img_dev, nullptr, B, B, H, W, counts_dev, as_stream(stream));
+  });
 }
 
 int imx_superpoint_dense(imx_handle_t h, const float* img_dev, int B, int H, int W, float* semi_dev, float* desc_dev, void* stream) {
-  if (!h) return -1;
-  HIP_OK(h, hipSetDevice(h->device));
-  hipStream_t s = as_stream(stream);
-  if (sp_detect(h, img_dev, nullptr, B, B, H, W, nullptr, s, true)) return -1;
-  RUN("dense_export", launch_dense_export(static_cast<const float*>(h->bufs["sp.semi"].p), 65,
-                                          static_cast<const float*>(h->bufs["sp.dense"].p), h->cfg.descriptor_dim, semi_dev,
-                                          desc_dev, B, h->det_Hc, h->det_Wc, h->cfg.sp_variant == IMX_SP_VARIANT_OFFICIAL, s));
-  return 0;
+  return guarded(h, "imx_superpoint_dense", [&]() -> int {
+    if (!h) return -1;
+    HIP_OK(h, hipSetDevice(h->device));
+    hipStream_t s = as_stream(stream);
+    if (sp_detect(h, img_dev, nullptr, B, B, H, W, nullptr, s, true)) return -1;
+    RUN("dense_export", launch_dense_export(static_cast<const float*>(h->bufs["sp.semi"].p), 65,
+                                            static_cast<const float*>(h->bufs["sp.dense"].p), h->cfg.descriptor_dim, semi_dev,
+                                            desc_dev, B, h->det_Hc, h->det_Wc, h->cfg.sp_variant == IMX_SP_VARIANT_OFFICIAL, s));
+    return 0;
+  });
 }
 
 int imx_superpoint_describe(imx_handle_t h, int B, int Kcap, float* kpts_dev, float* scores_dev, float* desc_dev, void* stream) {
-  if (!h) return -1;
-  HIP_OK(h, hipSetDevice(h->device));
-  if (Kcap <= 0) return 0;
-  return sp_describe(h, 0, B, Kcap, kpts_dev, scores_dev, desc_dev, as_stream(stream));
+  return guarded(h, "imx_superpoint_describe", [&]() -> int {
+    if (!h) return -1;
+    HIP_OK(h, hipSetDevice(h->device));
+    if (Kcap <= 0) return 0;
+    return sp_describe(h, 0, B, Kcap, kpts_dev, scores_dev, desc_dev, as_stream(stream));
+  });
 }
 
 int imx_superglue_forward(imx_handle_t h, int B, const float* kpts0_dev, const float* scores0_dev, const float* desc0_dev,
@@ -854,174 +858,198 @@ int imx_superglue_forward(imx_handle_t h, int B, const float* kpts0_dev, const f
                           int64_t desc1_stride_b, int64_t desc1_stride_c, int64_t desc1_stride_n, const int32_t* n1_dev,
                           int N1, int H1, int W1, int64_t* matches0_dev, int64_t* matches1_dev, float* mscores0_dev,
                           float* mscores1_dev, void* stream) {
-  if (!h) return -1;
-  HIP_OK(h, hipSetDevice(h->device));
-  SgSide sd[2] = {{kpts0_dev, scores0_dev, desc0_dev, desc0_stride_b, desc0_stride_c, desc0_stride_n, n0_dev, N0, H0, W0},
-                  {kpts1_dev, scores1_dev, desc1_dev, desc1_stride_b, desc1_stride_c, desc1_stride_n, n1_dev, N1, H1, W1}};
-  return sg_forward(h, B, sd, matches0_dev, matches1_dev, mscores0_dev, mscores1_dev, as_stream(stream));
+  return guarded(h, "imx_superglue_forward", [&]() -> int {
+    if (!h) return -1;
+    HIP_OK(h, hipSetDevice(h->device));
+    SgSide sd[2] = {{kpts0_dev, scores0_dev, desc0_dev, desc0_stride_b, desc0_stride_c, desc0_stride_n, n0_dev, N0, H0, W0},
+                    {kpts1_dev, scores1_dev, desc1_dev, desc1_stride_b, desc1_stride_c, desc1_stride_n, n1_dev, N1, H1, W1}};
+    return sg_forward(h, B, sd, matches0_dev, matches1_dev, mscores0_dev, mscores1_dev, as_stream(stream));
+  });
 }
 
 int imx_match_pairs(imx_handle_t h, const float* img0_dev, const float* img1_dev, int B, int H, int W, float* kpts0_dev,
                     float* kpts1_dev, float* scores0_dev, float* scores1_dev, int32_t* counts0_dev, int32_t* counts1_dev,
                     float* desc0_dev, float* desc1_dev, int64_t* matches0_dev, int64_t* matches1_dev, float* mscores0_dev,
                     float* mscores1_dev, void* stream) {
-  if (!h) return -1;
-  HIP_OK(h, hipSetDevice(h->device));
-  hipStream_t s = as_stream(stream);
-  const int K = h->cfg.max_keypoints, d = h->cfg.descriptor_dim;
-  if (K <= 0) return fail(h, "imx_match_pairs needs max_keypoints > 0 (fixed-size outputs); got %d", K);
-  WS(counts, int32_t, "mp.counts", (size_t)2 * B * 4);
-  if (sp_detect(h, img0_dev, img1_dev, B, 2 * B, H, W, counts, s)) return -1;
-  if (!desc0_dev) { WS(t0, float, "mp.desc0", (size_t)B * K * d * 4); desc0_dev = t0; }
-  if (!desc1_dev) { WS(t1, float, "mp.desc1", (size_t)B * K * d * 4); desc1_dev = t1; }
-  if (sp_describe(h, 0, B, K, kpts0_dev, scores0_dev, desc0_dev, s)) return -1;
-  if (sp_describe(h, B, B, K, kpts1_dev, scores1_dev, desc1_dev, s)) return -1;
-  if (counts0_dev) HIP_OK(h, hipMemcpyAsync(counts0_dev, counts, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
-  if (counts1_dev) HIP_OK(h, hipMemcpyAsync(counts1_dev, counts + B, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
-  const int H8 = h->det_Hc * 8, W8 = h->det_Wc * 8;
-  (void)H8; (void)W8;
-  SgSide sd[2] = {{kpts0_dev, scores0_dev, desc0_dev, (int64_t)K * d, 1, d, counts, K, H, W},
-                  {kpts1_dev, scores1_dev, desc1_dev, (int64_t)K * d, 1, d, counts + B, K, H, W}};
-  return sg_forward(h, B, sd, matches0_dev, matches1_dev, mscores0_dev, mscores1_dev, s);
+  return guarded(h, "imx_match_pairs", [&]() -> int {
+    if (!h) return -1;
+    HIP_OK(h, hipSetDevice(h->device));
+    hipStream_t s = as_stream(stream);
+    const int K = h->cfg.max_keypoints, d = h->cfg.descriptor_dim;
+    if (K <= 0) return fail(h, "imx_match_pairs needs max_keypoints > 0 (fixed-size outputs); got %d", K);
+    WS(counts, int32_t, "mp.counts", (size_t)2 * B * 4);
+    if (sp_detect(h, img0_dev, img1_dev, B, 2 * B, H, W, counts, s)) return -1;
+    if (!desc0_dev) { WS(t0, float, "mp.desc0", (size_t)B * K * d * 4); desc0_dev = t0; }
+    if (!desc1_dev) { WS(t1, float, "mp.desc1", (size_t)B * K * d * 4); desc1_dev = t1; }
+    if (sp_describe(h, 0, B, K, kpts0_dev, scores0_dev, desc0_dev, s)) return -1;
+    if (sp_describe(h, B, B, K, kpts1_dev, scores1_dev, desc1_dev, s)) return -1;
+    if (counts0_dev) HIP_OK(h, hipMemcpyAsync(counts0_dev, counts, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    if (counts1_dev) HIP_OK(h, hipMemcpyAsync(counts1_dev, counts + B, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    const int H8 = h->det_Hc * 8, W8 = h->det_Wc * 8;
+    (void)H8; (void)W8;
+    SgSide sd[2] = {{kpts0_dev, scores0_dev, desc0_dev, (int64_t)K * d, 1, d, counts, K, H, W},
+                    {kpts1_dev, scores1_dev, desc1_dev, (int64_t)K * d, 1, d, counts + B, K, H, W}};
+    return sg_forward(h, B, sd, matches0_dev, matches1_dev, mscores0_dev, mscores1_dev, s);
+  });
 }
 
 int imx_op_nms(imx_handle_t h, const float* scores_dev, float* out_dev, int B, int H, int W, int radius, void* stream) {
-  if (!h) return -1;
-  HIP_OK(h, hipSetDevice(h->device));
-  hipStream_t s = as_stream(stream);
-  RUN("nms", launch_nms(scores_dev, out_dev, B, H, W, radius, s));
-  return 0;
+  return guarded(h, "imx_op_nms", [&]() -> int {
+    if (!h) return -1;
+    HIP_OK(h, hipSetDevice(h->device));
+    hipStream_t s = as_stream(stream);
+    RUN("nms", launch_nms(scores_dev, out_dev, B, H, W, radius, s));
+    return 0;
+  });
 }
 
 int imx_estimate_affine_partial(imx_handle_t h, const float* kpts0_dev, const float* kpts1_dev, const int64_t* matches0_dev,
                                 const int32_t* counts0_dev, int B, int K, float ransac_threshold, int hypotheses, uint32_t seed,
                                 float* M_dev, uint8_t* inlier_dev, int32_t* n_inliers_dev, void* stream) {
-  if (!h) return -1;
-  HIP_OK(h, hipSetDevice(h->device));
-  hipStream_t s = as_stream(stream);
-  if (B <= 0 || K <= 0 || K > 8192) return fail(h, "imx_estimate_affine_partial: bad shape B=%d K=%d (K <= 8192)", B, K);
-  RansacArgs a{kpts0_dev, kpts1_dev, reinterpret_cast<const long long*>(matches0_dev), counts0_dev, B, K, ransac_threshold,
-               hypotheses, seed, M_dev, inlier_dev, n_inliers_dev};
-  RUN("ransac", launch_ransac(a, s));
-  return 0;
+  return guarded(h, "imx_estimate_affine_partial", [&]() -> int {
+    if (!h) return -1;
+    HIP_OK(h, hipSetDevice(h->device));
+    hipStream_t s = as_stream(stream);
+    if (B <= 0 || K <= 0 || K > 8192) return fail(h, "imx_estimate_affine_partial: bad shape B=%d K=%d (K <= 8192)", B, K);
+    RansacArgs a{kpts0_dev, kpts1_dev, reinterpret_cast<const long long*>(matches0_dev), counts0_dev, B, K, ransac_threshold,
+                 hypotheses, seed, M_dev, inlier_dev, n_inliers_dev};
+    RUN("ransac", launch_ransac(a, s));
+    return 0;
+  });
 }
 
 int imx_knn_ratio_match(imx_handle_t h, int B, const float* desc0_dev, int64_t s0b, int64_t s0c, int64_t s0n, const int32_t* n0_dev,
                         int N0, const float* desc1_dev, int64_t s1b, int64_t s1c, int64_t s1n, const int32_t* n1_dev, int N1,
                         float ratio, int64_t* matches_dev, float* dist1_dev, float* dist2_dev, void* stream) {
-  if (!h) return -1;
-  HIP_OK(h, hipSetDevice(h->device));
-  hipStream_t s = as_stream(stream);
-  const int d = h->cfg.descriptor_dim;
-  if (B <= 0 || N0 <= 0 || N1 < 0) return fail(h, "imx_knn_ratio_match: bad shape B=%d N0=%d N1=%d", B, N0, N1);
-  const int N0p = pad32(N0), N1p = pad32(std::max(N1, 1));
-  const size_t f = sizeof(float);
-  WS(r0, float, "knn.rows0", (size_t)B * N0p * d * f);
-  WS(r1, float, "knn.rows1", (size_t)B * N1p * d * f);
-  WS(nr0, float, "knn.norm0", (size_t)B * N0p * f);
-  WS(nr1, float, "knn.norm1", (size_t)B * N1p * f);
-  WS(dots, float, "knn.dots", (size_t)B * N0p * N1p * f);
-  RUN("gather_desc", launch_gather_desc(desc0_dev, s0b, s0c, s0n, B, N0, N0p, d, r0, s));
-  RUN("gather_desc", launch_gather_desc(desc1_dev, s1b, s1c, s1n, B, N1, N1p, d, r1, s));
-  RUN("rownorm2", launch_rownorm2(r0, d, (long)B * N0p, nr0, s));
-  RUN("rownorm2", launch_rownorm2(r1, d, (long)B * N1p, nr1, s));
-  ScoreArgs sc{r0, r1, dots, B, N0p, N1p, d, 1.0f};
-  RUN("knn_dots", launch_score_gemm(sc, s));
-  KnnArgs k{dots, nr0, nr1, B, N0, N1, N0p, N1p, n0_dev, n1_dev, ratio, reinterpret_cast<long long*>(matches_dev), dist1_dev, dist2_dev};
-  RUN("knn2", launch_knn2(k, s));
-  return 0;
+  return guarded(h, "imx_knn_ratio_match", [&]() -> int {
+    if (!h) return -1;
+    HIP_OK(h, hipSetDevice(h->device));
+    hipStream_t s = as_stream(stream);
+    const int d = h->cfg.descriptor_dim;
+    if (B <= 0 || N0 <= 0 || N1 < 0) return fail(h, "imx_knn_ratio_match: bad shape B=%d N0=%d N1=%d", B, N0, N1);
+    const int N0p = pad32(N0), N1p = pad32(std::max(N1, 1));
+    const size_t f = sizeof(float);
+    WS(r0, float, "knn.rows0", (size_t)B * N0p * d * f);
+    WS(r1, float, "knn.rows1", (size_t)B * N1p * d * f);
+    WS(nr0, float, "knn.norm0", (size_t)B * N0p * f);
+    WS(nr1, float, "knn.norm1", (size_t)B * N1p * f);
+    WS(dots, float, "knn.dots", (size_t)B * N0p * N1p * f);
+    RUN("gather_desc", launch_gather_desc(desc0_dev, s0b, s0c, s0n, B, N0, N0p, d, r0, s));
+    RUN("gather_desc", launch_gather_desc(desc1_dev, s1b, s1c, s1n, B, N1, N1p, d, r1, s));
+    RUN("rownorm2", launch_rownorm2(r0, d, (long)B * N0p, nr0, s));
+    RUN("rownorm2", launch_rownorm2(r1, d, (long)B * N1p, nr1, s));
+    ScoreArgs sc{r0, r1, dots, B, N0p, N1p, d, 1.0f};
+    RUN("knn_dots", launch_score_gemm(sc, s));
+    KnnArgs k{dots, nr0, nr1, B, N0, N1, N0p, N1p, n0_dev, n1_dev, ratio, reinterpret_cast<long long*>(matches_dev), dist1_dev, dist2_dev};
+    RUN("knn2", launch_knn2(k, s));
+    return 0;
+  });
 }
 
 int imx_ingest_resize_u8(imx_handle_t h, const uint8_t* src_dev, int B, int Hs, int Ws, int64_t src_stride_b, float* dst_dev, int H,
                          int W, void* stream) {
-  if (!h) return -1;
-  HIP_OK(h, hipSetDevice(h->device));
-  if (B <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0) return fail(h, "imx_ingest_resize_u8: bad shape %dx%dx%d -> %dx%d", B, Hs, Ws, H, W);
-  hipStream_t s = as_stream(stream);
-  RUN("ingest_resize", launch_resize_u8_unit(src_dev, (long)src_stride_b, B, Hs, Ws, dst_dev, H, W, s));
-  return 0;
+  return guarded(h, "imx_ingest_resize_u8", [&]() -> int {
+    if (!h) return -1;
+    HIP_OK(h, hipSetDevice(h->device));
+    if (B <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0) return fail(h, "imx_ingest_resize_u8: bad shape %dx%dx%d -> %dx%d", B, Hs, Ws, H, W);
+    hipStream_t s = as_stream(stream);
+    RUN("ingest_resize", launch_resize_u8_unit(src_dev, (long)src_stride_b, B, Hs, Ws, dst_dev, H, W, s));
+    return 0;
+  });
 }
 
 int imx_warp_affine_u8(imx_handle_t h, const uint8_t* src_dev, int Hs, int Ws, const double* M_host, uint8_t* dst_dev, int H, int W,
                        void* stream) {
-  if (!h) return -1;
-  HIP_OK(h, hipSetDevice(h->device));
-  if (Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0 || !M_host) return fail(h, "imx_warp_affine_u8: bad arguments");
-  // cv2.warpAffine without WARP_INVERSE_MAP inverts the 2x3 matrix in double precision (imgwarp.cpp invertAffineTransform path)
-  const double* M = M_host;
-  double D = M[0] * M[4] - M[1] * M[3];
-  D = D != 0.0 ? 1.0 / D : 0.0;
-  const double A11 = M[4] * D, A22 = M[0] * D;
-  double inv[6];
-  inv[0] = A11; inv[1] = M[1] * (-D); inv[3] = M[3] * (-D); inv[4] = A22;
-  inv[2] = -inv[0] * M[2] - inv[1] * M[5];
-  inv[5] = -inv[3] * M[2] - inv[4] * M[5];
-  hipStream_t s = as_stream(stream);
-  RUN("warp_affine", launch_warp_affine_u8(src_dev, Hs, Ws, dst_dev, H, W, inv, s));
-  return 0;
+  return guarded(h, "imx_warp_affine_u8", [&]() -> int {
+    if (!h) return -1;
+    HIP_OK(h, hipSetDevice(h->device));
+    if (Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0 || !M_host) return fail(h, "imx_warp_affine_u8: bad arguments");
+    // cv2.warpAffine without WARP_INVERSE_MAP inverts the 2x3 matrix in double precision (imgwarp.cpp invertAffineTransform path)
+    const double* M = M_host;
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0.0 ? 1.0 / D : 0.0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    double inv[6];
+    inv[0] = A11; inv[1] = M[1] * (-D); inv[3] = M[3] * (-D); inv[4] = A22;
+    inv[2] = -inv[0] * M[2] - inv[1] * M[5];
+    inv[5] = -inv[3] * M[2] - inv[4] * M[5];
+    hipStream_t s = as_stream(stream);
+    RUN("warp_affine", launch_warp_affine_u8(src_dev, Hs, Ws, dst_dev, H, W, inv, s));
+    return 0;
+  });
 }
 
 int imx_set_debug(imx_handle_t h, int enable) {
-  if (!h) return -1;
-  h->debug = enable != 0;
-  return 0;
+  return guarded(h, "imx_set_debug", [&]() -> int {
+    if (!h) return -1;
+    h->debug = enable != 0;
+    return 0;
+  });
 }
 
 int imx_debug_fetch(imx_handle_t h, const char* name, float* host_out, int64_t capacity, int64_t* shape_out, int* ndim_out) {
-  if (!h) return -1;
-  auto it = h->taps.find(name ? name : "");
-  if (it == h->taps.end()) return fail(h, "imx_debug_fetch: no tap named '%s'", name ? name : "(null)");
-  int64_t n = 1;
-  for (int64_t v : it->second.shape) n *= v;
-  if (ndim_out) *ndim_out = (int)it->second.shape.size();
-  if (shape_out) for (size_t i = 0; i < it->second.shape.size() && i < 4; ++i) shape_out[i] = it->second.shape[i];
-  if (!host_out) return 0;   // shape query
-  if (capacity < n) return fail(h, "imx_debug_fetch: capacity %lld < %lld elements", (long long)capacity, (long long)n);
-  HIP_OK(h, hipSetDevice(h->device));
-  HIP_OK(h, hipDeviceSynchronize());
-  HIP_OK(h, hipMemcpy(host_out, it->second.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-  return 0;
+  return guarded(h, "imx_debug_fetch", [&]() -> int {
+    if (!h) return -1;
+    auto it = h->taps.find(name ? name : "");
+    if (it == h->taps.end()) return fail(h, "imx_debug_fetch: no tap named '%s'", name ? name : "(null)");
+    int64_t n = 1;
+    for (int64_t v : it->second.shape) n *= v;
+    if (ndim_out) *ndim_out = (int)it->second.shape.size();
+    if (shape_out) for (size_t i = 0; i < it->second.shape.size() && i < 4; ++i) shape_out[i] = it->second.shape[i];
+    if (!host_out) return 0;   // shape query
+    if (capacity < n) return fail(h, "imx_debug_fetch: capacity %lld < %lld elements", (long long)capacity, (long long)n);
+    HIP_OK(h, hipSetDevice(h->device));
+    HIP_OK(h, hipDeviceSynchronize());
+    HIP_OK(h, hipMemcpy(host_out, it->second.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return 0;
+  });
 }
 
 int imx_set_timing(imx_handle_t h, int enable) {
-  if (!h) return -1;
-  h->timing = enable != 0;
-  return 0;
+  return guarded(h, "imx_set_timing", [&]() -> int {
+    if (!h) return -1;
+    h->timing = enable != 0;
+    return 0;
+  });
 }
 
 int imx_timing_reset(imx_handle_t h) {
-  if (!h) return -1;
-  (void)hipSetDevice(h->device);
-  (void)hipDeviceSynchronize();
-  for (auto& e : h->events) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
-  h->events.clear();
-  h->report.clear();
-  return 0;
+  return guarded(h, "imx_timing_reset", [&]() -> int {
+    if (!h) return -1;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (auto& e : h->events) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+    h->events.clear();
+    h->report.clear();
+    return 0;
+  });
 }
 
 int imx_timing_report(imx_handle_t h, int index, const char** name_out, int64_t* launches_out, double* total_ms_out) {
-  if (!h) return -1;
-  if (index < 0) {   // (re)build the report; returns the number of rows
-    HIP_OK(h, hipSetDevice(h->device));
-    HIP_OK(h, hipDeviceSynchronize());
-    std::map<std::string, TimingRow> agg;
-    std::vector<std::string> order;
-    for (auto& e : h->events) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, e.e0, e.e1) != hipSuccess) continue;
-      auto it = agg.find(e.name);
-      if (it == agg.end()) { agg[e.name] = TimingRow{e.name, 1, ms}; order.push_back(e.name); }
-      else { it->second.launches++; it->second.ms += ms; }
+  return guarded(h, "imx_timing_report", [&]() -> int {
+    if (!h) return -1;
+    if (index < 0) {   // (re)build the report; returns the number of rows
+      HIP_OK(h, hipSetDevice(h->device));
+      HIP_OK(h, hipDeviceSynchronize());
+      std::map<std::string, TimingRow> agg;
+      std::vector<std::string> order;
+      for (auto& e : h->events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.e0, e.e1) != hipSuccess) continue;
+        auto it = agg.find(e.name);
+        if (it == agg.end()) { agg[e.name] = TimingRow{e.name, 1, ms}; order.push_back(e.name); }
+        else { it->second.launches++; it->second.ms += ms; }
+      }
+      h->report.clear();
+      for (auto& n : order) h->report.push_back(agg[n]);
+      return (int)h->report.size();
     }
-    h->report.clear();
-    for (auto& n : order) h->report.push_back(agg[n]);
-    return (int)h->report.size();
-  }
-  if ((size_t)index >= h->report.size()) return fail(h, "imx_timing_report: index %d out of range", index);
-  if (name_out) *name_out = h->report[index].name.c_str();
-  if (launches_out) *launches_out = h->report[index].launches;
-  if (total_ms_out) *total_ms_out = h->report[index].ms;
-  return 0;
+    if ((size_t)index >= h->report.size()) return fail(h, "imx_timing_report: index %d out of range", index);
+    if (name_out) *name_out = h->report[index].name.c_str();
+    if (launches_out) *launches_out = h->report[index].launches;
+    if (total_ms_out) *total_ms_out = h->report[index].ms;
+    return 0;
+  });
 }
 
 }  // extern "C"

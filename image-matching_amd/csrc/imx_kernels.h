@@ -13,9 +13,6 @@ struct ConvArgs {
   const float* in2;
   int split;
   const float* w;     // [9][Cin][Cout]  (BN folded)
-  const float* wu;    // Winograd F(2x2,3x3) weights G g G^T: [Cout/64][Cin/8][16 pos][2][4][4][16] (conv3x3_wino.hip)
-  const float* wu4;   // same values, [Cout/64][Cin/8][16 pos][8 ci][64 co] (conv3x3_wino4.hip)
-  const float* wu6;   // same values, [Cout/64][Cin/8][2 k-steps][4 pos groups][4 co-blocks][64 lanes][4 pos] (conv3x3_wino6.hip)
   const float* wu24;  // Winograd F(2x4,3x3) weights G2 g G4^T: [Cout/64][Cin/8][12 quads][4 co-blocks][64 lanes][4] (conv1ab_wino24.hip, conv3x3_wino24.hip)
   const float* bias;  // [Cout]
   const float* w1;    // FIRST mode: conv1a weights [9][64] and bias [64] (BN folded), Cin == 64
@@ -26,15 +23,10 @@ struct ConvArgs {
 };
 // Cin % 16 == 0, Cout % 64 == 0.
 hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);       // direct form (conv3x3.hip)
-// Cin % 8 == 0, Cout % 64 == 0.
-hipError_t launch_conv3x3_wino(const ConvArgs& a, hipStream_t s);  // Winograd F(2x2,3x3), 16x16x4 MFMA, 2 groups / CU
-hipError_t launch_conv3x3_wino4(const ConvArgs& a, hipStream_t s); // Winograd F(2x2,3x3), 32x32x2 MFMA, software pipelined
-// Cin % 16 == 0, Cout % 64 == 0.
-hipError_t launch_conv3x3_wino6(const ConvArgs& a, hipStream_t s); // Winograd F(2x2,3x3), persistent producer/consumer waves
 // first && pool, Cin == Cout == 64.
 hipError_t launch_conv1ab_wino24(const ConvArgs& a, hipStream_t s); // fused conv1a + conv1b (Winograd F(2x4,3x3)) + pool
 // Cin % 32 == 0, Cout % 64 == 0, not first.
-bool conv3x3_wino24_supported(const ConvArgs& a);                   // false (e.g. an image of >= 2 GB per layer): callers fall back to wino6
+bool conv3x3_wino24_supported(const ConvArgs& a);                   // false (e.g. an image of >= 2 GB per layer): callers fall back to the direct form
 hipError_t launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s); // Winograd F(2x4,3x3), persistent, in-stream transform
 
 // ---------------------------------------------------------------- GEMM (MFMA fp32): 1x1 conv / linear

@@ -265,7 +265,9 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
   __syncthreads();
   const int rows = min(R, m + 1 - i0);      // rows of this slab, the last may be the dustbin row
   float2* pb = reinterpret_cast<float2*>(part + ((size_t)b * nslab_max + slab) * (a.N1p + 1) * 2);
-  const bool fastcol = rows == R && n == a.N1p;
+  // all R rows REAL (i0 + R <= m): `rows == R` alone also admits a slab whose last row is the dustbin row i == m
+  // (m % R == R-1), and that row of `tile` is never written by the row pass
+  const bool fastcol = i0 + R <= m && n == a.N1p;
   if (fastcol) {
     // Fast path (uniform): a full slab of real rows, every column real -- no masks; the dustbin column (j = n) is left to
     // the generic loop below, which then runs for one thread only

@@ -213,6 +213,7 @@ def synth_pair(seed, H, W, shift=(8, 16), noise=0.01):
 SP_SEED, SG_SEED = 123, 456
 SG_GAINS = {".mlp.3.weight": 0.3, "final_proj.weight": 0.7}
 SG_CONFIGS = {      # descriptor_dim -> (keypoint_encoder, sinkhorn_iterations, match_threshold)
+    64: ([32, 64], 30, 0.1),                  # README.md:134-140 pairing (descriptor_dim 64, HD = 16)
     128: ([32, 64, 128], 30, 0.1),            # superpoint_glue_test.py:23,33-35 defaults (C3)
     256: ([32, 64, 128, 256], 100, 0.2),      # SuperGlue.default_config (C5)
 }

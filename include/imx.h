@@ -45,7 +45,7 @@ typedef struct imx_handle_s* imx_handle_t;
  * (superglue_test.py:195-202), merged with the user's config by the Python classes. */
 typedef struct imx_config {
   /* SuperPoint */
-  int32_t descriptor_dim;      /* 'descriptor_dim' (multiple of 32; 4 heads => multiple of 128 for SuperGlue) */
+  int32_t descriptor_dim;      /* 'descriptor_dim': 64, 128 or 256 with SuperGlue (4 heads of 16/32/64 dims); multiple of 32 */
   int32_t nms_radius;          /* 'nms_radius' (0..8)                                   */
   float keypoint_threshold;    /* 'keypoint_threshold'                                  */
   int32_t max_keypoints;       /* 'max_keypoints' (-1 = keep all)                       */
@@ -183,7 +183,8 @@ int imx_timing_report(imx_handle_t h, int index, const char** name_out, int64_t*
                       double* total_ms_out);
 int imx_timing_reset(imx_handle_t h);
 
-/* Library build string, e.g. "imx 0.1 gfx950 hip-7.2". */
+/* Library build string, e.g. "imx 0.2 gfx950 hip-7.2 fp32-mfma build 3f2a91c07d1e" (the id is a digest of the library
+ * sources: measurements taken on one build are only quoted for that build). */
 const char* imx_version(void);
 
 #ifdef __cplusplus

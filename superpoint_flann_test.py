@@ -17,6 +17,7 @@ import torch
 
 from image_matching_amd import hostops, synth
 from image_matching_amd.superpoint.models.superpoint_test import SuperPoint
+import superpoint_glue_test as glue_cli
 from superpoint_glue_test import load_pair, write_synthetic_dataset
 
 MIN_MATCH_COUNT = 4
@@ -88,20 +89,17 @@ def main(argv=None):
             m, dist1, _ = eng.knn_ratio_match(d1[None], d2[None], ratio=RATIO)
             n_good = int((m >= 0).sum())
         if n_good > MIN_MATCH_COUNT:
-            if opt.ransac == 'gpu':
-                M, inl, ninl = eng.estimate_affine_partial(kp1[None], kp2[None], m, ransac_thresh=7)
-                ok = int(ninl[0]) > 0
-                Matrix, inl = M[0].double().cpu().numpy(), inl[0].cpu().numpy().astype(bool)
             m_h, dist_h = m[0].cpu().numpy(), dist1[0].cpu().numpy()
             KeyP1, KeyP2 = kp1.cpu().numpy(), kp2.cpu().numpy()
             good = m_h >= 0
             src_pts, dst_pts, match_dist = KeyP1[good], KeyP2[m_h[good]], dist_h[good]
-            if opt.ransac == 'host':
+            Matrix, mask = None, None
+            if opt.ransac == 'gpu':     # matched pairs compacted on the device; (None, None) when the GPU path does not apply
+                Matrix, mask = glue_cli.gpu_affine_partial(eng, {'matches0': m, 'keypoints0': [kp1], 'keypoints1': [kp2]}, 7)
+            if mask is None:
                 Matrix, mask = hostops.estimate_affine_partial_2d(src_pts, dst_pts, ransac_thresh=7)
-                ok = Matrix is not None
-                RansacMask = (np.asarray(mask) == 1).ravel() if ok else np.zeros(len(src_pts), bool)
-            else:
-                RansacMask = inl[good]
+            ok = Matrix is not None
+            RansacMask = (np.asarray(mask) == 1).ravel() if ok else np.zeros(len(src_pts), bool)
             if not ok:                  # the reference would raise on a None matrix: skip the pair
                 print(f"[imx] {filename}: RANSAC found no model, skipping")
                 results.append((filename, n_good, 0, None))

@@ -114,6 +114,30 @@ def main(argv=None):
     return run_registration(opt, matching, device)
 
 
+RANSAC_GPU_MAX = 8192      # imx_estimate_affine_partial: keypoint slots per pair (include/imx.h)
+
+
+def gpu_affine_partial(eng, pred, thresh):
+    """RANSAC partial-affine fit on the GPU over the MATCHED pairs only (compacted on the device, so the kernel's slot limit
+    applies to the number of matches, not to --max_keypoints -1 keypoint counts).  Returns (M or None, mask (n,1)) like
+    cv2.estimateAffinePartial2D, or (None, None) when the GPU path does not apply -- the caller then uses the host fit."""
+    from image_matching_amd.engine import ImxError
+    m0 = pred['matches0'][0].long()
+    sel = m0 > -1
+    n = int(sel.sum())
+    if n <= 3 or n > RANSAC_GPU_MAX:
+        return None, None
+    mk0 = pred['keypoints0'][0][sel][None].contiguous()
+    mk1 = pred['keypoints1'][0][m0[sel]][None].contiguous()
+    ident = torch.arange(n, device=m0.device, dtype=torch.int64)[None]
+    try:
+        M, inl, ninl = eng.estimate_affine_partial(mk0, mk1, ident, ransac_thresh=thresh)
+    except ImxError as e:
+        print(f"[imx] GPU RANSAC unavailable ({e}); falling back to the host fit")
+        return None, None
+    return (M[0].cpu().numpy() if int(ninl[0]) > 0 else None), inl[0].cpu().numpy()[:, None]
+
+
 def run_registration(opt, matching, device):
     """The per-pair loop shared by superpoint_glue_test.py:72-140 and superpoint_glue_official_test.py:66-137."""
     source_dir = opt.img_dir + 'source1/'
@@ -127,11 +151,6 @@ def run_registration(opt, matching, device):
         template_tensor = torch.from_numpy(template_image)[None].float().to(device)
         start = time.perf_counter()
         pred = matching({'image0': source_tensor, 'image1': template_tensor})
-        M_gpu = None
-        if opt.ransac == 'gpu' and pred['keypoints0'][0].shape[0] and pred['keypoints1'][0].shape[0]:
-            eng = matching._shared.engine          # RANSAC runs on the GPU before anything is copied back
-            M_gpu, inl_gpu, ninl_gpu = eng.estimate_affine_partial(pred['keypoints0'][0][None], pred['keypoints1'][0][None],
-                                                                   pred['matches0'].long(), ransac_thresh=7)
         kpts0 = pred['keypoints0'][0].cpu().numpy()
         kpts1 = pred['keypoints1'][0].cpu().numpy()
         matches = pred['matches0'][0].cpu().numpy()
@@ -139,10 +158,10 @@ def run_registration(opt, matching, device):
         valid = matches > -1
         mkpts0, mkpts1 = kpts0[valid], kpts1[matches[valid]]
         if len(mkpts0) > 3:
-            if M_gpu is not None:
-                M = M_gpu[0].cpu().numpy() if int(ninl_gpu[0]) > 0 else None
-                mask = inl_gpu[0].cpu().numpy()[valid][:, None]
-            else:
+            M, mask = None, None
+            if opt.ransac == 'gpu':
+                M, mask = gpu_affine_partial(matching._shared.engine, pred, 7)
+            if mask is None:       # --ransac host, more matched pairs than the kernel takes, or a failed GPU call
                 M, mask = hostops.estimate_affine_partial_2d(mkpts0, mkpts1, ransac_thresh=7)
             if M is not None:       # the reference crashes on a failed fit; we keep the last matrix
                 Matrix = np.array(M, dtype=np.float64)

@@ -116,6 +116,22 @@ def sg_dense(sg, data):
             "mdesc0": m0, "mdesc1": m1, "scores_in": sc, "Z": Z}
 
 
+def sg_dense_f64(sg, data):
+    """The same reference sub-module calls evaluated in float64 (a deep copy of the module cast with .double()):
+    the anchor the fp32 implementations (reference fp32, HIP fp32) are both measured against."""
+    import copy
+    sg64 = copy.deepcopy(sg).double()
+    d64 = {k: (v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in data.items()}
+    out = sg_dense(sg64, d64)
+    return {k: v for k, v in out.items() if k != "taps"}
+
+
+def envelope(a32, a64):
+    """(max, rms) of |fp32 - fp64| -- the reference's own fp32 rounding envelope on a tensor."""
+    e = (a32.double() - a64).abs()
+    return np.array([float(e.max()), float(e.pow(2).mean().sqrt())])
+
+
 def match_margins(Z, r, thr):
     """min top1-top2 gap over rows/cols that produced a match, min |mscore-thr| over mutual."""
     Zi = Z[0, :-1, :-1]
@@ -201,6 +217,26 @@ def main():
         sg_bin[d] = float(sc.mean() + 2.0 * sc.std())                      # mean+2σ
         stats_all[f"sg{d}/bin_score"] = np.float32(sg_bin[d])
         print(f"  d={d}: scores_in mean {sc.mean():.3f} std {sc.std():.3f} max {sc.max():.2f} -> bin_score {sg_bin[d]:.4f}")
+    # descriptor_dim 64 / keypoint_encoder [32, 64] (reference README.md:134-140), added in round 2 AFTER the 128/256
+    # entries so those stay bit-identical
+    sg_cfgs[64] = (synth.SG_CONFIGS[64][0], synth.SG_CONFIGS[64][1], synth.SG_CONFIGS[64][2])
+    sp, _ = build_sp(64, 1024)
+    st = calibrate(sp, lambda: sp(xb))
+    sp_stats[64] = st
+    for k, v in st.items():
+        stats_all[f"sp64/{k}"] = v
+    sp, _ = build_sp(64, 1024, sp_stats[64])
+    o0, o1 = sp(x0), sp(x1)
+    data = sg_data(x0, x1, o0, o1)
+    sg, _ = build_sg(64, *sg_cfgs[64])
+    st = calibrate(sg, lambda: sg(data))
+    sg_stats[64] = st
+    for k, v in st.items():
+        stats_all[f"sg64/{k}"] = v
+    sc = sg_dense(sg, data)["scores_in"]
+    sg_bin[64] = float(sc.mean() + 2.0 * sc.std())
+    stats_all["sg64/bin_score"] = np.float32(sg_bin[64])
+    print(f"  d=64: scores_in mean {sc.mean():.3f} std {sc.std():.3f} max {sc.max():.2f} -> bin_score {sg_bin[64]:.4f}")
     np.savez_compressed(os.path.join(DATA, "synth_bn_stats.npz"), **stats_all)
     print("  wrote synth_bn_stats.npz", os.path.getsize(os.path.join(DATA, "synth_bn_stats.npz")) // 1024, "KB")
 
@@ -303,6 +339,12 @@ def main():
         empty_dtype=str(r3["matches0"].dtype), normal_dtype=str(r2["matches0"].dtype),
         **{f"margin_{k}": v for k, v in mg2.items()})
 
+    anchors = {}          # fp64 anchors (round 2): filled below, written as fp64_anchor.npz
+    a64 = sg_dense_f64(sg, data)
+    for k in ("gnn0", "gnn1", "scores_in", "Z"):
+        anchors[f"sg_small/{k}_f64"] = a64[k]
+        anchors[f"sg_small/{k}_ref32_err"] = envelope(dn[k], a64[k])
+
     # ---------------------------------------------------------------- C3 end to end (Matching)
     for name, H, W, d, K, seeds in (("c3_pair", 480, 640, 128, 1024, (59, 55)),
                                     ("c5_pair", 960, 1280, 256, 2048, (19,))):
@@ -338,6 +380,95 @@ def main():
                 Z_sub=dn["Z"][0, ::8, ::8], scores_in_sub=dn["scores_in"][0, ::8, ::8],
                 out_dtypes=str({k: (str(v.dtype) if isinstance(v, torch.Tensor) else type(v).__name__ + ":" + str(v[0].dtype)) for k, v in pred.items()}),
                 **{f"margin_{k}": v for k, v in mg.items()})
+            # fp64 anchor of the same forward (reference module in double, same keypoints/descriptors)
+            a64 = sg_dense_f64(m.superglue, data)
+            tag = f"{name}_s{seed}"
+            anchors[f"{tag}/scores_in_sub_f64"] = a64["scores_in"][0, ::8, ::8]
+            anchors[f"{tag}/Z_sub_f64"] = a64["Z"][0, ::8, ::8]
+            anchors[f"{tag}/scores_in_ref32_err"] = envelope(dn["scores_in"][0, ::8, ::8], a64["scores_in"][0, ::8, ::8])
+            anchors[f"{tag}/Z_ref32_err"] = envelope(dn["Z"][0, ::8, ::8], a64["Z"][0, ::8, ::8])
+            print("  fp32-vs-fp64 (max, rms): scores_in", anchors[f"{tag}/scores_in_ref32_err"], "Z", anchors[f"{tag}/Z_ref32_err"])
+    npz("fp64_anchor.npz", **anchors)
+
+    # ---------------------------------------------------------------- descriptor_dim 64 (HD = 16), small, dense
+    print("sg_small_d64 (d=64, keypoint_encoder [32,64], reference README.md:134-140)")
+    kenc, iters, thr = sg_cfgs[64]
+    sp, _ = build_sp(64, 200, sp_stats[64])
+    xa, xb_ = pair_tensor(12, 120, 160)
+    dn_sp = sp_dense(sp, torch.cat([xa, xb_]))
+    cands = [np.sort(ref_sp_mod.remove_borders(torch.nonzero(s_ > 0.005), s_[s_ > 0.005], 4, s_.shape[0], s_.shape[1])[1].numpy())[::-1]
+             for s_ in dn_sp["nms"]]
+    K64 = max(range(180, 221), key=lambda k: min(c[k - 1] - c[k] for c in cands))
+    sp, _ = build_sp(64, K64, sp_stats[64])
+    o0, o1 = sp(xa), sp(xb_)
+    data = sg_data(xa, xb_, o0, o1)
+    sg, _ = build_sg(64, kenc, iters, thr, sg_stats[64], sg_bin[64])
+    r = sg(data)
+    dn = sg_dense(sg, data)
+    mg = match_margins(dn["Z"], r, thr)
+    print("  K", K64, "matches", int((r["matches0"] > -1).sum()), mg)
+    a64 = sg_dense_f64(sg, data)
+    npz("sg_small_d64.npz", H=120, W=160, seed=12, max_keypoints=K64,
+        keypoints0=data["keypoints0"], keypoints1=data["keypoints1"], scores0=data["scores0"], scores1=data["scores1"],
+        descriptors0=data["descriptors0"], descriptors1=data["descriptors1"],
+        kenc0=dn["kenc0"], kenc1=dn["kenc1"], tap0_0=dn["taps"][0][0], tap0_1=dn["taps"][0][1],
+        gnn0=dn["gnn0"], gnn1=dn["gnn1"], scores_in=dn["scores_in"], Z=dn["Z"],
+        gnn0_f64=a64["gnn0"], gnn1_f64=a64["gnn1"], scores_in_f64=a64["scores_in"], Z_f64=a64["Z"],
+        matches0=r["matches0"], matches1=r["matches1"],
+        matching_scores0=r["matching_scores0"], matching_scores1=r["matching_scores1"],
+        **{f"margin_{k}": v for k, v in mg.items()})
+
+    # ---------------------------------------------------------------- unselected seed sweeps (no rejection)
+    for name, H, W, d, K, seeds in (("sweep_c3", 480, 640, 128, 1024, range(1000, 1032)),
+                                    ("sweep_c5", 960, 1280, 256, 2048, range(2000, 2008))):
+        kenc, iters, thr = sg_cfgs[d]
+        cfg = {"superpoint": {"weights": None, "descriptor_dim": d, "nms_radius": 4,
+                              "keypoint_threshold": 0.005, "max_keypoints": K},
+               "superglue": {"weights": None, "descriptor_dim": d, "keypoint_encoder": kenc,
+                             "sinkhorn_iterations": iters, "match_threshold": thr}}
+        m = Matching(cfg).eval()
+        _, sd_sp = build_sp(d, K, sp_stats[d])
+        _, sd_sg = build_sg(d, kenc, iters, thr, sg_stats[d], sg_bin[d])
+        m.superpoint.load_state_dict(to_torch(sd_sp))
+        m.superglue.load_state_dict(to_torch(sd_sg))
+        rows = {k: [] for k in ("kpts0", "kpts1", "scores0", "scores1", "matches0", "matches1", "idx0", "idx1", "gap0", "gap1", "thr_gap0",
+                                "topk_gap", "n_matches")}
+        for seed in seeds:
+            xa, xb_ = pair_tensor(seed, H, W)
+            pred = m({"image0": xa, "image1": xb_})
+            assert len(pred["scores0"][0]) == K and len(pred["scores1"][0]) == K
+            data = {"image0": xa, "image1": xb_, **{k: torch.stack(list(v)) for k, v in pred.items() if isinstance(v, (list, tuple))}}
+            Z = sg_dense(m.superglue, data)["Z"][0, :-1, :-1]
+            t0, t1 = Z.topk(2, dim=1), Z.topk(2, dim=0)
+            # the indices the reference itself uses (superglue_test.py:268: Tensor.max -> FIRST maximal index); topk's
+            # order among exactly equal values is arbitrary (seed 1010 has an exact two-way tie: gap 0)
+            i0, i1 = Z.max(1).indices, Z.max(0).indices
+            mutual = i1[i0] == torch.arange(K)
+            tg = torch.where(mutual, (t0.values[:, 0] - float(np.log(thr))).abs(), torch.full((K,), float("inf")))
+            # top-k boundary of SuperPoint: gap between the last kept and the first dropped candidate score, per image
+            gaps = []
+            for x_ in (xa, xb_):
+                nm = sp_dense(m.superpoint, x_)["nms"][0]
+                sel = nm > 0.005
+                cs = ref_sp_mod.remove_borders(torch.nonzero(sel), nm[sel], 4, nm.shape[0], nm.shape[1])[1].numpy()
+                gaps.append(topk_margin(cs, K)[0])
+            nmatch = int((pred["matches0"] > -1).sum())
+            print(f"{name} seed {seed}: matches {nmatch}, min row gap {float((t0.values[:, 0] - t0.values[:, 1]).min()):.2e}, "
+                  f"min thr gap {float(tg.min()):.2e}, top-k gaps {gaps[0]:.2e} {gaps[1]:.2e}")
+            rows["kpts0"].append(pred["keypoints0"][0].numpy().astype(np.int16))
+            rows["kpts1"].append(pred["keypoints1"][0].numpy().astype(np.int16))
+            rows["scores0"].append(pred["scores0"][0].numpy())
+            rows["scores1"].append(pred["scores1"][0].numpy())
+            rows["matches0"].append(pred["matches0"][0].numpy().astype(np.int16))
+            rows["matches1"].append(pred["matches1"][0].numpy().astype(np.int16))
+            rows["idx0"].append(i0.numpy().astype(np.int16))
+            rows["idx1"].append(i1.numpy().astype(np.int16))
+            rows["gap0"].append((t0.values[:, 0] - t0.values[:, 1]).numpy())
+            rows["gap1"].append((t1.values[0] - t1.values[1]).numpy())
+            rows["thr_gap0"].append(tg.numpy())
+            rows["topk_gap"].append(np.array(gaps, np.float32))
+            rows["n_matches"].append(nmatch)
+        npz(name + ".npz", H=H, W=W, d=d, K=K, seeds=np.array(list(seeds)), **{k: np.stack(v) for k, v in rows.items()})
 
 
 if __name__ == "__main__":

@@ -1,0 +1,229 @@
+"""Round-2 parity hardening (VERDICT r1 'weak' #1-#3, 'missing' #1): descriptor_dim 64 (head dim 16),
+Sinkhorn slabs whose last row is the dustbin row, and the UNSELECTED seed sweeps with margin-gated mismatch accounting.
+Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+KEYS = ("keypoints0", "keypoints1", "scores0", "scores1", "descriptors0", "descriptors1")
+
+
+def _engine(d, K=1024, **kw):
+    from image_matching_amd import _lib as L
+    from image_matching_amd.engine import Engine
+    return Engine(util.sp_config(d, K), util.sg_config(d, **kw), "cuda"), L
+
+
+def _run(eng, t, shp, n0=None, n1=None):
+    out = eng.superglue(t["keypoints0"], t["scores0"], t["descriptors0"], shp,
+                        t["keypoints1"], t["scores1"], t["descriptors1"], shp, n0, n1)
+    torch.cuda.synchronize()
+    return [o.cpu().numpy() for o in out]
+
+
+# ------------------------------------------------------------------------------------------ descriptor_dim 64
+def test_descriptor_dim_64_superpoint_and_superglue_vs_reference_golden():
+    """reference README.md:134-140: descriptor_dim 64 pairs with keypoint_encoder [32, 64] (4 heads of 16 dims)."""
+    g = util.golden("sg_small_d64.npz")
+    H, W, seed, K = int(g["H"]), int(g["W"]), int(g["seed"]), int(g["max_keypoints"])
+    eng, L = _engine(64, K)
+    sd_sp, sd_sg = util.sp_sd(64), util.sg_sd(64)
+    eng.load_state_dict(L.NET_SUPERPOINT, sd_sp)
+    eng.load_state_dict(L.NET_SUPERGLUE, sd_sg)
+    # SuperPoint with a 64-channel descriptor head: the fixture's SuperGlue inputs ARE the reference's SuperPoint outputs
+    x = torch.cat(util.pair(seed, H, W))
+    kpts, scores, desc, n = eng.superpoint(x.cuda())
+    for b in range(2):
+        assert n[b] == K and np.array_equal(kpts[b].cpu().numpy(), g[f"keypoints{b}"][0]), f"image {b}: keypoints / order differ"
+        util.assert_close(scores[b].cpu(), g[f"scores{b}"][0], "scores (d=64)")
+        util.assert_close(desc[b].t().cpu(), g[f"descriptors{b}"][0], "descriptors (d=64)")
+    # SuperGlue, reference keypoints in
+    eng.set_debug(True)
+    t = {k: torch.from_numpy(g[k]).cuda() for k in KEYS}
+    m0, m1, ms0, ms1 = _run(eng, t, (1, 1, H, W))
+    N0, N1 = g["keypoints0"].shape[1], g["keypoints1"].shape[1]
+    N0p = (N0 + 31) // 32 * 32
+
+    def rows(a):
+        return a[:N0].T[None], a[N0p:N0p + N1].T[None]
+    for tap, (r0, r1) in (("kenc", (g["kenc0"], g["kenc1"])), ("gnn0", (g["tap0_0"], g["tap0_1"]))):
+        a0, a1 = rows(eng.fetch(tap))
+        util.assert_close(a0, r0, tap + " side0 (d=64)")
+        util.assert_close(a1, r1, tap + " side1 (d=64)")
+    a0, a1 = rows(eng.fetch("gnn17"))
+    util.assert_fp64_anchored(a0, g["gnn0"], g["gnn0_f64"], "d=64 gnn17 side0")
+    util.assert_fp64_anchored(a1, g["gnn1"], g["gnn1_f64"], "d=64 gnn17 side1")
+    S = eng.fetch("scores_in")[:, :N0, :N1]
+    util.assert_fp64_anchored(S, g["scores_in"], g["scores_in_f64"], "d=64 scores_in")
+    Z = util.transport_Z(S[0], eng.fetch("u")[0], eng.fetch("v")[0], N0, N1, float(sd_sg["bin_score"]))
+    util.assert_fp64_anchored(Z[None], g["Z"], g["Z_f64"], "d=64 Z")
+    assert np.array_equal(m0, g["matches0"]) and np.array_equal(m1, g["matches1"]), "match indices must be bit-exact (d=64)"
+    util.assert_close(ms0, g["matching_scores0"], "matching_scores0 (d=64)")
+    assert int((m0 > -1).sum()) > 0
+
+
+def test_descriptor_dim_64_matching_forward_and_ragged_counts_vs_oracle():
+    """End to end at d=64 through the drop-in Matching, and unequal keypoint counts (padding rows in the 64-key staged tiles)."""
+    from image_matching_amd.superglue.models.matching_test import Matching
+    from oracle import matching_ref, superglue_ref
+    d, K, H, W = 64, 150, 120, 160
+    cfg = {"superpoint": util.sp_config(d, K), "superglue": util.sg_config(d)}
+    sd_sp, sd_sg = util.sp_sd(d), util.sg_sd(d)
+    m = Matching(cfg).eval().to("cuda")
+    m.superpoint.load_state_dict(sd_sp)
+    m.superglue.load_state_dict(sd_sg)
+    x0, x1 = util.pair(12, H, W)
+    pred = m({"image0": x0.cuda(), "image1": x1.cuda()})
+    ref = matching_ref.matching_forward({"image0": x0, "image1": x1}, sd_sp, sd_sg, cfg)
+    assert pred["descriptors0"][0].shape == (d, K)
+    assert np.array_equal(pred["keypoints0"][0].cpu().numpy(), ref["keypoints0"][0].numpy())
+    assert np.array_equal(pred["matches0"].cpu().numpy(), ref["matches0"].numpy())
+    # ragged: 97 vs 150 keypoints
+    data = {"keypoints0": ref["keypoints0"][0][None, :97], "keypoints1": ref["keypoints1"][0][None],
+            "scores0": ref["scores0"][0][None, :97], "scores1": ref["scores1"][0][None],
+            "descriptors0": ref["descriptors0"][0][None, :, :97], "descriptors1": ref["descriptors1"][0][None],
+            "image0": x0, "image1": x1}
+    r2 = superglue_ref.superglue_forward(data, sd_sg, cfg["superglue"])
+    eng = m._shared.get_engine([1])
+    got = _run(eng, {k: v.cuda() for k, v in data.items() if k in KEYS}, (1, 1, H, W))
+    assert np.array_equal(got[0], r2["matches0"].numpy()) and np.array_equal(got[1], r2["matches1"].numpy())
+
+
+# ------------------------------------------------------------------------------------------ Sinkhorn slab edge
+@pytest.mark.parametrize("n0,n1", [(1023, 1024), (15, 32), (7, 64), (39, 32), (2047, 2048), (8, 32), (1, 32), (33, 1)])
+def test_sinkhorn_when_the_dustbin_row_closes_a_full_slab(n0, n1):
+    """with m % R == R-1 (R = 8 rows per LDS slab; R = 4 above 2048 columns) and every column real
+    (n == N1p) the last slab is 'full' but its last row is the dustbin row, which is never staged in LDS -- the unmasked
+    column fast path must not be taken for it.  Checked on the potentials' effect: Z from (scores_in, u, v) against the
+    oracle's log_optimal_transport on the SAME score matrix, and the exact column marginals of exp(Z)."""
+    from oracle import superglue_ref
+    d = 128
+    eng, L = _engine(d)
+    sd = util.sg_sd(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, sd)
+    eng.set_debug(True)
+    g = torch.Generator().manual_seed(n0 * 7919 + n1)
+    t = {"keypoints0": torch.rand(1, n0, 2, generator=g) * 600, "keypoints1": torch.rand(1, n1, 2, generator=g) * 600,
+         "scores0": torch.rand(1, n0, generator=g), "scores1": torch.rand(1, n1, generator=g),
+         "descriptors0": torch.nn.functional.normalize(torch.randn(1, d, n0, generator=g), dim=1),
+         "descriptors1": torch.nn.functional.normalize(torch.randn(1, d, n1, generator=g), dim=1)}
+    m0, m1, ms0, ms1 = _run(eng, {k: v.cuda() for k, v in t.items()}, (1, 1, 480, 640))
+    S = eng.fetch("scores_in")[0, :n0, :n1]
+    u, v = eng.fetch("u")[0], eng.fetch("v")[0]
+    assert np.isfinite(u[:n0 + 1]).all() and np.isfinite(v[:n1 + 1]).all(), "non-finite Sinkhorn potentials"
+    Z = util.transport_Z(S, u, v, n0, n1, float(sd["bin_score"]))
+    Zr = superglue_ref.log_optimal_transport(torch.from_numpy(S.copy())[None], sd["bin_score"], iters=30)[0].numpy()
+    err = np.abs(Z.astype(np.float64) - Zr)
+    assert err.max() < 2e-3 * max(1.0, np.abs(Zr).max() / 50), f"Z differs from the oracle's on the same scores: max {err.max():.3e}"
+    P = np.exp(Z.astype(np.float64))
+    np.testing.assert_allclose(P[:, :n1].sum(0), 1.0, rtol=5e-4)       # the loop ends on a v update: exact column marginals
+    np.testing.assert_allclose(P[:, n1].sum(), float(n0), rtol=5e-4)
+    i0, i1, r0, r1 = superglue_ref.extract_matches(torch.from_numpy(Z)[None], 0.1)
+    assert np.array_equal(m0, i0.numpy()) and np.array_equal(m1, i1.numpy()), "match extraction differs on the library's own Z"
+
+
+# ------------------------------------------------------------------------------------------ unselected seed sweeps
+def _explainable0(i, g, s, tau):
+    """A differing matches0[i] is explained by the reference's own margins: row i's top-1/top-2 gap, the gap of the column
+    its argmax points to, or its distance to the match threshold (all in Z units) below tau."""
+    j = int(g["idx0"][s][i])
+    return g["gap0"][s][i] < tau or g["gap1"][s][j] < tau or g["thr_gap0"][s][i] < tau
+
+
+def _explainable1(j, g, s, tau):
+    i = int(g["idx1"][s][j])
+    return g["gap1"][s][j] < tau or g["gap0"][s][i] < tau or g["thr_gap0"][s][i] < tau
+
+
+@pytest.mark.parametrize("name", ["sweep_c3.npz", "sweep_c5.npz"])
+def test_unselected_seed_sweep_superglue_decisions(name):
+    """consecutive seeds with NO rejection (32 at C3, 8 at C5).  The reference's keypoints and scores
+    are injected (descriptors re-sampled by the oracle at those keypoints, so no top-k decision is involved); every match
+    index that differs from the reference's must sit on a row/column whose reference margin (top-1 minus top-2 of Z, or the
+    distance to the match threshold) is below 2x the Z error measured on that very pair against the oracle.  The mismatch
+    rate is printed."""
+    from oracle import superglue_ref, superpoint_ref
+    g = util.golden(name)
+    H, W, d, K = (int(g[k]) for k in ("H", "W", "d", "K"))
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    eng, L = _engine(d, K)
+    sd_sp, sd_sg = util.sp_sd(d), util.sg_sd(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, sd_sg)
+    eng.set_debug(True)
+    total, bad, unexplained, worst_z = 0, 0, [], 0.0
+    for s, seed in enumerate(g["seeds"]):
+        x0, x1 = util.pair(int(seed), H, W)
+        data = {"image0": x0, "image1": x1}
+        for side, x in (("0", x0), ("1", x1)):
+            dense = superpoint_ref.superpoint_forward(x, sd_sp, util.sp_config(d, K), return_dense=True)["desc"]
+            kp = torch.from_numpy(g["kpts" + side][s].astype(np.float32))[None]
+            data["keypoints" + side] = kp
+            data["scores" + side] = torch.from_numpy(g["scores" + side][s])[None]
+            data["descriptors" + side] = superpoint_ref.sample_descriptors(kp, dense, 8)
+        m0, m1, ms0, ms1 = _run(eng, {k: data[k].cuda() for k in KEYS}, (1, 1, H, W))
+        ref = superglue_ref.superglue_forward(data, sd_sg, util.sg_config(d), return_dense=True)
+        Z = util.transport_Z(eng.fetch("scores_in")[0], eng.fetch("u")[0], eng.fetch("v")[0], K, K, float(sd_sg["bin_score"]))
+        zerr = float(np.abs(Z.astype(np.float64) - ref["dense"]["Z"][0].numpy()).max())
+        worst_z = max(worst_z, zerr)
+        tau = 2.0 * zerr
+        r0, r1 = g["matches0"][s].astype(np.int64), g["matches1"][s].astype(np.int64)
+        d0, d1 = np.nonzero(m0[0] != r0)[0], np.nonzero(m1[0] != r1)[0]
+        total += 2 * K
+        bad += len(d0) + len(d1)
+        unexplained += [(int(seed), 0, int(i), float(g["gap0"][s][i])) for i in d0 if not _explainable0(i, g, s, tau)]
+        unexplained += [(int(seed), 1, int(j), float(g["gap1"][s][j])) for j in d1 if not _explainable1(j, g, s, tau)]
+        if len(d0) + len(d1):
+            print(f"[sweep] {name} seed {seed}: {len(d0)}+{len(d1)} differing indices, Z err {zerr:.2e}, "
+                  f"row gaps {[float(g['gap0'][s][i]) for i in d0][:4]}")
+    print(f"[sweep] {name}: {bad} of {total} match indices differ from the reference over {len(g['seeds'])} unselected seeds "
+          f"(rate {bad / total:.2e}); worst Z error vs the oracle {worst_z:.2e}; unexplained {len(unexplained)}")
+    assert not unexplained, f"match indices differ where the reference's margin exceeds 2x the measured Z error: {unexplained[:8]}"
+    assert bad <= 0.002 * total, f"mismatch rate {bad / total:.2e} is implausibly high for margin noise"
+
+
+@pytest.mark.parametrize("name", ["sweep_c3.npz", "sweep_c5.npz"])
+def test_unselected_seed_sweep_end_to_end(name):
+    """The same unselected seeds through the whole HIP path (images in, matched coordinate pairs out).  Keypoint SETS may
+    differ from the reference's only where the top-k boundary gap (last kept minus first dropped score) is below 2e-5 (the
+    score map carries ~6e-6 of fp32 noise); on pairs whose keypoint sets agree, every matched coordinate pair that differs
+    must be explained by the reference's margins (tau = 2e-3: the end-to-end Z error with HIP descriptors, measured
+    3e-4..6e-4 in round 1, x2 and rounded up)."""
+    from image_matching_amd.superglue.models.matching_test import Matching
+    g = util.golden(name)
+    H, W, d, K = (int(g[k]) for k in ("H", "W", "d", "K"))
+    m = Matching({"superpoint": util.sp_config(d, K), "superglue": util.sg_config(d)}).eval().to("cuda")
+    m.superpoint.load_state_dict(util.sp_sd(d))
+    m.superglue.load_state_dict(util.sg_sd(d))
+    tau, n_pairs_ref, n_diff, kp_diff_images, unexplained = 2e-3, 0, 0, 0, []
+    for s, seed in enumerate(g["seeds"]):
+        x0, x1 = util.pair(int(seed), H, W)
+        pred = m({"image0": x0.cuda(), "image1": x1.cuda()})
+        k0, k1 = pred["keypoints0"][0].cpu().numpy().astype(int), pred["keypoints1"][0].cpu().numpy().astype(int)
+        same = True
+        for side, k in ((0, k0), (1, k1)):
+            mine, ref = set(map(tuple, k)), set(map(tuple, g[f"kpts{side}"][s].astype(int)))
+            if mine != ref:
+                same = False
+                kp_diff_images += 1
+                gap = float(g["topk_gap"][s][side])
+                assert gap < 2e-5 and len(mine ^ ref) <= 8, \
+                    f"seed {seed} image {side}: keypoint sets differ by {len(mine ^ ref)} with a top-k boundary gap of {gap:.2e}"
+        if not same:
+            continue                      # indices are not comparable row by row when the sets differ
+        pos0 = {tuple(p): i for i, p in enumerate(g["kpts0"][s].astype(int))}
+        pos1 = {tuple(p): i for i, p in enumerate(g["kpts1"][s].astype(int))}
+        m0 = pred["matches0"][0].cpu().numpy()
+        mine = np.full(K, -1, np.int64)                       # my matches0 re-indexed in the reference's keypoint order
+        for i, j in enumerate(m0):
+            mine[pos0[tuple(k0[i])]] = pos1[tuple(k1[j])] if j >= 0 else -1
+        r0 = g["matches0"][s].astype(np.int64)
+        diff = np.nonzero(mine != r0)[0]
+        n_pairs_ref += int((r0 >= 0).sum())
+        n_diff += len(diff)
+        unexplained += [(int(seed), int(i), float(g["gap0"][s][i])) for i in diff if not _explainable0(i, g, s, tau)]
+    print(f"[sweep e2e] {name}: keypoint sets differ on {kp_diff_images} of {2 * len(g['seeds'])} images (top-k boundary ties); "
+          f"{n_diff} differing rows over {n_pairs_ref} reference matches on the comparable pairs; unexplained {len(unexplained)}")
+    assert not unexplained, f"end-to-end matches differ where the reference's margin exceeds {tau}: {unexplained[:8]}"

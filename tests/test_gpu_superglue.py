@@ -37,18 +37,22 @@ def test_small_dense_and_matches_vs_reference_golden():
 
     def rows(a):
         return a[:N0].T[None], a[N0p:N0p + N1].T[None]
+    # early stages: the strict north_star tolerance, element-wise
     for tap, (r0, r1) in (("kenc", (g["kenc0"], g["kenc1"])), ("gnn0", (g["tap0_0"], g["tap0_1"])),
-                          ("gnn1", (g["tap1_0"], g["tap1_1"])), ("gnn17", (g["gnn0"], g["gnn1"]))):
+                          ("gnn1", (g["tap1_0"], g["tap1_1"]))):
         a0, a1 = rows(eng.fetch(tap))
-        util.assert_close(a0, r0, tap + " side0", scale_atol=True)
-        util.assert_close(a1, r1, tap + " side1", scale_atol=True)
+        util.assert_close(a0, r0, tap + " side0")
+        util.assert_close(a1, r1, tap + " side1")
+    # long fp32 reductions: anchored on the float64 evaluation of the reference module (fp64_anchor.npz)
+    an = util.golden("fp64_anchor.npz")
+    a0, a1 = rows(eng.fetch("gnn17"))
+    util.assert_fp64_anchored(a0, g["gnn0"], an["sg_small/gnn0_f64"], "gnn17 side0")
+    util.assert_fp64_anchored(a1, g["gnn1"], an["sg_small/gnn1_f64"], "gnn17 side1")
     S = eng.fetch("scores_in")[:, :N0, :N1]
-    util.assert_close(S, g["scores_in"], "scores_in", scale_atol=True)
+    util.assert_fp64_anchored(S, g["scores_in"], an["sg_small/scores_in_f64"], "scores_in")
     u, v = eng.fetch("u")[0], eng.fetch("v")[0]
-    Z = np.full((N0 + 1, N1 + 1), float(sd["bin_score"]), dtype=np.float32)
-    Z[:N0, :N1] = S[0]
-    Z = (Z + u[:N0 + 1, None]) + v[None, :N1 + 1] + np.log(np.float32(N0 + N1))
-    util.assert_close(Z[None], g["Z"], "Z (optimal transport)", scale_atol=True)
+    Z = util.transport_Z(S[0], u, v, N0, N1, float(sd["bin_score"]))
+    util.assert_fp64_anchored(Z[None], g["Z"], an["sg_small/Z_f64"], "Z (optimal transport)")
     # Appendix A.4: exp(Z) rows sum to 1 (dustbin row to N), after `iters` iterations columns nearly so
     P = np.exp(Z.astype(np.float64))
     np.testing.assert_allclose(P[:N0].sum(1), 1.0, rtol=0, atol=0.35)
@@ -117,11 +121,16 @@ def test_full_size_matches_bit_exact_vs_reference_golden(name):
     data = _oracle_pair_inputs(seed, H, W, d, K)
     assert np.array_equal(data["keypoints0"][0].numpy(), g["keypoints0"])     # the oracle is the reference here
     eng, L = _engine(d)
-    eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(d))
+    sd = util.sg_sd(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, sd)
+    eng.set_debug(True)
     t = {k: v.cuda() for k, v in data.items()}
     m0, m1, ms0, ms1 = _run(eng, t, (1, 1, H, W))
     S = eng.fetch("scores_in")[0]
-    util.assert_close(S[::8, ::8], g["scores_in_sub"], "scores_in (subsampled)", scale_atol=True)
+    an, tag = util.golden("fp64_anchor.npz"), name[:-4]
+    util.assert_fp64_anchored(S[:K:8, :K:8], g["scores_in_sub"], an[tag + "/scores_in_sub_f64"], f"{tag} scores_in (every 8th)")
+    Z = util.transport_Z(S, eng.fetch("u")[0], eng.fetch("v")[0], K, K, float(sd["bin_score"]))
+    util.assert_fp64_anchored(Z[::8, ::8], g["Z_sub"], an[tag + "/Z_sub_f64"], f"{tag} Z (every 8th)")
     nbad0, nbad1 = int((m0 != g["matches0"]).sum()), int((m1 != g["matches1"]).sum())
     assert nbad0 == 0 and nbad1 == 0, f"{nbad0}/{nbad1} match indices differ (fixture decision margin {float(g['margin_decision_gap']):.2e})"
     util.assert_close(ms0, g["matching_scores0"], "matching_scores0")
@@ -146,11 +155,10 @@ def test_batched_pairs_equal_single_pair_runs():
             "batched pairs must be bit-identical to single-pair runs"
 
 
-@pytest.mark.parametrize("mode", ["1", "2", "3", "4"])
+@pytest.mark.parametrize("mode", ["1", "4"])
 def test_every_attention_variant_matches_bit_exact(mode, monkeypatch):
-    """IMX_ATTN selects the attention kernel (1: one K/V tile in flight, 2: software-pipelined softmax, 3: two tiles in
-    flight; the default picks per head size).  Every variant must give the reference's matches on a C3 and the C5
-    fixture (head sizes 32 and 64)."""
+    """IMX_ATTN selects the attention kernel form (1: one K/V tile in flight, 3 = default: two tiles in flight, 4: 64-key
+    staged tiles).  Every form must give the reference's matches on a C3 and the C5 fixture (head sizes 32 and 64)."""
     monkeypatch.setenv("IMX_ATTN", mode)
     for name in ("c3_pair_s59.npz", "c5_pair_s19.npz"):
         test_full_size_matches_bit_exact_vs_reference_golden(name)

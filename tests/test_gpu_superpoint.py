@@ -173,19 +173,11 @@ def test_dense_forward_for_label_export_vs_reference_golden():
     util.assert_close(out["desc"], g["desc"], "desc")
 
 
-@pytest.mark.parametrize("mode", ["direct", "wino", "wino4", "wino6", "wino6-x1", "auto-f22", "auto-f22n"])
-def test_every_conv_kernel_variant_vs_reference_golden(mode, monkeypatch):
-    """The 3x3-conv layers have four implementations (IMX_CONV, read at imx_create): direct implicit GEMM, Winograd with
-    two workgroups per CU, the 32x32x2 variant and the persistent producer/consumer form; the default mixes two of them.
-    Each one alone must reproduce the reference's dense stages and keypoints on the ragged fixture (123x165: partial
-    tiles on both axes) and on the 120x160 one."""
-    monkeypatch.setenv("IMX_CONV", mode.split("-")[0])
-    if mode.endswith("-f22"):           # default dispatch, but the fused first layer as F(2x2,3x3) (default: F(2x4,3x3))
-        monkeypatch.setenv("IMX_CONV1", "f22")
-    if mode.endswith("-f22n"):          # default dispatch, but every later 3x3 layer as F(2x2,3x3) (default: F(2x4,3x3))
-        monkeypatch.setenv("IMX_CONVN", "f22")
-    if mode.endswith("-x1"):            # the 8-channels-per-phase form of the persistent kernel (default: 16)
-        monkeypatch.setenv("IMX_WINO6_X1", "1")
+def test_direct_conv_fallback_vs_reference_golden(monkeypatch):
+    """IMX_CONV=direct (read at imx_create) puts every 3x3 layer on the direct implicit-GEMM kernel -- the A/B reference of
+    the default Winograd F(2x4,3x3) kernels and the fallback for shapes those reject.  It must reproduce the reference's
+    dense stages and keypoints on the ragged fixture (123x165: partial tiles on both axes) and on the 120x160 one."""
+    monkeypatch.setenv("IMX_CONV", "direct")
     for name in ("sp_ragged.npz", "sp_small.npz"):
         g = util.golden(name)
         H, W, seed, K = int(g["H"]), int(g["W"]), int(g["seed"]), int(g["max_keypoints"])
@@ -194,8 +186,8 @@ def test_every_conv_kernel_variant_vs_reference_golden(mode, monkeypatch):
         x = torch.cat(util.pair(seed, H, W))
         _check_against(eng, x, [g["keypoints0"], g["keypoints1"]], [g["scores0"], g["scores1"]],
                        [g["descriptors0"], g["descriptors1"]])
-        util.assert_close(_nchw(eng.fetch("x4")), g["x4"], f"x4 ({mode})")
-        util.assert_close(_nchw(eng.fetch("semi")), g["semi"], f"semi ({mode})")
+        util.assert_close(_nchw(eng.fetch("x4")), g["x4"], "x4 (direct)")
+        util.assert_close(_nchw(eng.fetch("semi")), g["semi"], "semi (direct)")
 
 
 @pytest.mark.parametrize("radius", [1, 2, 3, 4, 6])

@@ -3,7 +3,7 @@
 tag=$1; shift
 R=$(pwd); export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/prof_$tag
-cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -- python $R/bench.py --no-cpu-baseline --no-roofline-pass --steps 3 --warmup 1 "$@" > $R/gpurun_out/prof_$tag/bench.log 2>&1
+cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -- python $R/bench.py --no-cpu-baseline --no-extras --no-roofline-pass --steps 3 --warmup 1 "$@" > $R/gpurun_out/prof_$tag/bench.log 2>&1
 cd $R
 db=$(find gpurun_out/prof_$tag -name "*.db" | head -1)
 python tools/rocpd_summary.py $db > gpurun_out/${tag}_kernel_stats.txt
