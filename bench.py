@@ -136,39 +136,64 @@ def build_matching(wl, device):
     return m, cfg, sd_sp, sd_sg
 
 
-def cpu_baseline(wl, cfg, sd_sp, sd_sg, budget_s=30.0):
-    """The oracle (port of the reference's PyTorch CPU forward) on this host's cores.  More threads are not better
-    for this model (128 threads: 0.32 pairs/s in round 1, slower than 8 threads in the survey container), so the
-    thread count is swept and the best one is reported: per count one warm-up pair + the median of up to 3 pairs,
-    ~30 s in total."""
+def cpu_baseline_worker(workload, n_pairs):
+    """Child process of cpu_baseline(): the oracle on `n_pairs` + 1 pairs with the thread count fixed by OMP_NUM_THREADS
+    in the environment (set before torch is imported); prints the per-pair seconds as JSON.  Never touches the GPU."""
     from oracle import matching_ref            # checker code: used here only as the CPU baseline leg
+    wl = WORKLOADS[workload]
+    d, K = wl["d"], wl["K"]
+    kenc, iters, thr = synth.SG_CONFIGS[d]
+    cfg = {"superpoint": {"weights": None, "descriptor_dim": d, "nms_radius": 4, "keypoint_threshold": 0.005, "max_keypoints": K},
+           "superglue": {"weights": None, "descriptor_dim": d, "keypoint_encoder": kenc, "sinkhorn_iterations": iters,
+                         "match_threshold": thr}}
+    sd_sp = {k: torch.from_numpy(np.array(v)) for k, v in synth.make_superpoint_state_dict(d).items()}
+    sd_sg = {k: torch.from_numpy(np.array(v)) for k, v in synth.make_superglue_state_dict(d).items()}
+    times = []
+    for i in range(n_pairs + 1):
+        im0, im1 = synth.synth_pair(1000 + i, wl["H"], wl["W"])
+        x0, x1 = torch.from_numpy(im0)[None, None], torch.from_numpy(im1)[None, None]
+        t = time.perf_counter()
+        matching_ref.matching_forward({"image0": x0, "image1": x1}, sd_sp, sd_sg, cfg)
+        times.append(time.perf_counter() - t)
+        print(json.dumps({"threads": torch.get_num_threads(), "times": times}), flush=True)      # last line wins (partial on timeout)
+
+
+def cpu_baseline(workload, budget_s=40.0, n_pairs=3):
+    """The oracle (port of the reference's PyTorch CPU forward) on this host's cores.  More threads are not better for
+    this model (128 threads gave 0.32 pairs/s in round 1, slower than 8 threads in the survey container), so the thread
+    count is swept and the best is reported.  Each count runs in its own child process (OMP_NUM_THREADS set before torch
+    loads, hard timeout): 1 warm-up pair + the median of up to `n_pairs` pairs; ~`budget_s` seconds in total."""
+    import subprocess
     try:
         avail = len(os.sched_getaffinity(0))       # cores this process may run on (cgroup/affinity aware)
     except AttributeError:
         avail = os.cpu_count() or 1
-    counts = sorted({c for c in (8, 16, 32, 64, avail) if c <= avail} or {avail})
-    pairs = [tuple(torch.from_numpy(a)[None, None] for a in synth.synth_pair(1000 + i, wl["H"], wl["W"])) for i in range(4)]
-    t_all, sweep, best = time.perf_counter(), {}, None
+    counts = sorted({c for c in (8, 16, 32, 64) if c <= avail} or {avail})
+    per = budget_s / len(counts)
+    sweep, best = {}, None
     for c in counts:
-        torch.set_num_threads(c)
-        times = []
-        for i, (x0, x1) in enumerate(pairs):
-            t = time.perf_counter()
-            matching_ref.matching_forward({"image0": x0, "image1": x1}, sd_sp, sd_sg, cfg)
-            if i > 0:                              # first pair at this thread count = warm-up
-                times.append(time.perf_counter() - t)
-            if time.perf_counter() - t_all > budget_s and times:
-                break
+        env = dict(os.environ, OMP_NUM_THREADS=str(c), MKL_NUM_THREADS=str(c), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(n_pairs), "--workload", workload]
+        try:
+            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=per + 15).stdout
+        except subprocess.TimeoutExpired as e:
+            out = (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        times = json.loads(lines[-1])["times"][1:] if lines else []          # first pair = warm-up
+        if not times:
+            sweep[str(c)] = None
+            continue
         med = float(np.median(times))
         sweep[str(c)] = round(1.0 / med, 4)
         if best is None or med < best[1]:
             best = (c, med, len(times))
-        if time.perf_counter() - t_all > budget_s:
-            break
+    if best is None:
+        return {"value": None, "unit": "image-pairs/s", "cores": 0, "kind": "port", "sample": f"no thread count finished: {sweep}"}
     c, med, n = best
+    wl = WORKLOADS[workload]
     return {"value": round(1.0 / med, 4), "unit": "image-pairs/s", "cores": c, "kind": "port",
-            "sample": f"best of a thread sweep {sweep} (pairs/s by thread count; {avail} cores available); median of {n} pairs "
-                      f"after 1 warm-up per count, {wl['H']}x{wl['W']}, torch {torch.__version__} CPU"}
+            "sample": f"best of a thread sweep {sweep} (pairs/s by OMP thread count, one child process each; {avail} cores "
+                      f"available); median of {n} pairs after 1 warm-up, {wl['H']}x{wl['W']}, torch {torch.__version__} CPU"}
 
 
 def latency_b1(matching, wl, device, n=50):
@@ -244,7 +269,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-pass", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip latency_b1_ms / pcie_inclusive_pairs_s")
+    ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args.workload, args.cpu_baseline_worker)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -424,7 +452,7 @@ def main():
         barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not sp_only:
         log("cpu baseline (oracle on host cores)")
-        line["cpu_baseline"] = cpu_baseline(wl, cfg, sd_sp, sd_sg)
+        line["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if use_pg:

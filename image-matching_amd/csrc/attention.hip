@@ -16,6 +16,12 @@
 //                    step s pairs key (s&3)+8(s>>2) (lanes 0-31) with that key +4 (lanes 32-63):
 //                    exactly the keys whose probabilities sit in accumulator register s — P is fed
 //                    to the matrix core straight from the S accumulators, no transposes, no LDS.
+// Accumulation order (round 2).  v_mfma_f32_* accumulates exactly like a sequential RNE fma chain (tools/ubench/mfma_round.hip),
+// and P >= 0, so one running accumulator over all N keys is a 1024-long chain whose partial sums only grow: emulating that
+// order on the CPU (tools/accuracy_emul.py) puts scores_in 2.2x further from a float64 evaluation than the reference's own
+// fp32 result, exactly what the kernel measured (2.1x at C3, 2.5x at C5).  The product is therefore accumulated in two levels:
+// the P.V MFMAs of a GROUP of 64 keys start from a zero accumulator T, and T is folded into the running O with packed adds
+// (8 v_pk_add_f32 per 32 output dims and group): 0.92x of the reference's error in the emulation, ~1 % of the tile's time.
 #include "imx_kernels.h"
 #include <math.h>
 #include <cstdlib>
@@ -44,6 +50,15 @@ __device__ __forceinline__ AttnBlock attn_block() {
   r.z = w / (nx * ny);
   return r;
 }
+
+// max / sum over a lane and its partner lane^32
+// (one v_permlane32_swap instead of the ds_bpermute round trip of __shfl_xor was measured: no difference, 10.2-10.4 ms per
+//  step either way; its __builtin_amdgcn_permlane32_swap form clobbered a live register under hipcc 7.2 -- memory fault)
+__device__ __forceinline__ float xhalf_max(float x) { return fmaxf(x, __shfl_xor(x, 32)); }
+__device__ __forceinline__ float xhalf_sum(float x) { return x + __shfl_xor(x, 32); }
+
+template <bool V>
+struct BoolC { static constexpr bool value = V; };
 
 template <int HD, bool DEEP, int TK = 32>
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale) {
@@ -87,11 +102,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
     for (int t = 0; t < HD / 2; ++t) q[t] = 0.f;
   }
 
-  f32x16 O[OB];
+  f32x16 O[OB], T[OB];      // running output, and the current 64-key group's partial product (two-level accumulation)
 #pragma unroll
   for (int o = 0; o < OB; ++o)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) O[o][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { O[o][r] = 0.f; T[o][r] = 0.f; }
   float m = -INFINITY, l = 0.f;
 
   const int nt = (nk + TK - 1) / TK;        // staged tiles
@@ -99,13 +114,28 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
   constexpr int V4 = HD / 4;                 // float4 per row
   constexpr int ITER = (TK * V4) / 256;      // 1..4
   f32x4 kreg[2][ITER], vreg[2][ITER];
+  // K/V rows of this (pair, side) through a buffer descriptor: per-thread byte offsets are loop invariant, the tile offset
+  // is an SGPR, rows past the padded count read as zeros (never used) -- no address arithmetic in the loop (12 VALU
+  // instructions per tile with global loads; the buffer form pays for the two-level accumulation: 10.7 -> 10.3 ms)
+  // (the base is block-uniform, but it is a phi over divergent control flow for the compiler: without the explicit
+  //  readfirstlane every load becomes a waterfall loop)
+  const unsigned long long kaddr = (unsigned long long)(p.qkv + kbase * ld);
+  const unsigned long long kaddr_u = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(kaddr >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((unsigned)kaddr);
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)kaddr_u, 0, __builtin_amdgcn_readfirstlane(Nkp * ld * 4), 0x00020000);
+  int kvo[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int e = tid + it * 256, key = e / V4, v4 = e % V4;
+    kvo[it] = (key * ld + head * HD + 4 * v4 + p.d) * 4;
+  }
 #define IMX_GLOAD(set_, kt_)                                                                   \
-  _Pragma("unroll") for (int it = 0; it < ITER; ++it) {                                        \
-    const int e = tid + it * 256, key = e / V4, v4 = e % V4;                                   \
-    const int krow = min((kt_) * TK + key, Nkp - 1);      /* rows past the padded count are never used */ \
-    const float* base = p.qkv + (kbase + (size_t)krow) * ld + head * HD + 4 * v4;              \
-    kreg[set_][it] = *reinterpret_cast<const f32x4*>(base + p.d);                              \
-    vreg[set_][it] = *reinterpret_cast<const f32x4*>(base + 2 * p.d);                          \
+  {                                                                                            \
+    const int so = __builtin_amdgcn_readfirstlane((kt_) * TK * ld * 4);                        \
+    _Pragma("unroll") for (int it = 0; it < ITER; ++it) {                                      \
+      kreg[set_][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, kvo[it], so, 0));            \
+      vreg[set_][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, kvo[it] + p.d * 4, so, 0));  \
+    }                                                                                          \
   }
 #define IMX_LSTORE(set_, buf_)                                                                 \
   _Pragma("unroll") for (int it = 0; it < ITER; ++it) {                                        \
@@ -116,7 +146,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
   }
 
   // one key tile: S^T = K.Q^T, online softmax, O^T = O^T*alpha + V^T.P^T
-  auto tile32 = [&](int kt, int buf, int sub) __attribute__((always_inline)) {      // kt = 32-key tile index
+  // `first`: this tile opens a 64-key group (folds the finished group T into O, then starts T from a zero accumulator)
+  auto tile32 = [&](int kt, int buf, int sub, auto first) __attribute__((always_inline)) {      // kt = 32-key tile index
     if (wave_active) {
       // ---- fetch this tile's K and V fragments from LDS up front (V lands during the S MFMAs)
       const float* kp = &Kt[buf][(sub * 32 + l31) * KS + hi * (HD / 2)];
@@ -153,7 +184,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
           mx = fmaxf(mx, sv);
         }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = xhalf_max(mx);
       const float mn = fmaxf(m, mx);
       const float alpha = __builtin_amdgcn_exp2f(m - mn);      // m = -inf on the first tile -> 0
       typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -167,32 +198,51 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
         S[r + 1] = pp[1];
         rs2 += pp;
       }
-      float rs = rs2[0] + rs2[1];
-      rs += __shfl_xor(rs, 32);
+      float rs = xhalf_sum(rs2[0] + rs2[1]);
       l = l * alpha + rs;
       m = mn;
-      // ---- O^T = O^T * alpha + V^T . P^T ; the rescale is skipped when no lane of the wave saw a larger maximum
+      // ---- (O^T + T) * alpha + V^T . P^T, two-level: the rescale is skipped when no lane of the wave saw a larger maximum
       //      (alpha == 1 exactly -- the common case after the first tiles)
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+      const bool rescale = __builtin_amdgcn_ballot_w64(alpha != 1.f) != 0;
+      if constexpr (decltype(first)::value) {
 #pragma unroll
-        for (int o = 0; o < OB; ++o)
+        for (int o = 0; o < OB; ++o) O[o] += T[o];          // the finished group (zeros before the first one)
+        if (rescale) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) O[o][r] *= alpha;
-      }
+          for (int o = 0; o < OB; ++o)
 #pragma unroll
-      for (int o = 0; o < OB; ++o) {
+            for (int r = 0; r < 16; ++r) O[o][r] *= alpha;
+        }
 #pragma unroll
-        for (int st = 0; st < 16; ++st)
-          O[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[o][st], S[st], O[o], 0, 0, 0);
+        for (int o = 0; o < OB; ++o) {
+          T[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[o][0], S[0], zero16, 0, 0, 0);
+#pragma unroll
+          for (int st = 1; st < 16; ++st) T[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[o][st], S[st], T[o], 0, 0, 0);
+        }
+      } else {
+        if (rescale) {
+#pragma unroll
+          for (int o = 0; o < OB; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { O[o][r] *= alpha; T[o][r] *= alpha; }
+        }
+#pragma unroll
+        for (int o = 0; o < OB; ++o) {
+#pragma unroll
+          for (int st = 0; st < 16; ++st) T[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[o][st], S[st], T[o], 0, 0, 0);
+        }
       }
     }
   };
 
-  auto tile = [&](int kts, int buf) __attribute__((always_inline)) {               // one staged tile = TK/32 sub-tiles
-#pragma unroll
-    for (int sub = 0; sub < TK / 32; ++sub) {
-      const int kt = kts * (TK / 32) + sub;
-      if (kt * 32 < nk) tile32(kt, buf, sub);          // block-uniform
+  // one staged tile = TK/32 sub-tiles.  Groups of two 32-key tiles: with 64-key staged tiles a group is one staged tile,
+  // with 32-key staged tiles the even staged tiles open a group (`even` is a compile-time tag at every call site)
+  auto tile = [&](int kts, int buf, auto even) __attribute__((always_inline)) {
+    if constexpr (TK == 64) {
+      if (kts * 64 < nk) tile32(kts * 2, buf, 0, BoolC<true>{});            // block-uniform
+      if (kts * 64 + 32 < nk) tile32(kts * 2 + 1, buf, 1, BoolC<false>{});
+    } else {
+      if (kts * 32 < nk) tile32(kts, buf, 0, even);
     }
   };
 
@@ -208,7 +258,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
     for (int kt = 0; kt < nt; ++kt) {
       const int buf = kt & 1;
       { IMX_GLOAD(0, kt + 1 < nt ? kt + 1 : kt) }   // branch-free prefetch (last tile re-fetches itself)
-      tile(kt, buf);
+      if (buf == 0) tile(kt, 0, BoolC<true>{}); else tile(kt, 1, BoolC<false>{});      // block-uniform
       { IMX_LSTORE(0, buf ^ 1) }
       __syncthreads();
     }
@@ -220,12 +270,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
     __syncthreads();
     for (int kt = 0; kt < nt; kt += 2) {
       { IMX_GLOAD(0, kt + 2 < nt ? kt + 2 : kt) }
-      tile(kt, 0);
+      tile(kt, 0, BoolC<true>{});
       { IMX_LSTORE(1, 1) }                          // tile kt+1
       __syncthreads();
       if (kt + 1 < nt) {                            // block-uniform
         { IMX_GLOAD(1, kt + 3 < nt ? kt + 3 : kt) }
-        tile(kt + 1, 1);
+        tile(kt + 1, 1, BoolC<false>{});
         { IMX_LSTORE(0, 0) }                        // tile kt+2
         __syncthreads();
       }
@@ -233,6 +283,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
   }
 
   if (wave_active) {
+#pragma unroll
+    for (int o = 0; o < OB; ++o) O[o] += T[o];                    // the last group
     const float inv = (l > 0.f && qrow < nq) ? 1.0f / l : 0.f;   // rows past the valid count: zeros
     float* op = p.out + (qbase + qrow) * p.d + head * HD;
 #pragma unroll
@@ -258,7 +310,8 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   // A/B switch IMX_ATTN (read per launch: tests switch it within one process): 1 = one K/V tile in flight, 3 = two tiles
   // in flight (default), 4 = 64-key staged tiles.  Round-1 measurements (whole step, pairs/s, C3 HD=32 / C5 HD=64):
   // 1: 1172 / 203.1, 3: 1185 / 207.6, 4: = 3; a software-pipelined softmax form (exponentials sliced between the P.V
-  // MFMAs) measured 1163 / 203.6 and was removed -- VALU work placed between MFMAs is not free (in-order issue).
+  // MFMAs) measured 1163 / 203.6 and was removed -- VALU work placed between MFMAs is not free (in-order issue).  Forcing
+  // 128 VGPRs (4 waves per SIMD, 12 spilled; the kernel needs 136 = 3 waves) made no difference either.
   const char* env = getenv("IMX_ATTN");
   const int mode = env ? atoi(env) : 3;
   if (hd == 32) {

@@ -8,10 +8,11 @@ world_size == 1 needs no process group.
 Record = one row of 32-bit words per pair (`record_width(K)` words):
   [pair_id i32 | n0 i32 | n1 i32 | kpts0 2K f32 | kpts1 2K f32 | matches0 K i32 | matches1 K i32 |
    mscores0 K f32 | mscores1 K f32]
-The buffer's torch dtype is float32; the integer fields are int32 *bit patterns* viewed as float32
-(`Tensor.view(dtype)`), never value-converted, so indices and ids are exact for any K.  A row with
-pair_id == -1 is padding (ranks with fewer pairs than ceil(n_pairs / world)) and is dropped after
-the gather.
+The buffer's torch dtype is int32; the float fields are float32 *bit patterns* viewed as int32
+(`Tensor.view(dtype)`), never value-converted, so every field round-trips exactly (an int32 -1
+viewed as float32 would be a NaN pattern: buffers would stop comparing equal to themselves).  A row
+with pair_id == -1 is padding (ranks with fewer pairs than ceil(n_pairs / world)) and is dropped
+after the gather.
 """
 import torch
 import torch.distributed as dist
@@ -34,31 +35,32 @@ def record_width(K):
     return 3 + 8 * K
 
 
-def _i32_as_f32(t):
-    return t.to(torch.int32).contiguous().view(torch.float32)
+def _f32_as_i32(t):
+    return t.to(torch.float32).contiguous().view(torch.int32)
 
 
 def pack_records(pair_ids, out, pad_to=None):
-    """out: dict from Engine.match_pairs (padded (B,K,...) tensors) -> (rows, record_width) float32 buffer,
+    """out: dict from Engine.match_pairs (padded (B,K,...) tensors) -> (rows, record_width) int32 buffer,
     rows = max(B, pad_to); rows past B are padding (pair_id -1, everything else 0)."""
     B, K = out["matches0"].shape
     dev = out["matches0"].device
     ids = torch.as_tensor(list(pair_ids), dtype=torch.int32, device=dev).reshape(B, 1)
-    parts = [_i32_as_f32(ids), _i32_as_f32(out["counts0"].reshape(B, 1)), _i32_as_f32(out["counts1"].reshape(B, 1)),
-             out["keypoints0"].reshape(B, 2 * K).float(), out["keypoints1"].reshape(B, 2 * K).float(),
-             _i32_as_f32(out["matches0"]), _i32_as_f32(out["matches1"]),
-             out["matching_scores0"].float(), out["matching_scores1"].float()]
+    i32 = lambda t: t.to(torch.int32)
+    parts = [ids, i32(out["counts0"]).reshape(B, 1), i32(out["counts1"]).reshape(B, 1),
+             _f32_as_i32(out["keypoints0"].reshape(B, 2 * K)), _f32_as_i32(out["keypoints1"].reshape(B, 2 * K)),
+             i32(out["matches0"]), i32(out["matches1"]),
+             _f32_as_i32(out["matching_scores0"]), _f32_as_i32(out["matching_scores1"])]
     rec = torch.cat(parts, dim=1).contiguous()
     if pad_to is not None and pad_to > B:
         pad = torch.zeros(pad_to - B, rec.shape[1], dtype=rec.dtype, device=dev)
-        pad[:, 0] = torch.full((pad_to - B,), PAD_ID, dtype=torch.int32, device=dev).view(torch.float32)
+        pad[:, 0] = PAD_ID
         rec = torch.cat([rec, pad])
     return rec
 
 
 def pair_ids_of(rec):
-    """int64 pair ids of a record buffer (bit-exact: the column holds int32 bit patterns)."""
-    return rec[:, 0].contiguous().view(torch.int32).long()
+    """int64 pair ids of a record buffer."""
+    return rec[:, 0].long()
 
 
 def drop_padding(rec):
@@ -70,18 +72,19 @@ def unpack_records(rec):
     rec = drop_padding(rec)
     K = (rec.shape[1] - 3) // 8
 
-    def i32(x):
-        return x.contiguous().view(torch.int32)
+    def f32(x):
+        return x.contiguous().view(torch.float32)
     o = 3
-    out = {"pair_id": i32(rec[:, 0]).long(), "counts0": i32(rec[:, 1]), "counts1": i32(rec[:, 2])}
+    out = {"pair_id": rec[:, 0].long(), "counts0": rec[:, 1].contiguous(), "counts1": rec[:, 2].contiguous()}
     for name, w in (("keypoints0", 2 * K), ("keypoints1", 2 * K), ("matches0", K), ("matches1", K),
                     ("matching_scores0", K), ("matching_scores1", K)):
         out[name] = rec[:, o:o + w]
         o += w
-    out["keypoints0"] = out["keypoints0"].reshape(-1, K, 2)
-    out["keypoints1"] = out["keypoints1"].reshape(-1, K, 2)
-    out["matches0"] = i32(out["matches0"]).long()
-    out["matches1"] = i32(out["matches1"]).long()
+    out["keypoints0"] = f32(out["keypoints0"]).reshape(-1, K, 2)
+    out["keypoints1"] = f32(out["keypoints1"]).reshape(-1, K, 2)
+    out["matching_scores0"], out["matching_scores1"] = f32(out["matching_scores0"]), f32(out["matching_scores1"])
+    out["matches0"] = out["matches0"].long()
+    out["matches1"] = out["matches1"].long()
     return out
 
 
