@@ -237,12 +237,15 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
 
   // one staged tile = TK/32 sub-tiles.  Groups of two 32-key tiles: with 64-key staged tiles a group is one staged tile,
   // with 32-key staged tiles the even staged tiles open a group (`even` is a compile-time tag at every call site)
+  // HD = 64 (C5: 2048 keys, d = 256) folds every 32-key tile: in the emulation of this order C5's scores_in goes from 1.48x
+  // to 1.23x of the reference's own fp32 distance to float64, for 16 more packed adds per 4096 MFMA cycles.
+  constexpr bool EVERY = HD >= 64;
   auto tile = [&](int kts, int buf, auto even) __attribute__((always_inline)) {
     if constexpr (TK == 64) {
       if (kts * 64 < nk) tile32(kts * 2, buf, 0, BoolC<true>{});            // block-uniform
-      if (kts * 64 + 32 < nk) tile32(kts * 2 + 1, buf, 1, BoolC<false>{});
+      if (kts * 64 + 32 < nk) tile32(kts * 2 + 1, buf, 1, BoolC<EVERY>{});
     } else {
-      if (kts * 32 < nk) tile32(kts, buf, 0, even);
+      if (kts * 32 < nk) tile32(kts, buf, 0, BoolC<EVERY || decltype(even)::value>{});
     }
   };
 

@@ -33,11 +33,12 @@ __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
   const int r0 = blockIdx.x * BM, n0 = blockIdx.y * NT;
   const int K = p.K0 + p.K1, nchunk = K / CK;
 
-  f32x16 acc[NB];
+  // two-level accumulation (see gemm_ws.hip): blocks of 128 k (four chunks) start from zero and are folded into `tot`
+  f32x16 acc[NB], tot[NB];
 #pragma unroll
   for (int n = 0; n < NB; ++n)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[n][r] = 0.f; tot[n][r] = 0.f; }
 
   // register-staged double buffering: chunk c+1 is fetched from L2/HBM while chunk c feeds the MFMAs.
   // Per-thread source pointers are set up once (rows >= M read a clamped row: their results are never stored), so a
@@ -119,6 +120,18 @@ __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
       for (int n = 0; n < NB; ++n)
         acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur][n], acc[n], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if ((c & 3) == 3 || c + 1 == nchunk) {       // block-uniform: end of a 128-k block (or of the reduction)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        tot[n] += acc[n];
+        if (c + 1 < nchunk) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        } else {
+          acc[n] = tot[n];
+        }
+      }
     }
     IMX_LSTORE((c + 1) & 1)
     __syncthreads();

@@ -100,12 +100,9 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
   constexpr int ERS = 256 / (NTW / 4);           // rows per epilogue pass: 8 / 16
   const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.M * p.ldo * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? p.res : p.out), 0, p.M * (RES ? p.ldr : p.ldo) * 4, 0x00020000);
-  int eo[EIT], er[EIT];
-#pragma unroll
-  for (int i = 0; i < EIT; ++i) {
-    eo[i] = ((erow + ERS * i) * p.ldo + n0 + c4) * 4;
-    er[i] = ((erow + ERS * i) * (RES ? p.ldr : p.ldo) + n0 + c4) * 4;
-  }
+  // per-thread byte offsets of pass 0; pass i adds a uniform i * ERS rows through the SGPR offset (no per-pass VGPRs)
+  const int eo0 = (erow * p.ldo + n0 + c4) * 4, er0 = (erow * (RES ? p.ldr : p.ldo) + n0 + c4) * 4;
+  const int estep_o = ERS * p.ldo * 4, estep_r = ERS * (RES ? p.ldr : p.ldo) * 4;
   const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + c4);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -118,11 +115,20 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
   const int aoff = n * AS + 4 * kq;          // A operand of row block rb, quad t: As[(16 rb + n) * AS + 16 t + 4 kq]
 
   for (int tile = part; tile < ntile; tile += nparts) {
-    f32x4 acc[4][CBW];
+    // Two-level accumulation for the long reductions (K = 512: C5's MLPs): v_mfma_f32 accumulates like a sequential fma chain
+    // (tools/ubench/mfma_round.hip), whose rounding error grows with the chain; blocks of 128 k start from zero and are folded
+    // into `tot` with packed adds (16 per 128 MFMAs).  With it C5's scores_in is 1.2x (without: 1.5x) further from a float64
+    // evaluation than the reference's fp32 result in the CPU emulation of this order (tools/accuracy_emul.py).  K <= 256 keeps
+    // one level: the K = 256 form has no registers to spare (248) and C3 measures 1.06x as it is.
+    constexpr bool TWO = K >= 512;
+    f32x4 acc[4][CBW], tot[TWO ? 4 : 1][CBW];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-      for (int cbk = 0; cbk < CBW; ++cbk) acc[rb][cbk] = zero4;
+      for (int cbk = 0; cbk < CBW; ++cbk) {
+        acc[rb][cbk] = zero4;
+        if constexpr (TWO) tot[rb][cbk] = zero4;
+      }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       __syncthreads();             // stage `par` complete; the other buffer's readers are done
@@ -144,6 +150,17 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
           __builtin_amdgcn_sched_barrier(0);
         }
       par ^= 1;
+      if constexpr (TWO) {
+        if ((c & 1) == 1) {          // two stages = 128 k
+#pragma unroll
+          for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cbk = 0; cbk < CBW; ++cbk) {
+              tot[rb][cbk] += acc[rb][cbk];
+              if (c + 1 < NC) acc[rb][cbk] = zero4; else acc[rb][cbk] = tot[rb][cbk];
+            }
+        }
+      }
     }
     // ---- tile done: stage the 64 x 128 result, then bias / ReLU / residual on whole float4 row segments.
     //      acc[rb][cbk][r]: row 16 rb + 4 kq + r, column 32 wave + 16 cbk + n.
@@ -160,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
       f32x4 v[EIT], rv[EIT];
 #pragma unroll
       for (int i = 0; i < EIT; ++i) {
-        if constexpr (RES) rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, er[i], rso, 0));
+        if constexpr (RES) rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, er0, rso + i * estep_r, 0));
         v[i] = *reinterpret_cast<const f32x4*>(Ot + (erow + ERS * i) * OSN + c4);
       }
 #pragma unroll
@@ -168,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
         f32x4 o = v[i] + bias4;
         if constexpr (RELU) o = __builtin_elementwise_max(o, zero4);      // compile-time: a run-time flag costs a v_cndmask per value
         if constexpr (RES) o = rv[i] + o;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), ors, eo[i], oso, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), ors, eo0, oso + i * estep_o, 0);
       }
     }
   }

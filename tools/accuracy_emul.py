@@ -3,7 +3,8 @@
 to a float64 evaluation (tests/util.py:assert_fp64_anchored) and what splitting it into independent chains buys.
 Measured on MI355X (tools/ubench/mfma_round.hip): v_mfma_f32_* accumulates exactly like a sequential fmaf chain (RNE), so a
 GEMM's error grows with the chain length K; `C` independent chains summed at the end halve it at C = 4.
-usage: python tools/accuracy_emul.py [gemm_chains] [pv_chains]      (build container, no GPU)"""
+usage: python tools/accuracy_emul.py [gemm_chains] [pv_chains] [c5]     (build container, no GPU)
+  chains > 0: that many interleaved sequential chains; < 0: two-level, blocks of |chains| consecutive k; 0: torch default"""
 import os
 import sys
 import time
@@ -18,8 +19,13 @@ from tests import util  # noqa: E402
 torch.set_grad_enabled(False)
 
 
+MINK = int(os.environ.get("EMUL_MINK", "0"))      # two-level only for reductions at least this long (else one chain)
+
+
 def chain_mm(a, w, C):
     """a (R,K) @ w (K,N) with C independent sequential fp32 chains (k -> chain k % C), summed pairwise at the end."""
+    if C < 0 and a.shape[1] < MINK:
+        C = 1
     if C == 0:
         return a @ w
     R, K = a.shape
@@ -89,7 +95,7 @@ def forward(data, sd, cfg, CG, CP):
 def main():
     CG = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     CP = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    d, K, H, W, seed = 128, 1024, 480, 640, 59
+    d, K, H, W, seed = (256, 2048, 960, 1280, 19) if len(sys.argv) > 3 and sys.argv[3] == "c5" else (128, 1024, 480, 640, 59)
     sd_sp, sd = util.sp_sd(d), util.sg_sd(d)
     x0, x1 = util.pair(seed, H, W)
     o0 = superpoint_ref.superpoint_forward(x0, sd_sp, util.sp_config(d, K))
