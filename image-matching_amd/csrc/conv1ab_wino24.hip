@@ -37,8 +37,11 @@ constexpr int RH = OH + 2, RW = OW + 2;        // conv1a patch (pad-1 halo)
 constexpr int IMG_H = RH + 2, IMG_W = RW + 2;  // image patch 12 x 20
 constexpr int RS = 66;                         // conv1a patch pixel stride: wtile columns 4 px apart land 8 banks apart
 constexpr int RAWSZ = 192 * RS;                // 10x18 = 180 pixels + 12 pad (the conv1a GEMM's twelfth pixel block stores unmasked)
-constexpr int KS = 18;                         // V: 16-byte slots per k index (16 wtiles + 2: conflict-free b128 writes)
-constexpr int QSL = 4 * KS;                    // slots per quad
+// V: [12 quads][4 k rows of 16 slots, 4 slots of padding between rows 1 and 2][4 floats] -- the layout conv3x3_wino24.hip
+// explains: ds_read_b128 lane groups mix k rows 2m / 2m+1, which must be a multiple of 16 slots apart (round 1's stride of
+// 18 made every A-operand read a 2-way bank conflict)
+constexpr int QSL = 68;                        // slots per quad
+__host__ __device__ constexpr int vslot(int k, int n) { return 16 * k + 4 * (k >> 1) + n; }
 constexpr int NQ = 12;                         // quads per chunk: 24 positions x 2 k-steps / 4
 constexpr int VSZ = NQ * QSL * 4;              // 3456
 constexpr int UCH = NQ * 4 * 64 * 4;           // 12288 floats of U per (64 co, 8 ci)
@@ -93,8 +96,8 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
   const f32x2 m5 = {-5.f, -5.f};
   const float* rpa = rbase + ra * RW * RS;
   const float* rpb = rbase + rb * RW * RS;
-  float* vwr = V + (tk * KS + tw) * 4 + (wave >> 1) * QSL * 4 + (wave & 1) * 2;
-  int aoff = ((lane >> 4) * KS + (lane & 15)) * 4;
+  float* vwr = V + vslot(tk, tw) * 4 + (wave >> 1) * QSL * 4 + (wave & 1) * 2;
+  int aoff = vslot(lane >> 4, lane & 15) * 4;
   asm volatile("" : "+v"(aoff));               // opaque: the 12 quad reads are immediate offsets from one base
   const float* vrd = V + aoff;
 

@@ -68,8 +68,6 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
         bq[cbk][t][j] = p.w[(size_t)(16 * t + 4 * kq + j) * p.Npad + n0 + 16 * CBW * wave + 16 * cbk + n];
 
   // ---- loader: a stage is 64 rows x 16 float4; thread -> rows tid/16 + 16 it (it = 0..3), float4 tid % 16
-  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a0, 0, p.M * p.lda0 * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a1 ? p.a1 : p.a0), 0, p.M * (p.a1 ? p.lda1 : p.lda0) * 4, 0x00020000);
   int vo0[4], vo1[4], ld_dst[4];
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
@@ -80,6 +78,10 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
   }
   f32x4 lr[4];
   int ltile = part, lc = 0;        // loader cursor (tile, stage)
+  // (the tile offset rides in the SGPR operand, which is NOT bounds-checked: rows past M in the last tile are READ from whatever
+  //  follows the M rows inside the workspace arena -- harmless, their results are never stored; the stores are range-checked)
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a0, 0, p.M * p.lda0 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a1 ? p.a1 : p.a0), 0, p.M * (p.a1 ? p.lda1 : p.lda0) * 4, 0x00020000);
   auto issue_load = [&]() {
     const int kb = lc * KC;
     const bool second = kb >= p.K0;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
     const __amdgpu_buffer_rsrc_t rs = second ? rs1 : rs0;      // branch-free: every issue is exactly four loads (exact vmcnt bookkeeping)
 #pragma unroll
     for (int it = 0; it < 4; ++it) lr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, second ? vo1[it] : vo0[it], so, 0));
-    if (++lc == NC) { lc = 0; ltile += nparts; }       // past the last tile the offsets run out of range: zeros, never used
+    if (++lc == NC) { lc = 0; ltile += nparts; }       // past the last tile: garbage or zeros, never used
   };
   auto store_stage = [&](int buf) {
 #pragma unroll
@@ -98,11 +100,10 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
   // over M rows: rows past M read zeros / are dropped by the hardware, so the epilogue is branch free too
   const int c4 = (tid % (NTW / 4)) * 4, erow = tid / (NTW / 4);
   constexpr int ERS = 256 / (NTW / 4);           // rows per epilogue pass: 8 / 16
-  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, p.M * p.ldo * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? p.res : p.out), 0, p.M * (RES ? p.ldr : p.ldo) * 4, 0x00020000);
-  // per-thread byte offsets of pass 0; pass i adds a uniform i * ERS rows through the SGPR offset (no per-pass VGPRs)
+  // (descriptors are built per tile in the epilogue: the SGPR offset operand of a buffer access is NOT bounds-checked, so the
+  //  tile's row offset must be part of the descriptor's base for rows past M to be out of range)
+  // per-thread byte offsets inside a pass of ERS rows (the pass's first row is the base of its buffer descriptor)
   const int eo0 = (erow * p.ldo + n0 + c4) * 4, er0 = (erow * (RES ? p.ldr : p.ldo) + n0 + c4) * 4;
-  const int estep_o = ERS * p.ldo * 4, estep_r = ERS * (RES ? p.ldr : p.ldo) * 4;
   const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + c4);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -172,12 +173,18 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
         for (int r = 0; r < 4; ++r) Ot[(16 * rb + 4 * kq + r) * OSN + 16 * CBW * wave + 16 * cbk + n] = acc[rb][cbk][r];
     __syncthreads();
     {
-      const int oso = __builtin_amdgcn_readfirstlane(tile * RT * p.ldo * 4);
-      const int rso = __builtin_amdgcn_readfirstlane(tile * RT * (RES ? p.ldr : p.ldo) * 4);
+      const int ldr_ = RES ? p.ldr : p.ldo;
+      const int trow = __builtin_amdgcn_readfirstlane(tile * RT);
+      // one descriptor per epilogue pass (scalar arithmetic only): base = first row of the pass, range = what is left of the M
+      // rows from there, so a thread's row inside the pass (VGPR offset, checked) past M is dropped / reads zero
+      auto pass_rsrc = [&](const float* ptr, int ld, int i) {
+        const int row0 = trow + ERS * i;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(ptr + (size_t)row0 * ld), 0, row0 < p.M ? (p.M - row0) * ld * 4 : 0, 0x00020000);
+      };
       f32x4 v[EIT], rv[EIT];
 #pragma unroll
       for (int i = 0; i < EIT; ++i) {
-        if constexpr (RES) rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, er0, rso + i * estep_r, 0));
+        if constexpr (RES) rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pass_rsrc(p.res, ldr_, i), er0, 0, 0));
         v[i] = *reinterpret_cast<const f32x4*>(Ot + (erow + ERS * i) * OSN + c4);
       }
 #pragma unroll
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws(GemmArgs p, int ntile, int ncg
         f32x4 o = v[i] + bias4;
         if constexpr (RELU) o = __builtin_elementwise_max(o, zero4);      // compile-time: a run-time flag costs a v_cndmask per value
         if constexpr (RES) o = rv[i] + o;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), ors, eo0, oso + i * estep_o, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), pass_rsrc(p.out, p.ldo, i), eo0, 0, 0);
       }
     }
   }

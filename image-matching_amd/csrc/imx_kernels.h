@@ -25,7 +25,7 @@ struct ConvArgs {
 hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);       // direct form (conv3x3.hip)
 // first && pool, Cin == Cout == 64.
 hipError_t launch_conv1ab_wino24(const ConvArgs& a, hipStream_t s); // fused conv1a + conv1b (Winograd F(2x4,3x3)) + pool
-// Cin % 32 == 0, Cout % 64 == 0, not first.
+// Cin % 64 == 0, Cout % 64 == 0, not first.
 bool conv3x3_wino24_supported(const ConvArgs& a);                   // false (e.g. an image of >= 2 GB per layer): callers fall back to the direct form
 hipError_t launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s); // Winograd F(2x4,3x3), persistent, in-stream transform
 

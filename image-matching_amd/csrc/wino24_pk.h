@@ -30,6 +30,52 @@ IMX_PK2(pk_fma_m2, "v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[1,0,0
 #undef IMX_PK3
 #undef IMX_PK2
 
+// a 128-bit accumulator cleared with TWO v_mov_b64 (hipcc materialises a zero f32x4 as four v_mov_b32; 24 accumulators
+// per work item: 96 -> 48 instructions, each ~4.5 cycles of matrix-pipe time on this SIMD)
+typedef float w24_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ w24_f32x4 w24_zero4() {
+  w24_f32x2 a, b;
+  asm volatile("v_mov_b64 %0, 0" : "=v"(a));
+  asm volatile("v_mov_b64 %0, 0" : "=v"(b));
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3);
+}
+__device__ __forceinline__ w24_f32x2 w24_lo(w24_f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ w24_f32x2 w24_hi(w24_f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+
+// Output transform Y = A2^T M A4 of one lane's 24 accumulators (m[j*4 + i]: position (i, j), four consecutive channels
+// each), on channel PAIRS with pinned packed instructions -- left to the compiler a third of it is scalarised (64 v_sub_f32):
+//   down the rows     s0[j] = m0j + m1j + m2j        s1[j] = m1j - m2j - m3j
+//   along the columns y[r][0] = s0 + (s1+s2) + (s3+s4)      y[r][1] = (s1-s2) + 2 (s3-s4)
+//                     y[r][2] = (s1+s2) + 4 (s3+s4)         y[r][3] = (s1-s2) + 8 (s3-s4) + s5
+// 2 x (24 + 20) = 88 packed instructions for the 8 x 4 outputs of the lane.
+__device__ __forceinline__ void w24_output_transform(const w24_f32x4 (&m)[24], w24_f32x2 k8, w24_f32x4 (&y)[2][4]) {
+  w24_f32x2 out[2][4][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {                  // channel pair: registers 0-1 / 2-3 of every accumulator
+    w24_f32x2 s0[6], s1[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const w24_f32x2 a0 = h ? w24_hi(m[j * 4 + 0]) : w24_lo(m[j * 4 + 0]), a1 = h ? w24_hi(m[j * 4 + 1]) : w24_lo(m[j * 4 + 1]);
+      const w24_f32x2 a2 = h ? w24_hi(m[j * 4 + 2]) : w24_lo(m[j * 4 + 2]), a3 = h ? w24_hi(m[j * 4 + 3]) : w24_lo(m[j * 4 + 3]);
+      s0[j] = pk_add(pk_add(a0, a1), a2);
+      s1[j] = pk_sub(pk_sub(a1, a2), a3);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const w24_f32x2* s = r ? s1 : s0;
+      const w24_f32x2 a12 = pk_add(s[1], s[2]), b12 = pk_sub(s[1], s[2]), c34 = pk_add(s[3], s[4]), d34 = pk_sub(s[3], s[4]);
+      out[r][0][h] = pk_add(pk_add(s[0], a12), c34);
+      out[r][1][h] = pk_fma_p2(d34, b12);
+      out[r][2][h] = pk_fma_p4(c34, a12);
+      out[r][3][h] = pk_add(pk_fma(d34, k8, b12), s[5]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) y[r][x] = __builtin_shufflevector(out[r][x][0], out[r][x][1], 0, 1, 2, 3);
+}
+
 // B4^T of F(4,3) on six values o[0..5] (one transformed row of the patch), in two batches of six instructions:
 //   t0 = 4 o0 - 5 o2 + o4      t1 = (o4 - 4 o2) + (o3 - 4 o1)     t2 = (o4 - 4 o2) - (o3 - 4 o1)
 //   t5 = 4 o1 - 5 o3 + o5      t3 = (o4 - o2) + 2 (o3 - o1)       t4 = (o4 - o2) - 2 (o3 - o1)
