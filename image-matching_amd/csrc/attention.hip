@@ -303,6 +303,178 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
 #undef IMX_GLOAD
 #undef IMX_LSTORE
 
+// ---------------------------------------------------------------------------------------------------------------
+// Key-split form for SMALL grids (single pair, BASELINE configs[2]): with one pair the kernel above launches
+// (N/128) x heads x 2 = 64 workgroups on 256 CUs, each walking all N keys -- 47 us per launch, 18 launches per pair, the
+// largest single item of the single-pair latency.  Here a workgroup owns 32 queries and its four waves split the KEYS:
+// a 128-key super tile is staged cooperatively (one buffer, two barriers), wave w multiplies sub-tile w, and the four
+// (max, sum, output) partials are merged through LDS at the end.  4x the workgroups, 1/4 of the serial work per wave.
+// Same per-tile arithmetic as attention_kernel (tile maximum, log2-domain softmax, P fed from the S accumulators); the
+// accumulation order differs (four partial sums), so results agree with the throughput form to rounding, not bit for bit.
+template <int HD>
+__global__ __launch_bounds__(256) void attention_split_kernel(AttnArgs p, float scale) {
+  constexpr int KS = HD + 4, HV = HD < 32 ? 32 : HD, OB = HV / 32, V4 = HD / 4;
+  constexpr int TKS = 128;                      // keys per staged super tile
+  constexpr int ITER = (TKS * V4) / 256;        // float4 of K (and of V) per thread and super tile: 2 / 4 / 8
+  extern __shared__ __attribute__((aligned(16))) float asm_[];
+  float* Kt = asm_;                              // [128][KS]
+  float* Vt = asm_ + TKS * KS;                   // [128][HV]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const AttnBlock blk = attn_block();
+  const int head = blk.y;
+  const int side = blk.z / p.B, b = blk.z % p.B;
+  const int kside = p.cross ? 1 - side : side;
+  const int Nqp = side ? p.N1p : p.N0p, Nkp = kside ? p.N1p : p.N0p;
+  const int q0 = blk.x * 32;
+  if (q0 >= Nqp) return;
+  const int nq = side ? (p.n1 ? p.n1[b] : p.N1) : (p.n0 ? p.n0[b] : p.N0);
+  const int nk = kside ? (p.n1 ? p.n1[b] : p.N1) : (p.n0 ? p.n0[b] : p.N0);
+  const size_t qbase = (side ? (size_t)p.B * p.N0p : 0) + (size_t)b * Nqp;
+  const size_t kbase = (kside ? (size_t)p.B * p.N0p : 0) + (size_t)b * Nkp;
+  const int ld = 3 * p.d;
+  const int qrow = q0 + l31;                     // every wave: the same 32 queries (N?p is a multiple of 32)
+
+  float q[HD / 2];
+  {
+    const float* qp = p.qkv + (qbase + qrow) * ld + head * HD + hi * (HD / 2);
+#pragma unroll
+    for (int t = 0; t < HD / 2; t += 4) {
+      float4 v = *reinterpret_cast<const float4*>(qp + t);
+      q[t] = v.x * scale; q[t + 1] = v.y * scale; q[t + 2] = v.z * scale; q[t + 3] = v.w * scale;
+    }
+  }
+  f32x16 O[OB];
+#pragma unroll
+  for (int o = 0; o < OB; ++o)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[o][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  if constexpr (HV != HD) {
+    for (int e = tid; e < TKS * (HV - HD); e += 256) Vt[(e / (HV - HD)) * HV + HD + e % (HV - HD)] = 0.f;
+  }
+  const unsigned long long kaddr = (unsigned long long)(p.qkv + kbase * ld);
+  const unsigned long long kaddr_u = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(kaddr >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((unsigned)kaddr);
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)kaddr_u, 0, __builtin_amdgcn_readfirstlane(Nkp * ld * 4), 0x00020000);
+  int kvo[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int e = tid + it * 256, key = e / V4, v4 = e % V4;
+    // rows past the padded count get an out-of-range VGPR offset (the SGPR tile offset is not bounds-checked): zeros
+    kvo[it] = (key * ld + head * HD + 4 * v4 + p.d) * 4;
+  }
+  f32x4 kreg[ITER], vreg[ITER];
+  auto gload = [&](int st) {
+    const int so = __builtin_amdgcn_readfirstlane(st * TKS * ld * 4);
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int key = (tid + it * 256) / V4;
+      const int vo = st * TKS + key < Nkp ? kvo[it] : 0x7ffffff0;
+      kreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, vo, so, 0));
+      vreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, vo + p.d * 4, so, 0));
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int e = tid + it * 256, key = e / V4, v4 = e % V4;
+      *reinterpret_cast<f32x4*>(&Kt[key * KS + 4 * v4]) = kreg[it];
+      *reinterpret_cast<f32x4*>(&Vt[key * HV + 4 * v4]) = vreg[it];
+    }
+  };
+
+  const int nst = (nk + TKS - 1) / TKS;
+  if (nst > 0) gload(0);
+  for (int st = 0; st < nst; ++st) {
+    __syncthreads();                   // the previous super tile's readers are done
+    lstore();
+    __syncthreads();
+    if (st + 1 < nst) gload(st + 1);   // block-uniform; in flight during the MFMAs below
+    const int k0 = st * TKS + 32 * wave;              // this wave's 32 keys
+    if (k0 < nk) {
+      const float* kp = &Kt[(32 * wave + l31) * KS + hi * (HD / 2)];
+      const float* vp = &Vt[(32 * wave + 4 * hi) * HV + l31];
+      float kf[HD / 2], vf[OB][16];
+#pragma unroll
+      for (int t = 0; t < HD / 2; t += 4) {
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(kp + t);
+        kf[t] = kv[0]; kf[t + 1] = kv[1]; kf[t + 2] = kv[2]; kf[t + 3] = kv[3];
+      }
+#pragma unroll
+      for (int o = 0; o < OB; ++o)
+#pragma unroll
+        for (int st2 = 0; st2 < 16; ++st2) vf[o][st2] = vp[((st2 & 3) + 8 * (st2 >> 2)) * HV + o * 32];
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16 S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[0], q[0], zero16, 0, 0, 0);
+#pragma unroll
+      for (int t = 1; t < HD / 2; ++t) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], q[t], S, 0, 0, 0);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float sv = key < nk ? S[r] : -INFINITY;
+        S[r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+      mx = xhalf_max(mx);
+      const float mn = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = __builtin_amdgcn_exp2f(S[r] - mn);
+        S[r] = pr;
+        rs += pr;
+      }
+      rs = xhalf_sum(rs);
+      l = l * alpha + rs;
+      m = mn;
+      // per-tile product from a zero accumulator, folded into O with the rescale (two-level accumulation as above)
+#pragma unroll
+      for (int o = 0; o < OB; ++o) {
+        f32x16 T = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[o][0], S[0], zero16, 0, 0, 0);
+#pragma unroll
+        for (int st2 = 1; st2 < 16; ++st2) T = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[o][st2], S[st2], T, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[o][r] = O[o][r] * alpha + T[r];
+      }
+    }
+  }
+  // ---- merge the four key ranges: wave w publishes (m, l) per query and its unnormalised O; every thread then combines
+  //      one (query, 4 dims) group:  out = sum_w 2^(m_w - m*) O_w / sum_w 2^(m_w - m*) l_w
+  __syncthreads();
+  float* Om = asm_;                               // [4][32 queries][HD + 4]   (the K/V staging area is free now)
+  float* ml = asm_ + 4 * 32 * (HD + 4);           // [4][32][2]
+  constexpr int OS = HD + 4;
+#pragma unroll
+  for (int o = 0; o < OB; ++o)
+#pragma unroll
+    for (int g = 0; g < (HD < 32 ? HD / 8 : 4); ++g) {
+      const f32x4 v = {O[o][4 * g], O[o][4 * g + 1], O[o][4 * g + 2], O[o][4 * g + 3]};
+      *reinterpret_cast<f32x4*>(&Om[(wave * 32 + l31) * OS + o * 32 + 8 * g + 4 * hi]) = v;
+    }
+  if (hi == 0) { ml[(wave * 32 + l31) * 2] = m; ml[(wave * 32 + l31) * 2 + 1] = l; }
+  __syncthreads();
+  for (int e = tid; e < 32 * (HD / 4); e += 256) {
+    const int qi = e / (HD / 4), d4 = (e % (HD / 4)) * 4;
+    float mw[4], ms = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { mw[w] = ml[(w * 32 + qi) * 2]; ms = fmaxf(ms, mw[w]); }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float lt = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = mw[w] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw[w] - ms);
+      lt += f * ml[(w * 32 + qi) * 2 + 1];
+      acc += f * *reinterpret_cast<const f32x4*>(&Om[(w * 32 + qi) * OS + d4]);
+    }
+    const float inv = (lt > 0.f && q0 + qi < nq) ? 1.0f / lt : 0.f;        // rows past the valid count: zeros
+    *reinterpret_cast<f32x4*>(p.out + (qbase + q0 + qi) * p.d + head * HD + d4) = acc * inv;
+  }
+}
+
 }  // namespace
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
@@ -317,6 +489,31 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   // 128 VGPRs (4 waves per SIMD, 12 spilled; the kernel needs 136 = 3 waves) made no difference either.
   const char* env = getenv("IMX_ATTN");
   const int mode = env ? atoi(env) : 3;
+  // small grids (one or two pairs): the key-split form -- 32-query workgroups whose four waves split the keys.  IMX_ATTN_SPLIT=0
+  // keeps the throughput form for every batch size (then results do not depend on the batch size bit for bit), =1 forces it.
+  const char* senv = getenv("IMX_ATTN_SPLIT");
+  const long wgs = (long)grid.x * grid.y * grid.z;
+  const bool split = senv ? atoi(senv) != 0 : (wgs <= 256 && nmax >= 256);
+  if (split) {
+    dim3 sgrid((unsigned)((nmax + 31) / 32), (unsigned)a.heads, (unsigned)(2 * a.B));
+    auto launch = [&](auto kern, int hdv) {
+      const int ks = hdv + 4, hv = hdv < 32 ? 32 : hdv;
+      const size_t stage = (size_t)128 * (ks + hv) * 4, merge = (size_t)(4 * 32 * (hdv + 4) + 4 * 32 * 2) * 4;
+      const size_t lds = stage > merge ? stage : merge;
+      static bool attr[3] = {false, false, false};
+      bool& done = attr[hdv == 16 ? 0 : hdv == 32 ? 1 : 2];
+      if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        done = true;
+      }
+      hipLaunchKernelGGL(kern, sgrid, dim3(256), lds, s, a, scale);
+    };
+    if (hd == 16) launch(attention_split_kernel<16>, 16);
+    else if (hd == 32) launch(attention_split_kernel<32>, 32);
+    else if (hd == 64) launch(attention_split_kernel<64>, 64);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   if (hd == 32) {
     if (mode == 1) hipLaunchKernelGGL((attention_kernel<32, false>), grid, dim3(256), 0, s, a, scale);
     else if (mode == 4) hipLaunchKernelGGL((attention_kernel<32, true, 64>), grid, dim3(256), 0, s, a, scale);

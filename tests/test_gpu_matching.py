@@ -120,10 +120,13 @@ def test_official_cli_end_to_end_on_synthetic_dataset(tmp_path):
     assert [r[0] for r in res] == ["src_000.png", "src_001.png"] and all(r[1] == 512 and r[2] == 512 for r in res)
 
 
-def test_pair_sharding_is_order_independent():
+def test_pair_sharding_is_order_independent(monkeypatch):
     """C4 shape in miniature: 8 pairs processed as two round-robin shards (what 2 ranks would do) and
-    collected through pack/gather/sort give exactly the records of one 8-pair batch."""
+    collected through pack/gather/sort give exactly the records of one 8-pair batch.  (IMX_ATTN_SPLIT=0: batches of up to
+    four pairs otherwise take the key-split attention form, whose results agree with the throughput form to rounding only;
+    this test compares record BYTES across batch sizes 4 and 8.)"""
     from image_matching_amd import shard
+    monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
     d, K, H, W = 128, 1024, 480, 640
     m = _matching(d, K)
     n_pairs, world = 8, 2

@@ -155,11 +155,32 @@ def test_batched_pairs_equal_single_pair_runs():
             "batched pairs must be bit-identical to single-pair runs"
 
 
+def test_attention_key_split_and_throughput_forms_agree(monkeypatch):
+    """Single pairs take the key-split attention form (32-query workgroups, four waves splitting the keys), batches the
+    throughput form.  Both must give the reference's matches on the full-size fixtures (the default B = 1 runs above use the
+    split form; here the throughput form is forced), and their matching scores agree to rounding."""
+    g = util.golden("c3_pair_s59.npz")
+    H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
+    data = {k: v.cuda() for k, v in _oracle_pair_inputs(seed, H, W, d, K).items()}
+    eng, L = _engine(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(d))
+    out = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("IMX_ATTN_SPLIT", split)
+        out[split] = _run(eng, data, (1, 1, H, W))
+        assert np.array_equal(out[split][0], g["matches0"]) and np.array_equal(out[split][1], g["matches1"]), f"IMX_ATTN_SPLIT={split}"
+    np.testing.assert_allclose(out["1"][2], out["0"][2], rtol=0, atol=2e-5)
+    monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
+    for name in ("c3_pair_s55.npz", "c5_pair_s19.npz"):
+        test_full_size_matches_bit_exact_vs_reference_golden(name)
+
+
 @pytest.mark.parametrize("mode", ["1", "4"])
 def test_every_attention_variant_matches_bit_exact(mode, monkeypatch):
     """IMX_ATTN selects the attention kernel form (1: one K/V tile in flight, 3 = default: two tiles in flight, 4: 64-key
     staged tiles).  Every form must give the reference's matches on a C3 and the C5 fixture (head sizes 32 and 64)."""
     monkeypatch.setenv("IMX_ATTN", mode)
+    monkeypatch.setenv("IMX_ATTN_SPLIT", "0")          # the A/B switch selects among the throughput forms
     for name in ("c3_pair_s59.npz", "c5_pair_s19.npz"):
         test_full_size_matches_bit_exact_vs_reference_golden(name)
 

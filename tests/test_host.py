@@ -246,3 +246,17 @@ def test_winograd_f2x4_matrices_reproduce_the_direct_convolution():
         Y = AT2 @ (U * V) @ AT4.T               # 2 x 4
         ref = np.array([[(g * d[y:y + 3, x:x + 3]).sum() for x in range(4)] for y in range(2)])
         np.testing.assert_allclose(Y, ref, rtol=0, atol=1e-12)
+
+
+def test_traditional_plumbing_flags_and_skip_line(capsys):
+    """BASELINE configs[0] (traditional.py:8-57): the reference's flags and defaults; without OpenCV the script prints one
+    skip line and returns instead of failing (the arithmetic is OpenCV's: no GPU path, no parity claim)."""
+    import traditional
+    from Traditional import registration
+    opt = traditional.build_parser().parse_args([])
+    assert (opt.Method, opt.img_dir, opt.Result_dir, opt.resize_scale, opt.match_viz) == \
+        ('SIFT', 'datasets/Amazon/', 'Results/Amazon/', 0.5, True)
+    assert registration.MIN_MATCH_COUNT == 10 and registration.RATIO == 0.7
+    if registration.cv2 is None:
+        assert traditional.main([]) == []
+        assert "skipped" in capsys.readouterr().out

@@ -21,3 +21,5 @@ for _ in range(10): m.match_batch(x0, x1)
 torch.cuda.synchronize()
 rows = eng.timing_report(); eng.set_timing(False)
 print("sum of kernel times per pair: %.3f ms over %d launches" % (sum(r[2] for r in rows) / 10, sum(r[1] for r in rows) / 10))
+for r in sorted(rows, key=lambda r: -r[2]):
+    print(f"  {r[0]:16s} launches/pair {r[1] / 10:6.1f}  ms/pair {r[2] / 10:7.4f}  us/launch {1e3 * r[2] / r[1]:7.2f}")
