@@ -289,7 +289,10 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
       const int wr = (lane & 15) >> 2, wc = lane & 3;
       const int Ho = H >> 1, Wo = W >> 1;
       const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)bcur * Ho * Wo * Cout), 0, Ho * Wo * Cout * 4, 0x00020000);
-      const int choff = (cb * 16 + 4 * (lane >> 4)) * 4;
+      // NHWC, or channel-blocked (B, Cout/8, Ho, Wo, 8) for the next Winograd layer (conv3x3_wino24.hip: dense patch loads)
+      const bool outb = p.out_blocked != 0;
+      const int opx = outb ? 32 : Cout * 4;
+      const int choff = outb ? (cb * 2 + (lane >> 5)) * (Ho * Wo * 32) + ((lane >> 4) & 1) * 16 : (cb * 16 + 4 * (lane >> 4)) * 4;
       typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
       const int oy = (y0 >> 1) + wr;
 #pragma unroll
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
         const f32x4 v = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_max(y[0][2 * hh], y[0][2 * hh + 1]),
                                                                             __builtin_elementwise_max(y[1][2 * hh], y[1][2 * hh + 1])) + bs4, zero4);
         const int ox = (x0 >> 1) + 2 * wc + hh;
-        const unsigned off = (oy < Ho && ox < Wo) ? (unsigned)((oy * Wo + ox) * Cout * 4 + choff) : 0x7ffffff0u;
+        const unsigned off = (oy < Ho && ox < Wo) ? (unsigned)((oy * Wo + ox) * opx + choff) : 0x7ffffff0u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (int)off, 0, 0);
       }
     }

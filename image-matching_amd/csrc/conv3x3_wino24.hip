@@ -57,7 +57,7 @@ struct BoolC { static constexpr bool value = V; };
 
 // EXP (trace builds only, IMX_WINO_EXP=n): timing experiments that DROP one ingredient of the phase (results are garbage):
 //   1 no in-stream input transform   2 no U-panel (B operand) loads   3 no raw patch loads / stores   4 no A-operand LDS reads
-//   5 MFMAs + barrier only           6 no barrier
+//   5 MFMAs + barrier only           6 no barrier                  7 raw patch loads made CONTIGUOUS (same bytes, dense lines)
 template <bool POOL, bool RELU, bool TRACE, int EXP = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x, int tiles_y, int nitems, unsigned* trace) {
   // TRACE: s_memtime deltas summed over the stream (bring-up instrumentation, IMX_WINO_TRACE=1)
@@ -110,7 +110,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int e = (k == 1 && tid + 256 < RH * RW * 2) ? tid + 256 : tid;
-    const int px = e % (RH * RW), half = e / (RH * RW);
+    // blocked input: lane pairs read a pixel's 32 contiguous bytes, consecutive lanes consecutive pixels (dense lines; the LDS
+    // stores are then 2-way conflicted, 16 extra LDS cycles per phase); NHWC input: pixel-major (conflict-free stores)
+    const int px = p.in_blocked ? e >> 1 : e % (RH * RW), half = p.in_blocked ? e & 1 : e / (RH * RW);
     lpy[k] = px / RW - 1;
     lpx[k] = px % RW - 1;
     ldst[k] = px * RSC + half * 4;
@@ -131,12 +133,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
   int litem = item_c, lchunk = 0;
   __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0, 0x00020000);
   unsigned goff[2];
+  // Input layout.  NHWC: a pixel's 8-channel chunk is 32 bytes of a Cin*4-byte record, so a wave's patch load touches 64
+  // different 128-byte lines for 1 KB of payload and the 2 x 56 KB per phase of U + patch traffic evicts them from the 32 KB
+  // L1 before the next chunk reuses them (measured: dense loads of the same volume shorten a phase from 3450 to 3050 cycles,
+  // IMX_WINO_EXP=7).  Channel-blocked (B, Cin/8, H, W, 8): the chunk's plane holds consecutive pixels' 32 bytes back to back --
+  // a patch row of 18 pixels is 576 contiguous bytes.  The chunk's plane offset rides in the SGPR operand.
+  const bool inb = p.in_blocked != 0;
+  const int pxb = inb ? CK * 4 : Cin * 4;                       // bytes from one pixel to the next
+  const int chunk_step = inb ? H * W * CK * 4 : CK * 4;         // bytes from one chunk to the next
   auto loader_item = [&](const Item& it, bool live) {
     lrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)(live ? it.b : 0) * H * W * Cin), 0, live ? img_bytes : 0, 0x00020000);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int gy = it.y0 + lpy[k], gx = it.x0 + lpx[k];
-      goff[k] = (live && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (unsigned)(((gy * W + gx) * Cin + lhalf[k] * 4) * 4) : OOB;
+      goff[k] = (live && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (unsigned)((gy * W + gx) * pxb + lhalf[k] * 16) : OOB;
+      if (EXP == 7) goff[k] = live ? (unsigned)((((it.y0 * W + it.x0) * Cin) + (tid + k * 256) * 4) * 4) : OOB;      // dense 16 B per lane
     }
   };
   // two register sets, one per stream-position parity: a patch is requested FOUR positions ahead and has two full phases
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
   // before its use -- removing the raw path altogether shortened a phase by 670 of 3500 cycles, IMX_WINO_EXP=3)
   f32x4 rr[2][2];
   auto issue_load = [&](int set) {
-    const int so = __builtin_amdgcn_readfirstlane(lchunk * (CK * 4));
+    const int so = __builtin_amdgcn_readfirstlane(lchunk * chunk_step);
     rr[set][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)goff[0], so, 0));
     rr[set][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)goff[1], so, 0));
   };
@@ -204,15 +215,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
   //      output block) goes into the BASE of a per-item buffer descriptor whose range is what is left of the image from
   //      there, so rows below the image are out of range and dropped by the hardware (the SGPR offset operand of a buffer
   //      access is NOT bounds-checked, so the item part must not ride there); no per-store address arithmetic.
+  //      Output layout: NHWC, or channel-blocked (B, Cout/8, Ho, Wo, 8) for the next Winograd layer: the lane's four channels
+  //      are half of chunk cob*8 + cb*2 + (lane>>5).  In the blocked layout a row below the image would land inside the next
+  //      chunk's plane instead of past the end, so the fast path there also needs the height to be a whole number of tiles.
   const int Ho_k = POOL ? H >> 1 : H, Wo_k = POOL ? W >> 1 : W;
-  const bool fastw = (Wo_k % (POOL ? OW / 2 : OW)) == 0;
+  const bool outb = p.out_blocked != 0;
+  const bool fastw = (Wo_k % (POOL ? OW / 2 : OW)) == 0 && (!outb || (Ho_k % (POOL ? OH / 2 : OH)) == 0);
   const int lwr = (lane & 15) >> 2, lwc = lane & 3;
-  const int chl = (cb * 16 + 4 * (lane >> 4)) * 4;
+  const int opx = outb ? CK * 4 : Cout * 4;                                  // bytes from one output pixel to the next
+  const int chl = outb ? (cb * 2 + (lane >> 5)) * (Ho_k * Wo_k * CK * 4) + ((lane >> 4) & 1) * 16 : (cb * 16 + 4 * (lane >> 4)) * 4;
   int soff[POOL ? 2 : 8];
 #pragma unroll
   for (int e = 0; e < (POOL ? 2 : 8); ++e) {
     const int oy = POOL ? lwr : 2 * lwr + (e >> 2), ox = POOL ? 2 * lwc + e : 4 * lwc + (e & 3);
-    soff[e] = (oy * Wo_k + ox) * Cout * 4 + chl;
+    soff[e] = (oy * Wo_k + ox) * opx + chl;
   }
   int chunk = 0;
   f32x4 bs4 = {0.f, 0.f, 0.f, 0.f};   // bias of this lane's four output channels (current item)
@@ -301,7 +317,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
       const int Ho = Ho_k, Wo = Wo_k;
       typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
       // item part of every store offset: first output pixel of the tile + output block (uniform)
-      const int ibase = __builtin_amdgcn_readfirstlane((((POOL ? cur.y0 >> 1 : cur.y0) * Wo + (POOL ? cur.x0 >> 1 : cur.x0)) * Cout + cur.cob * NT) * 4);
+      const int ibase = __builtin_amdgcn_readfirstlane(((POOL ? cur.y0 >> 1 : cur.y0) * Wo + (POOL ? cur.x0 >> 1 : cur.x0)) * opx +
+                                                       (outb ? cur.cob * (NT / CK) * (Ho * Wo * CK * 4) : cur.cob * NT * 4));
       const int fbase = fastw ? ibase : 0;      // FASTW: descriptor starts at the item; else at the image (offsets masked per store)
       const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)cur.b * Ho * Wo * Cout + (fbase >> 2)), 0,
                                                                            Ho * Wo * Cout * 4 - fbase, 0x00020000);
@@ -375,6 +392,7 @@ hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
   if (exp_id == 4) kt = conv3x3_wino24<POOL, RELU, true, 4>;
   if (exp_id == 5) kt = conv3x3_wino24<POOL, RELU, true, 5>;
   if (exp_id == 6) kt = conv3x3_wino24<POOL, RELU, true, 6>;
+  if (exp_id == 7) kt = conv3x3_wino24<POOL, RELU, true, 7>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

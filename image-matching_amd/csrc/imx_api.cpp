@@ -50,7 +50,8 @@ struct GnnLayer {
 };
 struct Tap {
   const void* p;
-  std::vector<int64_t> shape;
+  std::vector<int64_t> shape;      // what imx_debug_fetch returns (NHWC for activations)
+  bool blocked = false;            // the device buffer is channel-blocked (B, C/8, H, W, 8): un-blocked on the host at fetch time
 };
 struct TimedEvent {
   std::string name;
@@ -159,7 +160,9 @@ int run(imx_handle_t h, const char* name, hipStream_t s, F&& f) {
     if (run(h, name, s, [&]() -> hipError_t { return (expr); })) return -1; \
   } while (0)
 
-void tap(imx_handle_t h, const char* name, const void* p, std::vector<int64_t> shape) { h->taps[name] = Tap{p, std::move(shape)}; }
+void tap(imx_handle_t h, const char* name, const void* p, std::vector<int64_t> shape, bool blocked = false) {
+  h->taps[name] = Tap{p, std::move(shape), blocked};
+}
 
 // ----------------------------------------------------------------------------- expected keys
 void add_conv_keys(std::map<std::string, std::vector<int64_t>>& m, const std::string& conv, int cout, int cin, int k,
@@ -518,8 +521,23 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   WS(smap, float, "sp.score_map", (size_t)B * H8 * W8 * f);
   WS(nms, float, "sp.nms", (size_t)B * H8 * W8 * f);
 
-  auto conv = [&](const char* name, const ConvW& w, const float* in, float* out, int hh, int ww, bool pool, bool first) -> int {
+  // Activations between the Winograd layers are channel-blocked (B, C/8, H, W, 8) -- dense patch loads for the next layer
+  // (conv3x3_wino24.hip); the last 3x3 layer writes NHWC rows for the 1x1-conv GEMMs.  IMX_CONV=direct (or a layer the Winograd
+  // kernels reject) keeps NHWC everywhere: the direct kernel reads nothing else.
+  static const bool blocked_env = !(getenv("IMX_CONV_BLOCKED") && atoi(getenv("IMX_CONV_BLOCKED")) == 0);     // A/B switch
+  bool blocked = !h->conv_direct && blocked_env;
+  {
+    const int hs[7] = {H2, H2, H4, H4, Hc, Hc, Hc}, ws_[7] = {W2, W2, W4, W4, Wc, Wc, Wc};
+    for (int i = 1; i < 8 && blocked; ++i) {
+      ConvArgs t{};
+      t.H = hs[i - 1]; t.W = ws_[i - 1]; t.Cin = h->conv[i].cin; t.Cout = h->conv[i].cout; t.wu24 = h->conv[i].wu24;
+      blocked = conv3x3_wino24_supported(t);
+    }
+  }
+  auto conv = [&](const char* name, const ConvW& w, const float* in, float* out, int hh, int ww, bool pool, bool first, bool last = false) -> int {
     ConvArgs a{};
+    a.in_blocked = (blocked && !first) ? 1 : 0;
+    a.out_blocked = (blocked && !last) ? 1 : 0;
     a.in = in; a.in2 = first ? img1 : nullptr; a.split = first ? split : 0;
     a.w = w.w; a.wu24 = w.wu24; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
     a.B = B; a.H = hh; a.W = ww; a.Cin = w.cin; a.Cout = w.cout; a.relu = 1; a.pool = pool ? 1 : 0; a.first = first ? 1 : 0;
@@ -535,7 +553,7 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   if (conv("conv3b_pool", h->conv[4], a3a, a3, H4, W4, true, false)) return -1;
   if (conv("conv4a", h->conv[5], a3, a4a, Hc, Wc, false, false)) return -1;
   if (conv("conv4b", h->conv[6], a4a, x4, Hc, Wc, false, false)) return -1;
-  if (conv("convPaDa", h->conv[7], x4, hd, Hc, Wc, false, false)) return -1;
+  if (conv("convPaDa", h->conv[7], x4, hd, Hc, Wc, false, false, true)) return -1;
   const int rows = B * Hc * Wc;
   if (gemm(h, s, "convPb", h->pb, hd, 512, 256, nullptr, 0, 0, nullptr, 0, semi, 65, rows, false)) return -1;
   if (gemm(h, s, "convDb", h->db, hd + 256, 512, 256, nullptr, 0, 0, nullptr, 0, dense, d, rows, false)) return -1;
@@ -563,10 +581,10 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   if (counts_out) HIP_OK(h, hipMemcpyAsync(counts_out, sel_count, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
 
   h->det_B = B; h->det_H = H; h->det_W = W; h->det_Hc = Hc; h->det_Wc = Wc; h->det_Ksel = Ksel;
-  tap(h, "a1", a1, {B, H2, W2, 64});
-  tap(h, "a2", a2, {B, H4, W4, 64});
-  tap(h, "a3", a3, {B, Hc, Wc, 128});
-  tap(h, "x4", x4, {B, Hc, Wc, 128});
+  tap(h, "a1", a1, {B, H2, W2, 64}, blocked);
+  tap(h, "a2", a2, {B, H4, W4, 64}, blocked);
+  tap(h, "a3", a3, {B, Hc, Wc, 128}, blocked);
+  tap(h, "x4", x4, {B, Hc, Wc, 128}, blocked);
   tap(h, "semi", semi, {B, Hc, Wc, 65});
   tap(h, "desc_raw", dense, {B, Hc, Wc, d});
   tap(h, "score_map", smap, {B, H8, W8});
@@ -1000,7 +1018,19 @@ int imx_debug_fetch(imx_handle_t h, const char* name, float* host_out, int64_t c
     if (capacity < n) return fail(h, "imx_debug_fetch: capacity %lld < %lld elements", (long long)capacity, (long long)n);
     HIP_OK(h, hipSetDevice(h->device));
     HIP_OK(h, hipDeviceSynchronize());
-    HIP_OK(h, hipMemcpy(host_out, it->second.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (!it->second.blocked) {
+      HIP_OK(h, hipMemcpy(host_out, it->second.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+      return 0;
+    }
+    // channel-blocked activation (B, C/8, H, W, 8) -> the NHWC tensor the tap promises
+    std::vector<float> raw((size_t)n);
+    HIP_OK(h, hipMemcpy(raw.data(), it->second.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    const int64_t Bn = it->second.shape[0], Hn = it->second.shape[1], Wn = it->second.shape[2], Cn = it->second.shape[3];
+    for (int64_t bb = 0; bb < Bn; ++bb)
+      for (int64_t ck = 0; ck < Cn / 8; ++ck)
+        for (int64_t yx = 0; yx < Hn * Wn; ++yx)
+          for (int64_t c = 0; c < 8; ++c)
+            host_out[(bb * Hn * Wn + yx) * Cn + ck * 8 + c] = raw[((bb * (Cn / 8) + ck) * Hn * Wn + yx) * 8 + c];
     return 0;
   });
 }

@@ -20,6 +20,10 @@ struct ConvArgs {
   float* out;         // NHWC (B,Ho,Wo,Cout); Ho,Wo = H/2,W/2 (floor) when pool
   int B, H, W, Cin, Cout;
   int relu, pool, first;
+  // Activation layout between the Winograd layers: 0 = NHWC (B,H,W,C); 1 = channel-blocked (B, C/8, H, W, 8) -- a chunk of eight
+  // channels of consecutive pixels is contiguous, which is what the Winograd kernels' per-chunk patch loads read (conv3x3_wino24.hip).
+  // The direct kernel (conv3x3.hip) and the 1x1-conv GEMMs take NHWC only.
+  int in_blocked, out_blocked;
 };
 // Cin % 16 == 0, Cout % 64 == 0.
 hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);       // direct form (conv3x3.hip)
