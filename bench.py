@@ -83,7 +83,7 @@ def algorithmic_work(B, H, W, d, K, kenc, iters, n_layers=18):
         "gnn_mlp2": ("mfma", 2.0 * R * 2 * d * d),
         "final_proj": ("mfma", 2.0 * R * d * d),
         "score_gemm": ("mfma", 2.0 * B * K * K * d),
-        "sinkhorn": ("hbm", 4.0 * B * K * K * 2 * iters),       # one launch group = all iterations
+        "sinkhorn": ("hbm", 4.0 * B * K * K * iters),           # one launch group = all iterations; the slab form reads S ONCE per iteration
         "matches": ("hbm", 4.0 * B * K * K * 2),
     }
     ch = list(kenc) + [d]
