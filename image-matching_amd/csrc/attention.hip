@@ -311,11 +311,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
 // (max, sum, output) partials are merged through LDS at the end.  4x the workgroups, 1/4 of the serial work per wave.
 // Same per-tile arithmetic as attention_kernel (tile maximum, log2-domain softmax, P fed from the S accumulators); the
 // accumulation order differs (four partial sums), so results agree with the throughput form to rounding, not bit for bit.
-template <int HD>
-__global__ __launch_bounds__(256) void attention_split_kernel(AttnArgs p, float scale) {
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW) void attention_split_kernel(AttnArgs p, float scale) {
   constexpr int KS = HD + 4, HV = HD < 32 ? 32 : HD, OB = HV / 32, V4 = HD / 4;
-  constexpr int TKS = 128;                      // keys per staged super tile
-  constexpr int ITER = (TKS * V4) / 256;        // float4 of K (and of V) per thread and super tile: 2 / 4 / 8
+  constexpr int NT = 64 * NW;                   // threads: NW waves, each multiplying its own 32-key sub-tile
+  constexpr int TKS = 32 * NW;                  // keys per staged super tile
+  constexpr int ITER = (TKS * V4) / NT;         // float4 of K (and of V) per thread and super tile: 2 / 4 / 8
   extern __shared__ __attribute__((aligned(16))) float asm_[];
   float* Kt = asm_;                              // [128][KS]
   float* Vt = asm_ + TKS * KS;                   // [128][HV]
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AttnArgs p, float 
   float m = -INFINITY, l = 0.f;
 
   if constexpr (HV != HD) {
-    for (int e = tid; e < TKS * (HV - HD); e += 256) Vt[(e / (HV - HD)) * HV + HD + e % (HV - HD)] = 0.f;
+    for (int e = tid; e < TKS * (HV - HD); e += NT) Vt[(e / (HV - HD)) * HV + HD + e % (HV - HD)] = 0.f;
   }
   const unsigned long long kaddr = (unsigned long long)(p.qkv + kbase * ld);
   const unsigned long long kaddr_u = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(kaddr >> 32)) << 32) |
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AttnArgs p, float 
   int kvo[ITER];
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
-    const int e = tid + it * 256, key = e / V4, v4 = e % V4;
+    const int e = tid + it * NT, key = e / V4, v4 = e % V4;
     // rows past the padded count get an out-of-range VGPR offset (the SGPR tile offset is not bounds-checked): zeros
     kvo[it] = (key * ld + head * HD + 4 * v4 + p.d) * 4;
   }
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AttnArgs p, float 
     const int so = __builtin_amdgcn_readfirstlane(st * TKS * ld * 4);
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-      const int key = (tid + it * 256) / V4;
+      const int key = (tid + it * NT) / V4;
       const int vo = st * TKS + key < Nkp ? kvo[it] : 0x7ffffff0;
       kreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, vo, so, 0));
       vreg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, vo + p.d * 4, so, 0));
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AttnArgs p, float 
   auto lstore = [&]() {
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-      const int e = tid + it * 256, key = e / V4, v4 = e % V4;
+      const int e = tid + it * NT, key = e / V4, v4 = e % V4;
       *reinterpret_cast<f32x4*>(&Kt[key * KS + 4 * v4]) = kreg[it];
       *reinterpret_cast<f32x4*>(&Vt[key * HV + 4 * v4]) = vreg[it];
     }
@@ -445,8 +446,8 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AttnArgs p, float 
   // ---- merge the four key ranges: wave w publishes (m, l) per query and its unnormalised O; every thread then combines
   //      one (query, 4 dims) group:  out = sum_w 2^(m_w - m*) O_w / sum_w 2^(m_w - m*) l_w
   __syncthreads();
-  float* Om = asm_;                               // [4][32 queries][HD + 4]   (the K/V staging area is free now)
-  float* ml = asm_ + 4 * 32 * (HD + 4);           // [4][32][2]
+  float* Om = asm_;                               // [NW][32 queries][HD + 4]   (the K/V staging area is free now)
+  float* ml = asm_ + NW * 32 * (HD + 4);          // [NW][32][2]
   constexpr int OS = HD + 4;
 #pragma unroll
   for (int o = 0; o < OB; ++o)
@@ -457,15 +458,15 @@ __global__ __launch_bounds__(256) void attention_split_kernel(AttnArgs p, float 
     }
   if (hi == 0) { ml[(wave * 32 + l31) * 2] = m; ml[(wave * 32 + l31) * 2 + 1] = l; }
   __syncthreads();
-  for (int e = tid; e < 32 * (HD / 4); e += 256) {
+  for (int e = tid; e < 32 * (HD / 4); e += NT) {
     const int qi = e / (HD / 4), d4 = (e % (HD / 4)) * 4;
-    float mw[4], ms = -INFINITY;
+    float mw[NW], ms = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { mw[w] = ml[(w * 32 + qi) * 2]; ms = fmaxf(ms, mw[w]); }
+    for (int w = 0; w < NW; ++w) { mw[w] = ml[(w * 32 + qi) * 2]; ms = fmaxf(ms, mw[w]); }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float lt = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const float f = mw[w] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw[w] - ms);
       lt += f * ml[(w * 32 + qi) * 2 + 1];
       acc += f * *reinterpret_cast<const f32x4*>(&Om[(w * 32 + qi) * OS + d4]);
@@ -496,9 +497,9 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   const bool split = senv ? atoi(senv) != 0 : (wgs <= 256 && nmax >= 256);
   if (split) {
     dim3 sgrid((unsigned)((nmax + 31) / 32), (unsigned)a.heads, (unsigned)(2 * a.B));
-    auto launch = [&](auto kern, int hdv) {
+    auto launch = [&](auto kern, int hdv, int nw) {
       const int ks = hdv + 4, hv = hdv < 32 ? 32 : hdv;
-      const size_t stage = (size_t)128 * (ks + hv) * 4, merge = (size_t)(4 * 32 * (hdv + 4) + 4 * 32 * 2) * 4;
+      const size_t stage = (size_t)32 * nw * (ks + hv) * 4, merge = (size_t)(nw * 32 * (hdv + 4) + nw * 32 * 2) * 4;
       const size_t lds = stage > merge ? stage : merge;
       static bool attr[3] = {false, false, false};
       bool& done = attr[hdv == 16 ? 0 : hdv == 32 ? 1 : 2];
@@ -506,11 +507,11 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         done = true;
       }
-      hipLaunchKernelGGL(kern, sgrid, dim3(256), lds, s, a, scale);
+      hipLaunchKernelGGL(kern, sgrid, dim3(64 * nw), lds, s, a, scale);
     };
-    if (hd == 16) launch(attention_split_kernel<16>, 16);
-    else if (hd == 32) launch(attention_split_kernel<32>, 32);
-    else if (hd == 64) launch(attention_split_kernel<64>, 64);
+    if (hd == 16) launch(attention_split_kernel<16, 8>, 16, 8);
+    else if (hd == 32) launch(attention_split_kernel<32, 8>, 32, 8);
+    else if (hd == 64) launch(attention_split_kernel<64, 4>, 64, 4);
     else return hipErrorInvalidValue;
     return hipGetLastError();
   }

@@ -495,7 +495,10 @@ int gemm(imx_handle_t h, hipStream_t s, const char* name, const GemmW& W, const 
   // IMX_GEMM=tiled keeps every product on the tiled kernels of gemm.hip (read per call so tests can switch)
   const char* ge = getenv("IMX_GEMM");
   const bool ws = gemm_ws_supported(g) && !(ge && (ge[0] == 't' || ge[0] == '1' || ge[0] == '3'));
-  RUN(name, ws ? launch_gemm_ws(g, s) : launch_gemm(g, s));
+  // small row counts (one or two pairs): the latency form.  IMX_GEMM_SMALL=0 never, =1 whenever the shape allows.
+  const char* gs = getenv("IMX_GEMM_SMALL");
+  const bool small = gemm_small_supported(g) && !(ge && ge[0] == 't') && (gs ? atoi(gs) != 0 : M <= 4096);
+  RUN(name, small ? launch_gemm_small(g, s) : ws ? launch_gemm_ws(g, s) : launch_gemm(g, s));
   return 0;
 }
 

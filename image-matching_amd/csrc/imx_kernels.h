@@ -51,6 +51,9 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 // float4-aligned leading dimensions
 bool gemm_ws_supported(const GemmArgs& a);
 hipError_t launch_gemm_ws(const GemmArgs& a, hipStream_t s);
+// latency form for small row counts (gemm_small.hip): 32 x 32 output tiles, whole-K panels staged in LDS; K % 64 == 0, K <= 512
+bool gemm_small_supported(const GemmArgs& a);
+hipError_t launch_gemm_small(const GemmArgs& a, hipStream_t s);
 
 // scores[b][i][j] = scale * sum_k m0[b][i][k] * m1[b][j][k]   ("NT" GEMM, per pair)
 struct ScoreArgs {

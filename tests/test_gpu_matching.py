@@ -49,21 +49,35 @@ def test_matching_forward_vs_reference_golden(name):
     assert np.array_equal(m1[m0[i]], i)
 
 
-def test_fused_batch_equals_per_pair_forward():
+def test_fused_batch_equals_per_pair_forward(monkeypatch):
+    """A batch through the fused call equals the per-pair drop-in forward.  With the throughput kernel forms forced for every
+    batch size (IMX_ATTN_SPLIT=0, IMX_GEMM_SMALL=0) the results are bit-identical; with the default dispatch single pairs take
+    the latency forms (key-split attention, small-M GEMM), whose accumulation order differs: same keypoints, descriptors and
+    match indices, matching scores equal to rounding."""
     d, K, H, W = 128, 1024, 480, 640
-    m = _matching(d, K)
     pairs = [util.pair(s, H, W) for s in (59, 55, 7)]
     i0 = torch.cat([p[0] for p in pairs]).cuda()
     i1 = torch.cat([p[1] for p in pairs]).cuda()
-    out = m.match_batch(i0, i1, want_desc=True)
-    torch.cuda.synchronize()
-    assert out["counts0"].tolist() == [K] * 3 and out["counts1"].tolist() == [K] * 3
-    for b, (x0, x1) in enumerate(pairs):
-        pred = m({"image0": x0.cuda(), "image1": x1.cuda()})
-        assert torch.equal(out["keypoints0"][b], pred["keypoints0"][0])
-        assert torch.equal(out["descriptors1"][b].t(), pred["descriptors1"][0])
-        assert torch.equal(out["matches0"][b], pred["matches0"][0])
-        assert torch.equal(out["matching_scores1"][b], pred["matching_scores1"][0])
+    for exact in (True, False):
+        if exact:
+            monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
+            monkeypatch.setenv("IMX_GEMM_SMALL", "0")
+        else:
+            monkeypatch.delenv("IMX_ATTN_SPLIT")
+            monkeypatch.delenv("IMX_GEMM_SMALL")
+        m = _matching(d, K)
+        out = m.match_batch(i0, i1, want_desc=True)
+        torch.cuda.synchronize()
+        assert out["counts0"].tolist() == [K] * 3 and out["counts1"].tolist() == [K] * 3
+        for b, (x0, x1) in enumerate(pairs):
+            pred = m({"image0": x0.cuda(), "image1": x1.cuda()})
+            assert torch.equal(out["keypoints0"][b], pred["keypoints0"][0])
+            assert torch.equal(out["descriptors1"][b].t(), pred["descriptors1"][0])
+            assert torch.equal(out["matches0"][b], pred["matches0"][0])
+            if exact:
+                assert torch.equal(out["matching_scores1"][b], pred["matching_scores1"][0])
+            else:
+                torch.testing.assert_close(out["matching_scores1"][b], pred["matching_scores1"][0], rtol=0, atol=2e-5)
 
 
 def test_skip_superpoint_when_keypoints_supplied():
@@ -123,10 +137,12 @@ def test_official_cli_end_to_end_on_synthetic_dataset(tmp_path):
 def test_pair_sharding_is_order_independent(monkeypatch):
     """C4 shape in miniature: 8 pairs processed as two round-robin shards (what 2 ranks would do) and
     collected through pack/gather/sort give exactly the records of one 8-pair batch.  (IMX_ATTN_SPLIT=0: batches of up to
-    four pairs otherwise take the key-split attention form, whose results agree with the throughput form to rounding only;
+    four pairs otherwise take the latency kernel forms (key-split attention, small-M GEMM), whose results agree with the
+    throughput forms to rounding only; IMX_GEMM_SMALL=0 likewise;
     this test compares record BYTES across batch sizes 4 and 8.)"""
     from image_matching_amd import shard
     monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
+    monkeypatch.setenv("IMX_GEMM_SMALL", "0")
     d, K, H, W = 128, 1024, 480, 640
     m = _matching(d, K)
     n_pairs, world = 8, 2

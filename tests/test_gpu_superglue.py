@@ -167,10 +167,12 @@ def test_attention_key_split_and_throughput_forms_agree(monkeypatch):
     out = {}
     for split in ("1", "0"):
         monkeypatch.setenv("IMX_ATTN_SPLIT", split)
+        monkeypatch.setenv("IMX_GEMM_SMALL", split)          # likewise the small-M (latency) vs weights-stationary GEMM
         out[split] = _run(eng, data, (1, 1, H, W))
         assert np.array_equal(out[split][0], g["matches0"]) and np.array_equal(out[split][1], g["matches1"]), f"IMX_ATTN_SPLIT={split}"
     np.testing.assert_allclose(out["1"][2], out["0"][2], rtol=0, atol=2e-5)
     monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
+    monkeypatch.setenv("IMX_GEMM_SMALL", "0")
     for name in ("c3_pair_s55.npz", "c5_pair_s19.npz"):
         test_full_size_matches_bit_exact_vs_reference_golden(name)
 
@@ -212,6 +214,6 @@ def test_full_size_transport_marginals(name):
 def test_tiled_gemm_form_matches_bit_exact(monkeypatch):
     """IMX_GEMM=tiled keeps every 1x1-conv product on the tiled kernels of gemm.hip (the default sends K in {128, 256},
     N % 128 == 0 to the weights-stationary persistent form, gemm_ws.hip).  Both must give the reference's matches."""
-    monkeypatch.setenv("IMX_GEMM", "tiled")
+    monkeypatch.setenv("IMX_GEMM", "tiled")      # (also keeps the small-M latency form out: every product on gemm.hip)
     for name in ("c3_pair_s59.npz", "c5_pair_s19.npz"):
         test_full_size_matches_bit_exact_vs_reference_golden(name)
