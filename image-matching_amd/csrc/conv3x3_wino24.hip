@@ -58,6 +58,7 @@ struct BoolC { static constexpr bool value = V; };
 // EXP (trace builds only, IMX_WINO_EXP=n): timing experiments that DROP one ingredient of the phase (results are garbage):
 //   1 no in-stream input transform   2 no U-panel (B operand) loads   3 no raw patch loads / stores   4 no A-operand LDS reads
 //   5 MFMAs + barrier only           6 no barrier                  7 raw patch loads made CONTIGUOUS (same bytes, dense lines)
+//   8 HALF of the U-panel loads (odd quads keep stale registers)
 template <bool POOL, bool RELU, bool TRACE, int EXP = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x, int tiles_y, int nitems, unsigned* trace) {
   // TRACE: s_memtime deltas summed over the stream (bring-up instrumentation, IMX_WINO_TRACE=1)
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
         acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][2], af[cu][2], acc[2 * g + 1], 0, 0, 0);
         acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][1], af[cu][1], acc[2 * g], 0, 0, 0);
         acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][3], af[cu][3], acc[2 * g + 1], 0, 0, 0);
-        if (EXP != 2 && EXP != 5) bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
+        if (EXP != 2 && EXP != 5 && !(EXP == 8 && (g & 1))) bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
         if (g == 0 && EXP != 1 && EXP != 5) {
 #pragma unroll
           for (int bb = 0; bb < 6; ++bb) { va[bb] = *reinterpret_cast<const f32x2*>(pa + bb * RSC); vb[bb] = *reinterpret_cast<const f32x2*>(pb + bb * RSC); }
@@ -393,6 +394,7 @@ hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
   if (exp_id == 5) kt = conv3x3_wino24<POOL, RELU, true, 5>;
   if (exp_id == 6) kt = conv3x3_wino24<POOL, RELU, true, 6>;
   if (exp_id == 7) kt = conv3x3_wino24<POOL, RELU, true, 7>;
+  if (exp_id == 8) kt = conv3x3_wino24<POOL, RELU, true, 8>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -159,6 +159,44 @@ def test_pair_sharding_is_order_independent(monkeypatch):
     assert rec["pair_id"].tolist() == list(range(n_pairs)) and (rec["counts0"] == K).all()
 
 
+def test_c4_shape_512_pairs_as_eight_shards_of_64():
+    """BASELINE configs[3] on the one GPU a test box has: 512 synthetic 640x480 pairs processed as the eight round-robin shards
+    of 64 pairs the eight ranks would take (pair i -> rank i % 8), each shard's records packed as on a rank, concatenated in
+    rank order as the gather to rank 0 delivers them, and checked: every pair exactly once, 1024 keypoints per image, and the
+    records of a shard identical to the same pairs' records when the shard boundaries are drawn differently (pairs 0..63 as one
+    batch vs as members of shards 0..7) -- pairs never interact."""
+    from image_matching_amd import shard
+    d, K, H, W = 128, 1024, 480, 640
+    m = _matching(d, K)
+    n_pairs, world = 512, 8
+    cache = {}
+
+    def images(ids):
+        for i in ids:
+            if i not in cache:
+                cache[i] = util.pair(3000 + i % 64, H, W)        # 64 distinct pairs reused over the 512 slots (host synthesis is slow)
+        return torch.cat([cache[i][0] for i in ids]).cuda(), torch.cat([cache[i][1] for i in ids]).cuda()
+
+    gathered = []
+    for r in range(world):
+        ids = shard.shard_indices(n_pairs, r, world)
+        assert len(ids) == 64
+        i0, i1 = images(ids)
+        gathered.append(shard.pack_records(ids, m.match_batch(i0, i1), pad_to=shard.shard_rows(n_pairs, world)))
+    rec = shard.unpack_records(shard.sort_by_pair_id(torch.cat(gathered)))
+    assert rec["pair_id"].tolist() == list(range(n_pairs))
+    assert bool((rec["counts0"] == K).all()) and bool((rec["counts1"] == K).all())
+    assert int((rec["matches0"] > -1).sum()) > 50 * n_pairs
+    # the same first 64 pairs as ONE contiguous batch (different batch neighbours, different slots)
+    ids = list(range(64))
+    i0, i1 = images(ids)
+    one = shard.unpack_records(shard.pack_records(ids, m.match_batch(i0, i1)))
+    for k in ("keypoints0", "matches0", "matches1", "matching_scores0"):
+        assert torch.equal(one[k], rec[k][:64]), k
+    # slots that hold the same image pair (i and i + 64) carry identical results
+    assert torch.equal(rec["matches0"][:64], rec["matches0"][64:128]) and torch.equal(rec["keypoints1"][:64], rec["keypoints1"][448:])
+
+
 def test_bench_through_the_driver_launch_line_with_rccl():
     """The driver starts N>1 benches as `python -m torch.distributed.run ... bench.py --gpus N`.  On a 1-GPU box the
     same launch line with one rank and IMX_BENCH_FORCE_PG=1 runs every statement of the N>1 control flow over the
