@@ -23,7 +23,7 @@ def _pair_set(k0, k1, m0):
     return {(tuple(k0[i].astype(int)), tuple(k1[j].astype(int))) for i, j in enumerate(m0) if j >= 0}
 
 
-@pytest.mark.parametrize("name", ["c3_pair_s59.npz", "c3_pair_s55.npz"])
+@pytest.mark.parametrize("name", ["c3_pair_s59.npz", "c3_pair_s55.npz", "c5_pair_s19.npz"])
 def test_matching_forward_vs_reference_golden(name):
     g = util.golden(name)
     H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
