@@ -161,12 +161,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
     rr[set][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)goff[1], so, 0));
   };
   auto advance_loader = [&]() {      // kept out of the MFMA stream: a branch there ends the scheduling region
-    if (++lchunk == nchunk) {        // the loader moves on to this workgroup's next item (at most one item ahead of the MFMAs)
+    // a REAL (uniform) branch: if-converted, the item decode below -- three divisions by run-time values, ~60 scalar
+    // instructions -- was executed in every phase
+    if (__builtin_expect(++lchunk == nchunk, 0)) {   // the loader moves on to this workgroup's next item
       lchunk = 0;
       litem += grid;
       const bool live = litem < nitems;
       if (live) nxt = decode(litem);
       loader_item(nxt, live);
+      asm volatile("" ::: "memory");                 // keeps the block a block (no select conversion across it)
     }
   };
   auto store_raw = [&](int buf, int set) {
