@@ -123,6 +123,29 @@ def test_cli_end_to_end_on_synthetic_dataset(tmp_path):
     assert sorted(os.listdir(os.path.join(res_dir, "t", "Transform"))) == ["trans_src_000.png", "trans_src_001.png"]
 
 
+def test_cli_keep_all_keypoints_takes_the_generic_path_and_compacted_gpu_ransac(tmp_path):
+    """--max_keypoints -1 (the reference CLI's default): variable keypoint counts, so Matching.forward runs the generic
+    SuperPoint x2 + SuperGlue sequence (the fused latency path needs a fixed K), and the GPU RANSAC sees only the matched pairs
+    (compacted on the device: its slot limit applies to matches, not keypoints).  The helper returns (None, None)
+    -- host fit -- when there are at most 3 matches."""
+    import os
+    import superpoint_glue_test as cli
+    img_dir, res_dir = str(tmp_path / "data") + "/", str(tmp_path / "out") + "/"
+    res = cli.main(["--img_dir", img_dir, "--Result_dir", res_dir, "--synthetic", "2", "--resize_scale", "0.25",
+                    "--max_keypoints", "-1", "--exper_name", "k"])
+    assert sorted(os.listdir(os.path.join(res_dir, "k", "Transform"))) == ["trans_src_000.png", "trans_src_001.png"]
+    assert all(r[1] > 100 and r[2] > 100 and r[3] > 3 and r[5] is not None for r in res), [r[:5] for r in res]
+    # the shift of pair i is (8, 16) * (i + 1) px at the network's resolution: the fitted translation must recover it
+    for i, r in enumerate(res):
+        M = r[5]
+        assert abs(M[0, 0] - 1) < 0.05 and abs(M[1, 1] - 1) < 0.05, M
+    m = _matching(128, 64)
+    eng = m._shared.get_engine([0, 1])
+    pred = {"matches0": torch.full((1, 64), -1, dtype=torch.int64, device="cuda"), "keypoints0": [torch.zeros(64, 2, device="cuda")],
+            "keypoints1": [torch.zeros(64, 2, device="cuda")]}
+    assert cli.gpu_affine_partial(eng, pred, 7) == (None, None)
+
+
 def test_official_cli_end_to_end_on_synthetic_dataset(tmp_path):
     """superpoint_glue_official_test.py:53-137: official (no-BN, d=256) SuperPoint + SuperGlue through the same loop."""
     import os
