@@ -227,3 +227,57 @@ def test_unselected_seed_sweep_end_to_end(name):
     print(f"[sweep e2e] {name}: keypoint sets differ on {kp_diff_images} of {2 * len(g['seeds'])} images (top-k boundary ties); "
           f"{n_diff} differing rows over {n_pairs_ref} reference matches on the comparable pairs; unexplained {len(unexplained)}")
     assert not unexplained, f"end-to-end matches differ where the reference's margin exceeds {tau}: {unexplained[:8]}"
+
+
+# ------------------------------------------------------------------------------------------ ragged / batched fuzz
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_superglue_random_shapes_batches_and_counts_vs_oracle(seed):
+    """Random batch sizes (1-3), keypoint capacities (1-420) and per-pair device-side counts, d = 128: the masked paths of every
+    SuperGlue kernel form (key-split and throughput attention, small-M and weights-stationary GEMM, Sinkhorn slabs, match
+    extraction).  Per pair, against the oracle run on the truncated inputs: the score matrix (GNN + final projection), the
+    transport matrix computed from the library's own scores, and the matches extracted from the library's own Z; entries past
+    a pair's counts must be -1 / 0."""
+    from oracle import superglue_ref
+    rng = np.random.RandomState(1234 + seed)
+    d = 128
+    B = int(rng.randint(1, 4))
+    N0, N1 = int(rng.randint(1, 421)), int(rng.randint(1, 421))
+    if seed % 3 == 0:
+        N0, N1 = max(N0, 260), max(N1, 300)          # large enough for the key-split attention form at B <= 3
+    n0 = rng.randint(1, N0 + 1, size=B).astype(np.int32)
+    n1 = rng.randint(1, N1 + 1, size=B).astype(np.int32)
+    if seed % 2 == 0:
+        n0[0], n1[-1] = N0, N1                        # at least one full side
+    g = torch.Generator().manual_seed(99 + seed)
+    t = {"keypoints0": torch.rand(B, N0, 2, generator=g) * torch.tensor([639.0, 479.0]), "keypoints1": torch.rand(B, N1, 2, generator=g) * torch.tensor([639.0, 479.0]),
+         "scores0": torch.rand(B, N0, generator=g), "scores1": torch.rand(B, N1, generator=g),
+         "descriptors0": torch.nn.functional.normalize(torch.randn(B, d, N0, generator=g), dim=1),
+         "descriptors1": torch.nn.functional.normalize(torch.randn(B, d, N1, generator=g), dim=1)}
+    eng, L = _engine(d)
+    sd = util.sg_sd(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, sd)
+    eng.set_debug(True)
+    c0, c1 = torch.from_numpy(n0).cuda(), torch.from_numpy(n1).cuda()
+    m0, m1, ms0, ms1 = _run(eng, {k: v.cuda() for k, v in t.items()}, (1, 1, 480, 640), c0, c1)
+    S, U, V = eng.fetch("scores_in"), eng.fetch("u"), eng.fetch("v")
+    cfg = util.sg_config(d)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    for b in range(B):
+        a, c = int(n0[b]), int(n1[b])
+        data = {"keypoints0": t["keypoints0"][b:b + 1, :a], "keypoints1": t["keypoints1"][b:b + 1, :c],
+                "scores0": t["scores0"][b:b + 1, :a], "scores1": t["scores1"][b:b + 1, :c],
+                "descriptors0": t["descriptors0"][b:b + 1, :, :a], "descriptors1": t["descriptors1"][b:b + 1, :, :c],
+                "image_shape0": (1, 1, 480, 640), "image_shape1": (1, 1, 480, 640)}
+        ref = superglue_ref.superglue_forward(data, sd, cfg, return_dense=True)["dense"]
+        d64 = {k: (v.double() if torch.is_tensor(v) else v) for k, v in data.items()}
+        f64 = superglue_ref.superglue_forward(d64, sd64, cfg, return_dense=True)["dense"]["scores_in"][0]
+        Sb = S[b, :a, :c]
+        # random descriptors drive the GNN to |scores| of several hundred: judged against the float64 evaluation, like the
+        # fixtures (a masking bug shows up as O(1..100) errors, far outside 4x the reference's own fp32 distance)
+        util.assert_fp64_anchored(Sb, ref["scores_in"][0], f64, f"pair {b} ({a}x{c} of {N0}x{N1}, B={B}) scores_in", c=4.0, c_max=6.0)
+        Z = util.transport_Z(Sb, U[b], V[b], a, c, float(sd["bin_score"]))
+        Zr = superglue_ref.log_optimal_transport(torch.from_numpy(Sb.copy())[None], sd["bin_score"], iters=cfg["sinkhorn_iterations"])[0].numpy()
+        assert np.abs(Z - Zr).max() < 2e-3 * max(1.0, np.abs(Zr).max() / 50), f"pair {b}: Z differs from the oracle's on the same scores"
+        i0, i1, r0, r1 = superglue_ref.extract_matches(torch.from_numpy(Z)[None], cfg["match_threshold"])
+        assert np.array_equal(m0[b, :a], i0[0].numpy()) and np.array_equal(m1[b, :c], i1[0].numpy()), f"pair {b}: matches differ on the library's own Z"
+        assert (m0[b, a:] == -1).all() and (m1[b, c:] == -1).all() and (ms0[b, a:] == 0).all() and (ms1[b, c:] == 0).all()
