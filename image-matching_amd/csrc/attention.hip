@@ -515,6 +515,10 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     else return hipErrorInvalidValue;
     return hipGetLastError();
   }
+  // fp32 products on the bf16 matrix pipe as six bf16 term products (attention_x3.hip); IMX_MFMA=f32 or an explicit IMX_ATTN
+  // variant keeps the fp32-MFMA kernels
+  const char* mf = getenv("IMX_MFMA");
+  if (!env && !(mf && mf[0] == 'f') && attention_x3_supported(a)) return launch_attention_x3(a, s);
   if (hd == 32) {
     if (mode == 1) hipLaunchKernelGGL((attention_kernel<32, false>), grid, dim3(256), 0, s, a, scale);
     else if (mode == 4) hipLaunchKernelGGL((attention_kernel<32, true, 64>), grid, dim3(256), 0, s, a, scale);

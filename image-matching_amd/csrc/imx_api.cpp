@@ -42,6 +42,7 @@ struct ConvW {
 };
 struct GemmW {
   float* w = nullptr;
+  float* wx3 = nullptr;   // the same weights as three bf16 terms per value in MFMA fragment order (split_bf16x3; gemm_x3.hip)
   float* b = nullptr;
   int K = 0, N = 0, Npad = 0;
 };
@@ -327,14 +328,50 @@ void build_gemm_host(const std::map<std::string, HostTensor>& raw, const std::st
   }
 }
 
+// x = h + m + l with three bf16 terms (round-to-nearest-even residuals; exact for every finite fp32 whose last term does not
+// underflow): W[k][n] -> planes [3][Npad][K], k contiguous, packed two bf16 per float slot (bit patterns only)
+uint16_t bf16_rne(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+float bf16_to_f32(uint16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float x;
+  memcpy(&x, &u, 4);
+  return x;
+}
+std::vector<float> split_bf16x3(const std::vector<float>& w, int K, int Npad) {
+  // fragment order of v_mfma_f32_32x32x16_bf16's B operand: [column block of 32][16-k step][plane][lane = (col & 31) + 32 kb][8]
+  // holds W[16 st + 8 kb + j][32 nb + (col & 31)], j = 0..7
+  const int nst = K / 16;
+  std::vector<uint16_t> pl((size_t)3 * Npad * K);
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < Npad; ++n) {
+      const float x = w[(size_t)k * Npad + n];
+      uint16_t t[3];
+      t[0] = bf16_rne(x);
+      const float r1 = x - bf16_to_f32(t[0]);
+      t[1] = bf16_rne(r1);
+      t[2] = bf16_rne(r1 - bf16_to_f32(t[1]));
+      const int nb = n >> 5, st = k >> 4, lane = (n & 31) + 32 * ((k >> 3) & 1), j = k & 7;
+      for (int q = 0; q < 3; ++q) pl[((((size_t)nb * nst + st) * 3 + q) * 64 + lane) * 8 + j] = t[q];
+    }
+  std::vector<float> out((pl.size() + 1) / 2);
+  memcpy(out.data(), pl.data(), pl.size() * sizeof(uint16_t));
+  return out;
+}
+
 int upload_gemm(imx_handle_t h, GemmW& out, const std::vector<float>& w, const std::vector<float>& b, int K, int N, int Npad,
                 const char* what) {
   out.w = upload(h, w);
+  out.wx3 = upload(h, split_bf16x3(w, K, Npad));
   out.b = upload(h, b);
   out.K = K;
   out.N = N;
   out.Npad = Npad;
-  return (out.w && out.b) ? 0 : fail(h, "weight upload failed (%s)", what);
+  return (out.w && out.wx3 && out.b) ? 0 : fail(h, "weight upload failed (%s)", what);
 }
 
 int make_gemm(imx_handle_t h, GemmW& out, const std::map<std::string, HostTensor>& raw, const std::string& conv,
@@ -498,7 +535,10 @@ int gemm(imx_handle_t h, hipStream_t s, const char* name, const GemmW& W, const 
   // small row counts (one or two pairs): the latency form.  IMX_GEMM_SMALL=0 never, =1 whenever the shape allows.
   const char* gs = getenv("IMX_GEMM_SMALL");
   const bool small = gemm_small_supported(g) && !(ge && ge[0] == 't') && (gs ? atoi(gs) != 0 : M <= 4096);
-  RUN(name, small ? launch_gemm_small(g, s) : ws ? launch_gemm_ws(g, s) : launch_gemm(g, s));
+  // fp32 products on the bf16 matrix pipe as six bf16 term products (gemm_x3.hip); IMX_MFMA=f32 keeps the fp32-MFMA forms
+  const char* mf = getenv("IMX_MFMA");
+  const bool x3 = !small && W.wx3 && gemm_x3_supported(g) && !(mf && mf[0] == 'f') && !(ge && ge[0] == 't');
+  RUN(name, small ? launch_gemm_small(g, s) : x3 ? launch_gemm_x3(g, W.wx3, s) : ws ? launch_gemm_ws(g, s) : launch_gemm(g, s));
   return 0;
 }
 

@@ -51,6 +51,10 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 // float4-aligned leading dimensions
 bool gemm_ws_supported(const GemmArgs& a);
 hipError_t launch_gemm_ws(const GemmArgs& a, hipStream_t s);
+// fp32 products as six bf16 term products on the bf16 matrix pipe (gemm_x3.hip): wx3 = the weights as three bf16 terms per value in
+// B-fragment order [Npad/32][K/16][3][64][8]; (K0, K1) % 32 == 0, Npad % 64 == 0, float4-aligned leading dimensions
+bool gemm_x3_supported(const GemmArgs& a);
+hipError_t launch_gemm_x3(const GemmArgs& a, const void* wx3, hipStream_t s);
 // latency form for small row counts (gemm_small.hip): 32 x 32 output tiles, whole-K panels staged in LDS; K % 64 == 0, K <= 512
 bool gemm_small_supported(const GemmArgs& a);
 hipError_t launch_gemm_small(const GemmArgs& a, hipStream_t s);
@@ -125,6 +129,9 @@ struct AttnArgs {
   int cross;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+// both products as six bf16 term products on the bf16 matrix pipe (attention_x3.hip): head dim 32 or 64
+bool attention_x3_supported(const AttnArgs& a);
+hipError_t launch_attention_x3(const AttnArgs& a, hipStream_t s);
 
 // log-domain Sinkhorn with implicit dustbins (superglue_test.py:141-170).
 struct SinkhornArgs {
