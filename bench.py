@@ -47,6 +47,7 @@ WORKLOADS = {
     "c2": dict(H=480, W=640, d=128, K=1024, name="C2 SuperPoint-only 640x480 d=128 NMS + top-1024 keypoints"),
 }
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+PEAK_MFMA_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA dense peak (no sparsity)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -367,7 +368,11 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["name"], "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B,
                    "parallelism": f"pair-sharded x{world}" + (" + RCCL gather of match records to rank 0" if world > 1 else ""),
-                   "weights": "synthetic, BN-calibrated (synth.py seeds 123/456)", "matches_per_pair": round(n_matches / B, 1)},
+                   "weights": "synthetic, BN-calibrated (synth.py seeds 123/456)", "matches_per_pair": round(n_matches / B, 1),
+                   "arithmetic": "fp32 in, fp32 accumulate, fp32 out everywhere; convolutions and the q|k|v projection on the fp32 MFMA, "
+                                 "attention (head dim 32) and the K = 256 linear layers carry each fp32 product as six bf16 term products "
+                                 "on the bf16 MFMA (x = h + m + l exactly; error vs float64 below the fp32 MFMA's: "
+                                 "profiles/r02_mfma_bf16x3.txt; IMX_MFMA=f32 switches it off)"},
     }
 
     # ---- roofline: second pass of the same K steps with per-launch HIP events on the launch stream
@@ -399,9 +404,18 @@ def main():
         bound, units = work[name]
         avg_s = ms / launches * 1e-3
         lib_build = matching._shared.engine.lib.imx_version().decode()
+        # Kernels that carry their fp32 products as six bf16 term products on the bf16 matrix pipe (gemm_x3.hip, attention_x3.hip;
+        # the dispatch rule of csrc/imx_api.cpp gemm() and csrc/attention.hip launch_attention, mirrored here): they EXECUTE six
+        # bf16 FLOPs per fp32 FLOP and are bounded by the bf16 MFMA peak.
+        f32_only = os.environ.get("IMX_MFMA", "")[:1] == "f"
+        x3 = set() if f32_only else {"gnn_mlp1", "gnn_mlp2", "convPb", "convDb"}
+        if not f32_only and d // 4 == 32 and not os.environ.get("IMX_ATTN") and (K + 127) // 128 * 4 * 2 * B > 256:
+            x3.add("attention")
+        pipe_peak = lambda k: PEAK_MFMA_BF16_TFLOPS if k in x3 else PEAK_MFMA_F32_TFLOPS
+        pipe_flops = lambda k: exe[k] * (6.0 if k in x3 else 1.0)
         if bound == "mfma":
-            algorithmic, peak, unit = units / avg_s / 1e12, PEAK_MFMA_F32_TFLOPS, "TFLOP/s"
-            achieved = exe[name] / avg_s / 1e12          # what the matrix cores execute: the rate the MFMA roofline bounds
+            algorithmic, peak, unit = units / avg_s / 1e12, pipe_peak(name), "TFLOP/s"
+            achieved = pipe_flops(name) / avg_s / 1e12   # what the matrix cores execute: the rate the MFMA roofline bounds
         else:
             algorithmic, peak, unit = units / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
             achieved = algorithmic
@@ -420,7 +434,9 @@ def main():
                             "avg_launch_ms": round(ms / launches, 4), "share_of_gpu_time": round(ms / tot_ms, 4), "build": lib_build}
         if traffic_note:
             line["roofline"]["traffic_note"] = traffic_note
-        if abs(algorithmic - achieved) > 1e-9:
+        if bound == "mfma":
+            line["roofline"]["pipe"] = "bf16 MFMA, six bf16 term products per fp32 product" if name in x3 else "fp32 MFMA"
+        if abs(algorithmic - achieved) > 1e-9 and name not in x3:
             line["roofline"]["algorithmic"] = {
                 "rate": round(algorithmic, 3), "ratio_to_peak": round(algorithmic / peak, 4),
                 "note": "reference direct-form FLOPs / launch time; the kernel executes fewer multiplies (Winograd F(2x4,3x3)), "
@@ -430,13 +446,20 @@ def main():
         step_s = dt / args.steps
         exe_step = sum(u * per_step.get(k, 0.0) for k, u in exe.items())
         alg_step = sum(u * per_step.get(k, 0.0) for k, (bd, u) in work.items() if bd == "mfma")
-        line["roofline"]["executed_pair_frac"] = round(exe_step / step_s / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)
+        # time the matrix pipes would need at their dense peaks (fp32 MFMA 157.3, bf16 MFMA 2500 TFLOP/s) / measured step time
+        at_peak_s = sum(pipe_flops(k) * per_step.get(k, 0.0) / (pipe_peak(k) * 1e12) for k in exe)
+        line["roofline"]["executed_pair_frac"] = round(at_peak_s / step_s, 4)
+        line["roofline"]["fp32_equivalent_pair_tflops"] = round(exe_step / step_s / 1e12, 2)
+        line["roofline"]["bf16x3_kernels"] = sorted(x3)
         line["roofline"]["algorithmic_pair_ratio"] = round(alg_step / step_s / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)
         kern = {}
         for r in rows:
             k = {"launches": r[1], "ms_per_step": round(r[2] / args.steps, 4)}
             if r[0] in exe:
-                k["executed_frac"] = round(exe[r[0]] / (r[2] / r[1] * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)
+                k["executed_frac"] = round(pipe_flops(r[0]) / (r[2] / r[1] * 1e-3) / 1e12 / pipe_peak(r[0]), 4)
+                if r[0] in x3:
+                    k["pipe"] = "bf16x3"
+                    k["fp32_equivalent_tflops"] = round(exe[r[0]] / (r[2] / r[1] * 1e-3) / 1e12, 2)
             elif r[0] in work:
                 k["hbm_frac"] = round(work[r[0]][1] / (r[2] / r[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
             kern[r[0]] = k

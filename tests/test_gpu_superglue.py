@@ -177,6 +177,20 @@ def test_attention_key_split_and_throughput_forms_agree(monkeypatch):
         test_full_size_matches_bit_exact_vs_reference_golden(name)
 
 
+@pytest.mark.parametrize("mfma", ["f32", "x3"])
+def test_throughput_forms_on_both_matrix_pipes(mfma, monkeypatch):
+    """The throughput forms run their fp32 products either on the fp32 MFMA (IMX_MFMA=f32) or as six bf16 term products on the
+    bf16 MFMA (attention_x3, gemm_x3; IMX_MFMA=x3 also sends the K = 128 products there, which by default stay
+    weights-stationary).  Both must reproduce the reference's matches on the full-size fixtures and pass the float64-anchored
+    checks on scores_in and Z -- the split is exact, so the bf16 pipe is held to the same bar as the fp32 one."""
+    monkeypatch.setenv("IMX_MFMA", mfma)
+    monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
+    monkeypatch.setenv("IMX_GEMM_SMALL", "0")
+    for name in ("c3_pair_s59.npz", "c3_pair_s55.npz"):
+        test_full_size_matches_bit_exact_vs_reference_golden(name)
+    test_small_dense_and_matches_vs_reference_golden()
+
+
 @pytest.mark.parametrize("mode", ["1", "4"])
 def test_every_attention_variant_matches_bit_exact(mode, monkeypatch):
     """IMX_ATTN selects the attention kernel form (1: one K/V tile in flight, 3 = default: two tiles in flight, 4: 64-key
