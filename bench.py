@@ -408,8 +408,8 @@ def main():
         # the dispatch rule of csrc/imx_api.cpp gemm() and csrc/attention.hip launch_attention, mirrored here): they EXECUTE six
         # bf16 FLOPs per fp32 FLOP and are bounded by the bf16 MFMA peak.
         f32_only = os.environ.get("IMX_MFMA", "")[:1] == "f"
-        x3 = set() if f32_only else {"gnn_mlp1", "gnn_mlp2", "convPb", "convDb"}
-        if not f32_only and d // 4 == 32 and not os.environ.get("IMX_ATTN") and (K + 127) // 128 * 4 * 2 * B > 256:
+        x3 = set() if f32_only else {"convPb", "convDb", "qkv_proj", "gnn_mlp1", "gnn_mlp2", "final_proj", "kenc"}   # M > 4096 rows
+        if not f32_only and d // 4 in (32, 64) and not os.environ.get("IMX_ATTN") and (K + 127) // 128 * 4 * 2 * B > 256:
             x3.add("attention")
         pipe_peak = lambda k: PEAK_MFMA_BF16_TFLOPS if k in x3 else PEAK_MFMA_F32_TFLOPS
         pipe_flops = lambda k: exe[k] * (6.0 if k in x3 else 1.0)

@@ -484,11 +484,12 @@ int finalize_superglue(imx_handle_t h) {
         }
       }
       L.qkv.w = upload(h, w);
+      L.qkv.wx3 = upload(h, split_bf16x3(w, d, N));
       L.qkv.b = upload(h, b);
       L.qkv.K = d;
       L.qkv.N = N;
       L.qkv.Npad = N;
-      if (!L.qkv.w || !L.qkv.b) return fail(h, "weight upload failed (%s qkv)", p.c_str());
+      if (!L.qkv.w || !L.qkv.wx3 || !L.qkv.b) return fail(h, "weight upload failed (%s qkv)", p.c_str());
     }
     // attn.merge is linear and feeds only mlp.0's second input half (superglue_test.py:107,119):
     //   mlp.0([x ; Wm a + bm]) = W1x x + (W1m Wm) a + (W1m bm + b1)
@@ -537,12 +538,9 @@ int gemm(imx_handle_t h, hipStream_t s, const char* name, const GemmW& W, const 
   const bool small = gemm_small_supported(g) && !(ge && ge[0] == 't') && (gs ? atoi(gs) != 0 : M <= 4096);
   // fp32 products on the bf16 matrix pipe as six bf16 term products (gemm_x3.hip); IMX_MFMA=f32 keeps the fp32-MFMA forms
   const char* mf = getenv("IMX_MFMA");
-  // Measured per layer inside the step (C3, 64 pairs / C5): K = 256 products 1.26 vs 1.45 ms (mlp.3), 2.43 vs 2.57 (mlp.0), 0.31 vs
-  // 0.51 (convPb); C5's K = 512 products 15.4 vs 19.2 and 7.8 vs 9.9 ms.  The q|k|v projection (K = d, N = 3 d) is slower on it
-  // (C3: 2.42 vs 2.08 ms, C5: 16.8 vs 14.5): few chunks per tile do not amortise a tile's prologue and epilogue, and its output
-  // is three times its input; it stays weights-stationary.  IMX_MFMA=x3 forces the bf16 form wherever the shape allows.
-  const bool x3 = !small && W.wx3 && gemm_x3_supported(g) && !(mf && mf[0] == 'f') && !(ge && ge[0] == 't') &&
-                  ((W.K >= 256 && W.N <= W.K) || (mf && mf[0] == 'x'));
+  // Measured per layer inside the C3 step (64 pairs, persistent gemm_x3 vs gemm_ws): mlp.0 1.85 vs 2.57 ms, mlp.3 1.11 vs 1.45,
+  // convPb 0.23 vs 0.51, convDb 0.25 vs 0.35, q|k|v 2.06 vs 2.08.
+  const bool x3 = !small && W.wx3 && gemm_x3_supported(g) && !(mf && mf[0] == 'f') && !(ge && ge[0] == 't');
   RUN(name, small ? launch_gemm_small(g, s) : x3 ? launch_gemm_x3(g, W.wx3, s) : ws ? launch_gemm_ws(g, s) : launch_gemm(g, s));
   return 0;
 }

@@ -9,7 +9,6 @@
 #include <cstring>
 #include <vector>
 using namespace imx;
-namespace imx { extern long long* g_x3_trace; }
 static uint16_t bf16_rne(float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 static float bf16_f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; }
 int main() {
@@ -59,18 +58,6 @@ int main() {
           if (sh.relu && ref < 0) ref = 0;
           const double e = out[(size_t)r * N + n] - ref; se += e * e; if (fabs(e) > mx) mx = fabs(e);
         }
-      if (!form && getenv("X3_TRACE")) {
-        long long* dt; hipMalloc(&dt, 256 * 16 * 8); hipMemset(dt, 0, 256 * 16 * 8);
-        g_x3_trace = dt; run(); hipDeviceSynchronize(); g_x3_trace = nullptr;
-        std::vector<long long> t(256 * 16); hipMemcpy(t.data(), dt, t.size() * 8, hipMemcpyDeviceToHost); hipFree(dt);
-        for (int wg : {0, 1, 7, 100, 255}) {
-          printf("   wg %3d: start %lld; deltas:", wg, t[wg * 16] - t[0]);
-          int last = 0;
-          for (int q = 1; q < 14 && t[wg * 16 + q]; ++q) { printf(" %lld", t[wg * 16 + q] - t[wg * 16 + q - 1]); last = q; }
-          printf("  | %lld s_memtime ticks in %lld wall ticks (100 MHz)", t[wg * 16 + last] - t[wg * 16], t[wg * 16 + 15] - t[wg * 16 + 14]);
-          printf("\n");
-        }
-      }
       const double us = ms * 1000 / 20, gf = 2.0 * M * K * N * 1e-9;
       printf("%-18s %-8s %7.1f us  %6.1f TFLOP/s fp32-equivalent  %5.2f TB/s (A once + out)   rms err %.2e max %.2e\n", sh.name, form ? "gemm_ws" : "gemm_x3",
              us, gf / us * 1e-3 * 1e3, ((double)M * K * 4 + (double)M * N * 4 * (sh.res ? 2 : 1)) / us * 1e-6, sqrt(se / (64.0 * N)), mx);
