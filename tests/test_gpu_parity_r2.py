@@ -281,3 +281,23 @@ def test_superglue_random_shapes_batches_and_counts_vs_oracle(seed):
         i0, i1, r0, r1 = superglue_ref.extract_matches(torch.from_numpy(Z)[None], cfg["match_threshold"])
         assert np.array_equal(m0[b, :a], i0[0].numpy()) and np.array_equal(m1[b, :c], i1[0].numpy()), f"pair {b}: matches differ on the library's own Z"
         assert (m0[b, a:] == -1).all() and (m1[b, c:] == -1).all() and (ms0[b, a:] == 0).all() and (ms1[b, c:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------ the bf16-pipe forms on ragged shapes
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 5])
+def test_superglue_random_shapes_on_the_throughput_forms(seed, monkeypatch):
+    """The same fuzz with the throughput forms forced at these small sizes (IMX_ATTN_SPLIT=0, IMX_GEMM_SMALL=0): attention_x3 with
+    partial key tiles, query blocks past the padded row count and per-pair device-side counts; the persistent gemm_x3 with row
+    counts that are not multiples of its 128-row tile and fewer tiles than workgroups."""
+    monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
+    monkeypatch.setenv("IMX_GEMM_SMALL", "0")
+    test_superglue_random_shapes_batches_and_counts_vs_oracle(seed)
+
+
+def test_descriptor_dim_64_on_the_throughput_forms(monkeypatch):
+    """descriptor_dim 64 with the throughput forms forced: gemm_x3's 64-column tiles (N = 64, 192), K = 32 / 64 (one and two
+    chunks per tile), the fp32 attention kernel for head dim 16 beside bf16-pipe linear layers."""
+    monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
+    monkeypatch.setenv("IMX_GEMM_SMALL", "0")
+    test_descriptor_dim_64_superpoint_and_superglue_vs_reference_golden()
+    test_descriptor_dim_64_matching_forward_and_ragged_counts_vs_oracle()
