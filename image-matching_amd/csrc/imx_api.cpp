@@ -797,7 +797,7 @@ extern "C" {
 #ifndef IMX_BUILD_ID
 #define IMX_BUILD_ID "dev"
 #endif
-const char* imx_version(void) { return "imx 0.2 gfx950 hip-7.2 fp32-mfma build " IMX_BUILD_ID; }
+const char* imx_version(void) { return "imx 0.3 gfx950 hip-7.2 fp32 build " IMX_BUILD_ID; }
 
 int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
   return guarded(nullptr, "imx_create", [&]() -> int {

@@ -183,7 +183,7 @@ int imx_timing_report(imx_handle_t h, int index, const char** name_out, int64_t*
                       double* total_ms_out);
 int imx_timing_reset(imx_handle_t h);
 
-/* Library build string, e.g. "imx 0.2 gfx950 hip-7.2 fp32-mfma build 3f2a91c07d1e" (the id is a digest of the library
+/* Library build string, e.g. "imx 0.3 gfx950 hip-7.2 fp32 build 3f2a91c07d1e" (the id is a digest of the library
  * sources: measurements taken on one build are only quoted for that build). */
 const char* imx_version(void);
 
