@@ -606,7 +606,8 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   h->det_Hc = Hc; h->det_Wc = Wc;
   if (dense_only) { h->det_B = 0; return 0; }     // network only (imx_superpoint_dense)
   RUN("softmax_shuffle", launch_softmax_shuffle(semi, 65, smap, B, Hc, Wc, s));
-  RUN("nms", launch_nms(smap, nms, B, H8, W8, c.nms_radius, s));
+  WS(nms_bits, unsigned, "sp.nms_bits", (size_t)2 * B * H8 * ((W8 + 31) / 32) * sizeof(unsigned));
+  RUN("nms", launch_nms(smap, nms, B, H8, W8, c.nms_radius, s, nms_bits));
 
   const int Ksel = c.max_keypoints >= 0 ? (c.max_keypoints > 0 ? c.max_keypoints : 1) : H8 * W8;
   if (c.max_keypoints > 16384) return fail(h, "max_keypoints > 16384 is not supported (got %d)", c.max_keypoints);
@@ -962,7 +963,8 @@ int imx_op_nms(imx_handle_t h, const float* scores_dev, float* out_dev, int B, i
     if (!h) return -1;
     HIP_OK(h, hipSetDevice(h->device));
     hipStream_t s = as_stream(stream);
-    RUN("nms", launch_nms(scores_dev, out_dev, B, H, W, radius, s));
+    WS(nms_bits, unsigned, "op.nms_bits", (size_t)2 * B * H * ((W + 31) / 32) * sizeof(unsigned));
+    RUN("nms", launch_nms(scores_dev, out_dev, B, H, W, radius, s, nms_bits));
     return 0;
   });
 }

@@ -75,7 +75,8 @@ hipError_t launch_softmax_shuffle(const float* semi, int ld, float* scores, int 
 hipError_t launch_dense_export(const float* semi, int ld, const float* dense, int d, float* semi_out, float* desc_out,
                                int B, int Hc, int Wc, int eps_mode, hipStream_t s);
 // simple_nms (3 rounds, radius r<=8) fused; out = where(max_mask, scores, 0)
-hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int radius, hipStream_t s);
+// scratch (optional): 2 x B x H x ceil(W / 32) words -> the staged three-kernel form for radius <= 4 (sp_tail.hip)
+hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int radius, hipStream_t s, unsigned* scratch = nullptr);
 // threshold + border removal + row-major compaction, then top-k (score desc, index asc on ties).
 struct KeypointArgs {
   const float* nms;          // (B,H,W)

@@ -314,6 +314,126 @@ __global__ __launch_bounds__(1024, 8) void nms_fast_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Staged form (radius 1..4, needs 2 x B x H x ceil(W/32) words of scratch): simple_nms as THREE kernels, one per round.
+// The fused kernel above pays for its five dependent pools with a 5R halo (3.7x the tile area at R = 4) and ~20 block-wide
+// barriers of 16 waves; here a round only needs the halo of its own pools:
+//   stage 0   max_mask = scores == max_pool(scores)                                     halo R, mask written as BIT rows
+//   stage 1/2 supp = dilate(max_mask) (bit rows: shifts + an OR over 2R+1 rows), supp_scores = supp ? -1 : scores,
+//             max_mask |= ~supp & (supp_scores == max_pool(supp_scores))                halo 2R for the bits, R for the scores
+// stage 2 writes where(max_mask, scores, 0) instead of the bits.  Same compare-only arithmetic: bit-exact.
+template <int R, int STAGE>
+__global__ __launch_bounds__(256) void nms_stage_kernel(const float* __restrict__ scores, const unsigned* __restrict__ min_,
+                                                         unsigned* __restrict__ mout, float* __restrict__ out, int H, int W, int WW) {
+  constexpr int TY = 32, TX = 64, SY = TY + 2 * R, SX = TX + 2 * R, PITCH = SX | 1, NV = 8 + 2 * R;
+  constexpr int MR = SY + 2 * R;                     // bit rows of the previous mask (halo 2R)
+  __shared__ float P[SY * PITCH];                    // scores / supp_scores on the region
+  __shared__ float Hb[SY * (TX + 1)];                // horizontal pass
+  __shared__ unsigned Mb[MR * 4], Hd[MR * 4], Sp[SY * 4];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, y0 = blockIdx.y * TY, x0 = blockIdx.x * TX;
+  const float* img = scores + (size_t)b * H * W;
+  const float NEG = -INFINITY;
+
+  if constexpr (STAGE > 0) {
+    // previous mask: bit rows y0 - 2R .. , the 128-bit window of columns x0 - 32 .. x0 + 95 (x0 is a multiple of 64)
+    const unsigned* mb = min_ + (size_t)b * H * WW;
+    for (int e = tid; e < MR * 4; e += 256) {
+      const int gy = y0 - 2 * R + e / 4, wi = (x0 >> 5) - 1 + (e & 3);
+      Mb[e] = (gy >= 0 && gy < H && wi >= 0 && wi < WW) ? mb[(size_t)gy * WW + wi] : 0u;
+    }
+    __syncthreads();
+    for (int e = tid; e < MR * 4; e += 256) {        // horizontal dilation inside the window
+      const int wi = e & 3;
+      const unsigned w = Mb[e], wl = wi > 0 ? Mb[e - 1] : 0u, wr = wi < 3 ? Mb[e + 1] : 0u;
+      unsigned d = w;
+#pragma unroll
+      for (int sft = 1; sft <= R; ++sft) d |= (w << sft) | (wl >> (32 - sft)) | (w >> sft) | (wr << (32 - sft));
+      Hd[e] = d;
+    }
+    __syncthreads();
+    for (int e = tid; e < SY * 4; e += 256) {        // vertical: region row ry <-> mask rows ry .. ry + 2R
+      unsigned d = 0u;
+#pragma unroll
+      for (int k = 0; k <= 2 * R; ++k) d |= Hd[e + 4 * k];
+      Sp[e] = d;
+    }
+    __syncthreads();
+  }
+  // region of (supp_)scores: image rows y0 - R .., columns x0 - R ..; outside the image -inf (max_pool padding)
+  for (int e = tid; e < SY * SX; e += 256) {
+    const int ry = e / SX, rx = e - ry * SX, gy = y0 - R + ry, gx = x0 - R + rx;
+    float v = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : NEG;
+    if constexpr (STAGE > 0) {
+      const int bit = rx + 32 - R;                   // column x0 - R + rx in the window that starts at x0 - 32
+      if (v > NEG && ((Sp[ry * 4 + (bit >> 5)] >> (bit & 31)) & 1u)) v = -1.f;
+    }
+    P[ry * PITCH + rx] = v;
+  }
+  __syncthreads();
+  // separable max-pool through 8-output register strips: rows SY x columns TX, then rows TY x columns TX
+  for (int sidx = tid; sidx < SY * (TX / 8); sidx += 256) {
+    const int row = sidx % SY, st = sidx / SY;
+    float v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = P[row * PITCH + 8 * st + k];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      float m = v[o];
+#pragma unroll
+      for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, v[o + k]);
+      Hb[row * (TX + 1) + 8 * st + o] = m;
+    }
+  }
+  __syncthreads();
+  {
+    const int tx = tid & 63, st = tid >> 6;          // a wave = 64 consecutive columns of rows 8 st .. 8 st + 7
+    float v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = Hb[(8 * st + k) * (TX + 1) + tx];
+    const int gx = x0 + tx;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      float m = v[o];
+#pragma unroll
+      for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, v[o + k]);
+      const int ty = 8 * st + o, gy = y0 + ty;
+      const float x = P[(ty + R) * PITCH + tx + R];  // this pixel's own (supp_)score
+      const bool in = gy < H && gx < W;
+      bool mx;
+      if constexpr (STAGE == 0) {
+        mx = in && x == m;                                                                // (:16)
+      } else {
+        const int bit = tx + 32;
+        const bool was = (Mb[(ty + 2 * R) * 4 + (bit >> 5)] >> (bit & 31)) & 1u;
+        mx = in && (was || (x >= 0.f && x == m));                                         // (:19-21)
+      }
+      if constexpr (STAGE < 2) {
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(mx);
+        if (tx == 0 && gy < H) {
+          unsigned* mo = mout + ((size_t)b * H + gy) * WW + (x0 >> 5);
+          mo[0] = (unsigned)bal;
+          if ((x0 >> 5) + 1 < WW) mo[1] = (unsigned)(bal >> 32);
+        }
+      } else {
+        if (in) out[((size_t)b * H + gy) * W + gx] = mx ? img[(size_t)gy * W + gx] : 0.f;   // (:22)
+      }
+    }
+  }
+}
+
+template <int R>
+hipError_t launch_nms_staged(const float* scores, float* out, unsigned* scratch, int B, int H, int W, hipStream_t s) {
+  const int WW = (W + 31) / 32;
+  unsigned* m0 = scratch;
+  unsigned* m1 = scratch + (size_t)B * H * WW;
+  dim3 grid((W + 63) / 64, (H + 31) / 32, B);
+  hipLaunchKernelGGL((nms_stage_kernel<R, 0>), grid, dim3(256), 0, s, scores, (const unsigned*)nullptr, m0, (float*)nullptr, H, W, WW);
+  hipLaunchKernelGGL((nms_stage_kernel<R, 1>), grid, dim3(256), 0, s, scores, (const unsigned*)m0, m1, (float*)nullptr, H, W, WW);
+  hipLaunchKernelGGL((nms_stage_kernel<R, 2>), grid, dim3(256), 0, s, scores, (const unsigned*)m1, (unsigned*)nullptr, out, H, W, WW);
+  return hipGetLastError();
+}
+
 template <int R>
 hipError_t launch_nms_fast(const float* scores, float* out, int B, int H, int W, hipStream_t s) {
   constexpr int TY = 32, TX = 64, SY = ((TY + 10 * R + 7) / 8) * 8, SX = ((TX + 10 * R + 7) / 8) * 8;
@@ -610,9 +730,19 @@ hipError_t launch_softmax_shuffle(const float* semi, int ld, float* scores, int 
   return hipGetLastError();
 }
 
-hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int radius, hipStream_t s) {
+hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int radius, hipStream_t s, unsigned* scratch) {
   if (radius < 0 || radius > 8) return hipErrorInvalidValue;
   if (radius == 0) return hipMemcpyAsync(out, scores, (size_t)B * H * W * sizeof(float), hipMemcpyDeviceToDevice, s);
+  // the staged (three-kernel) form when the caller provides scratch; IMX_NMS=fused keeps the single-kernel form
+  const char* ne = getenv("IMX_NMS");
+  if (scratch && radius <= 4 && !(ne && ne[0] == 'f')) {
+    switch (radius) {
+      case 1: return launch_nms_staged<1>(scores, out, scratch, B, H, W, s);
+      case 2: return launch_nms_staged<2>(scores, out, scratch, B, H, W, s);
+      case 3: return launch_nms_staged<3>(scores, out, scratch, B, H, W, s);
+      default: return launch_nms_staged<4>(scores, out, scratch, B, H, W, s);
+    }
+  }
   auto lds_bytes = [&](int T) {
     size_t side = T + 10 * radius, n = side * side;
     return n * 4 * 3 + n * 2 + 4 + n * 4;   // S, X, tmp, M, Q, pad, P

@@ -190,14 +190,26 @@ def test_direct_conv_fallback_vs_reference_golden(monkeypatch):
         util.assert_close(_nchw(eng.fetch("semi")), g["semi"], "semi (direct)")
 
 
+@pytest.mark.parametrize("form", ["staged", "fused"])
 @pytest.mark.parametrize("radius", [1, 2, 3, 4, 6])
-def test_nms_every_radius_bit_exact_vs_oracle(radius):
-    """simple_nms is compare-only, so the kernels (register-strip form for radius <= 4, generic form above) must reproduce
-    the oracle bit for bit on the reference's own score map, for every --nms_radius, on partial tiles too."""
+def test_nms_every_radius_bit_exact_vs_oracle(radius, form, monkeypatch):
+    """simple_nms is compare-only, so the kernels (radius <= 4: the staged three-kernel form with bit-row masks, default, and the
+    fused register-strip form, IMX_NMS=fused; generic form above) must reproduce the oracle bit for bit on the reference's own
+    score map, for every --nms_radius, on partial tiles too -- and on a batch of wider maps whose width is not a multiple of the
+    64-column tile or of the 32-bit mask words."""
     from oracle import superpoint_ref
+    if form == "fused":
+        monkeypatch.setenv("IMX_NMS", "fused")
     g = util.golden("sp_ragged.npz")
     eng, L = _engine(128, -1)
     sm = torch.from_numpy(g["score_map"])
     out = eng.op_nms(sm, radius).cpu().numpy()
     ref = superpoint_ref.simple_nms(sm, radius).numpy()
     assert np.array_equal(out, ref), f"radius {radius}: {(out != ref).sum()} pixels differ"
+    rng = np.random.RandomState(radius)
+    big = np.round(rng.rand(3, 77, 203).astype(np.float32) * 8) / 8          # many exact ties
+    big[rng.rand(*big.shape) < 0.5] = 0.0
+    t = torch.from_numpy(big)
+    out = eng.op_nms(t, radius).cpu().numpy()
+    ref = superpoint_ref.simple_nms(t, radius).numpy()
+    assert np.array_equal(out, ref), f"radius {radius} (3 x 77 x 203, ties): {(out != ref).sum()} pixels differ"
