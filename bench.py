@@ -17,8 +17,16 @@ Rank 0 prints ONE JSON line (contract in the task statement) including
                   matrix cores actually EXECUTE (never above 1); where a kernel executes fewer multiplies than
                   the reference's direct-form count (Winograd F(2x4,3x3): 3x fewer) the algorithmic rate is
                   reported next to it under `algorithmic`.  `executed_pair_frac` is the whole-pair view.
-                  `traffic` comes from rocprofv3 PMC passes (profiles/r02_pmc_traffic.json) and is dropped when
-                  that file was measured on a different library build than the one being timed;
+                  Which matrix pipe a kernel is priced against comes from the LIBRARY (imx_timing_form: the kernel form
+                  that actually ran), not from a copy of its dispatch rule.  `traffic` comes from rocprofv3 PMC passes
+                  (profiles/r03_pmc_traffic.json, taken at this run's 64 pairs per step) and is dropped when that file was
+                  measured on a different library build than the one being timed;
+  "parity_in_run": the first 32 pairs of the timed batch are the UNSELECTED sweep seeds 1000..1031 whose reference outputs
+                  are committed in tests/golden/sweep_c3.npz; after the timed region the keypoints and match indices of the
+                  LAST timed step are compared with them (tests/util.py: sweep_compare_end_to_end -- fixture only, no oracle):
+                  the number the driver times and the parity evidence meet in one process;
+  "c5":           a short leg on the stress configuration (BASELINE configs[4]) with its own parity_in_run;
+  "gather_ms":    the path's one collective (RCCL gather of the step's match records) timed at world 1 as the N>1 baseline;
   "latency_b1_ms":          Matching.forward on ONE pair (BASELINE configs[2]), median of 50 synchronised calls;
   "pcie_inclusive_pairs_s": the same step fed from uint8 frames in pinned host memory (never `value`);
   "cpu_baseline": the oracle (CPU restatement of the reference, torch CPU ops) timed on this
@@ -41,10 +49,11 @@ if ROOT not in sys.path:
 from image_matching_amd import shard, synth                                    # noqa: E402
 from image_matching_amd.superglue.models.matching_test import Matching         # noqa: E402
 
+# seed0: pair i of the job is synth_pair(seed0 + i) -- the first pairs are the unselected sweep seeds of tests/golden/<sweep>
 WORKLOADS = {
-    "c3": dict(H=480, W=640, d=128, K=1024, name="C3 SuperPoint+SuperGlue 640x480 d=128 1024 kpts 30 Sinkhorn iters"),
-    "c5": dict(H=960, W=1280, d=256, K=2048, name="C5 SuperPoint+SuperGlue 1280x960 d=256 2048 kpts 100 Sinkhorn iters"),
-    "c2": dict(H=480, W=640, d=128, K=1024, name="C2 SuperPoint-only 640x480 d=128 NMS + top-1024 keypoints"),
+    "c3": dict(H=480, W=640, d=128, K=1024, seed0=1000, sweep="sweep_c3.npz", name="C3 SuperPoint+SuperGlue 640x480 d=128 1024 kpts 30 Sinkhorn iters"),
+    "c5": dict(H=960, W=1280, d=256, K=2048, seed0=2000, sweep="sweep_c5.npz", name="C5 SuperPoint+SuperGlue 1280x960 d=256 2048 kpts 100 Sinkhorn iters"),
+    "c2": dict(H=480, W=640, d=128, K=1024, seed0=1000, sweep=None, name="C2 SuperPoint-only 640x480 d=128 NMS + top-1024 keypoints"),
 }
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 PEAK_MFMA_BF16_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA dense peak (no sparsity)
@@ -159,11 +168,12 @@ def cpu_baseline_worker(workload, n_pairs):
         print(json.dumps({"threads": torch.get_num_threads(), "times": times}), flush=True)      # last line wins (partial on timeout)
 
 
-def cpu_baseline(workload, budget_s=40.0, n_pairs=3):
+def cpu_baseline(workload, budget_s=60.0, n_pairs=5):
     """The oracle (port of the reference's PyTorch CPU forward) on this host's cores.  More threads are not better for
     this model (128 threads gave 0.32 pairs/s in round 1, slower than 8 threads in the survey container), so the thread
     count is swept and the best is reported.  Each count runs in its own child process (OMP_NUM_THREADS set before torch
-    loads, hard timeout): 1 warm-up pair + the median of up to `n_pairs` pairs; ~`budget_s` seconds in total."""
+    loads, hard timeout): 1 warm-up pair + the median of up to `n_pairs` pairs (>= 5; a count that times out
+    before 5 is reported with the pairs it finished); ~`budget_s` seconds in total."""
     import subprocess
     try:
         avail = len(os.sched_getaffinity(0))       # cores this process may run on (cgroup/affinity aware)
@@ -260,6 +270,188 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def resident_inputs(wl, pair_ids, device):
+    """This rank's pairs of the global batch, resident in HBM: pair i of the job = synth_pair(seed0 + i)."""
+    ims = [synth.synth_pair(wl["seed0"] + pid, wl["H"], wl["W"]) for pid in pair_ids]
+    img0 = torch.from_numpy(np.stack([p[0] for p in ims]))[:, None].to(device)
+    img1 = torch.from_numpy(np.stack([p[1] for p in ims]))[:, None].to(device)
+    return img0, img1
+
+
+def parity_in_run(wl, pair_ids, out):
+    """The outputs of the LAST timed step against the reference's outputs on the unselected sweep seeds (committed fixture; the
+    comparison rule is the GPU tests': keypoint sets may differ only on a top-k boundary tie, a differing match must sit on a
+    reference margin below tau = 2e-3 in Z units).  Pairs whose job index is below the sweep length are checked."""
+    from tests import util                                  # fixture reader + comparison rule (no oracle involved)
+    g = util.golden(wl["sweep"])
+    n = len(g["seeds"])
+    assert int(g["seeds"][0]) == wl["seed0"]
+    k0, k1, m0 = out["keypoints0"].cpu().numpy(), out["keypoints1"].cpu().numpy(), out["matches0"].cpu().numpy()
+    res = [util.sweep_compare_end_to_end(g, pid, k0[b], k1[b], m0[b]) for b, pid in enumerate(pair_ids) if pid < n]
+    rep = {"pairs": len(res), "fixture": "tests/golden/" + wl["sweep"],
+           "keypoint_set_mismatch_images": sum(r["kp_diff_images"] for r in res),
+           "keypoint_set_mismatch_beyond_topk_ties": sum(len(r["kp_bad"]) for r in res),
+           "reference_matches": sum(r["n_ref"] for r in res), "index_mismatches": sum(r["diff"] for r in res),
+           "unexplained": sum(len(r["unexplained"]) for r in res),
+           "rule": "keypoint sets equal unless the top-k boundary gap < 2e-5; a differing match index must lie on a reference margin < 2e-3 (Z units)"}
+    assert rep["unexplained"] == 0 and rep["keypoint_set_mismatch_beyond_topk_ties"] == 0, f"parity_in_run failed: {rep}"
+    return rep
+
+
+PIPES = {"f32": ("fp32 MFMA", PEAK_MFMA_F32_TFLOPS, 1.0),
+         "bf16x3": ("bf16 MFMA, six bf16 term products per fp32 product", PEAK_MFMA_BF16_TFLOPS, 6.0)}
+
+
+def roofline_block(rows, wl, B, steps, dt, lib_build, workload):
+    """rows: Engine.timing_report(forms=True) of `steps` instrumented steps: (name, launches, total_ms, form) with form =
+    '<kernel family>:<pipe>' as the LIBRARY reports it (imx_timing_form)."""
+    H, W, d, K = wl["H"], wl["W"], wl["d"], wl["K"]
+    kenc, iters, _ = synth.SG_CONFIGS[d]
+    work = algorithmic_work(B, H, W, d, K, kenc, iters)
+    exe = executed_work(B, H, W, d, K, kenc, iters)
+    by = {}                                # name -> [launches, ms, {form: ms}]
+    for name, launches, ms, form in rows:
+        e = by.setdefault(name, [0, 0.0, {}])
+        e[0] += launches
+        e[1] += ms
+        e[2][form] = e[2].get(form, 0.0) + ms
+    form_of = {n: max(e[2], key=e[2].get) for n, e in by.items()}          # a name's dominant form (one form per name in practice)
+    pipe_of = {n: (f.split(":")[1] if ":" in f else "") for n, f in form_of.items()}
+    for n, f in form_of.items():           # the direct-form convolution executes the algorithmic FLOPs
+        if f.startswith("conv3x3_direct") and n in exe:
+            exe[n] = work[n][1]
+    pipe_peak = lambda k: PIPES.get(pipe_of.get(k), PIPES["f32"])[1]
+    pipe_flops = lambda k: exe[k] * PIPES.get(pipe_of.get(k), PIPES["f32"])[2]
+    tot_ms = sum(e[1] for e in by.values())
+    name = max(by, key=lambda n: by[n][1])
+    launches, ms = by[name][0], by[name][1]
+    bound, units = work[name]
+    avg_s = ms / launches * 1e-3
+    if bound == "mfma":
+        algorithmic, peak, unit = units / avg_s / 1e12, pipe_peak(name), "TFLOP/s"
+        achieved = pipe_flops(name) / avg_s / 1e12      # what the matrix cores execute: the rate the MFMA roofline bounds
+    else:
+        algorithmic, peak, unit = units / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
+        achieved = algorithmic
+    traffic, traffic_note, pmc = None, None, None   # HBM bytes per launch from rocprofv3 PMC passes (tools/pmc_traffic.py -> profiles/)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        if pmc.get("build") != lib_build:
+            traffic_note = f"dropped: PMC passes were taken on build {pmc.get('build')!r}, this run is {lib_build!r}"
+            pmc = None
+        elif workload != "c3" or pmc["pairs_per_gpu"] != B:
+            traffic_note = f"dropped: PMC passes were taken at {pmc['pairs_per_gpu']} C3 pairs per step, this run is {workload} at {B}"
+            pmc = None
+        elif name in pmc["kernels"]:
+            traffic = pmc["kernels"][name]["traffic_bytes"]
+    except (OSError, ValueError, KeyError):
+        traffic_note = "no PMC traffic file for this round"
+    rf = {"bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic,
+          "kernel": name, "form": form_of[name], "avg_launch_ms": round(ms / launches, 4), "share_of_gpu_time": round(ms / tot_ms, 4), "build": lib_build}
+    if traffic_note:
+        rf["traffic_note"] = traffic_note
+    if bound == "mfma":
+        rf["pipe"] = PIPES.get(pipe_of[name], PIPES["f32"])[0]
+    if abs(algorithmic - achieved) > 1e-9 and pipe_of[name] != "bf16x3":
+        rf["algorithmic"] = {
+            "rate": round(algorithmic, 3), "ratio_to_peak": round(algorithmic / peak, 4),
+            "note": "reference direct-form FLOPs / launch time; the kernel executes fewer multiplies (Winograd F(2x4,3x3)), "
+                    "so this ratio may exceed 1 and is NOT a utilisation"}
+    # whole-pair view: time the matrix pipes would need at their dense peaks (fp32 MFMA 157.3, bf16 MFMA 2500 TFLOP/s) / step time
+    per_step = {n: e[0] / steps for n, e in by.items()}          # launches per step
+    step_s = dt / steps
+    exe_step = sum(u * per_step.get(k, 0.0) for k, u in exe.items())
+    alg_step = sum(u * per_step.get(k, 0.0) for k, (bd, u) in work.items() if bd == "mfma")
+    at_peak_s = sum(pipe_flops(k) * per_step.get(k, 0.0) / (pipe_peak(k) * 1e12) for k in exe)
+    rf["executed_pair_frac"] = round(at_peak_s / step_s, 4)
+    rf["fp32_equivalent_pair_tflops"] = round(exe_step / step_s / 1e12, 2)
+    rf["bf16x3_kernels"] = sorted(k for k, v in pipe_of.items() if v == "bf16x3")
+    rf["algorithmic_pair_ratio"] = round(alg_step / step_s / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)
+    rf["launches_per_step"] = int(round(sum(per_step.values())))
+    kern = {}
+    for n, (launches, ms, forms) in by.items():
+        k = {"launches": launches, "ms_per_step": round(ms / steps, 4)}
+        if form_of[n]:
+            k["form"] = form_of[n] if len(forms) == 1 else sorted(forms)
+        if n in exe:
+            k["executed_frac"] = round(pipe_flops(n) / (ms / launches * 1e-3) / 1e12 / pipe_peak(n), 4)
+            if pipe_of[n] == "bf16x3":
+                k["fp32_equivalent_tflops"] = round(exe[n] / (ms / launches * 1e-3) / 1e12, 2)
+        elif n in work:
+            k["hbm_frac"] = round(work[n][1] / (ms / launches * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+        if pmc and n in pmc["kernels"]:
+            k["traffic_bytes_per_launch"] = pmc["kernels"][n]["traffic_bytes"]
+        kern[n] = k
+    rf["kernels"] = kern
+    return rf
+
+
+def arithmetic_text(rf):
+    x3 = rf.get("bf16x3_kernels", []) if rf else []
+    return ("fp32 in, fp32 accumulate, fp32 out everywhere.  On the fp32 MFMA: the 3x3 convolutions (Winograd F(2x4,3x3)) and score_gemm.  "
+            + (f"On the bf16 MFMA, each fp32 product carried as six bf16 term products (x = h + m + l exactly; error vs float64 below the "
+               f"fp32 MFMA's: profiles/r02_mfma_bf16x3.txt), as reported by the library for this run: {', '.join(x3)}.  " if x3 else "")
+            + "imx_set_option(h, 'mfma', 'f32') keeps every product on the fp32 MFMA (the parity tests hold both to the same bar).  "
+              "|Z_hip - Z_reference| reaches ~1e-3 where the reference's own fp32 result is 2e-4..2.6e-3 from float64 (see parity_in_run, "
+              "profiles/r03_tolerance_report.txt): matching_scores / keypoints / descriptors are within 1e-4, match indices differ only on reference margins below that noise")
+
+
+def c5_leg(device, steps=3, B=8):
+    """BASELINE configs[4] (1280x960, d=256, 2048 kpts, 100 iterations) next to the headline: a short timed leg with its own
+    roofline entry for its dominant kernel and its own parity_in_run (the 8 unselected C5 sweep seeds)."""
+    wl = WORKLOADS["c5"]
+    matching, *_ = build_matching(wl, device)
+    pair_ids = list(range(B))
+    img0, img1 = resident_inputs(wl, pair_ids, device)
+    for _ in range(1):
+        matching.match_batch(img0, img1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = matching.match_batch(img0, img1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng = matching._shared.engine
+    eng.timing_reset()
+    eng.set_timing(True)
+    for _ in range(steps):
+        matching.match_batch(img0, img1)
+    rows = eng.timing_report(forms=True)
+    eng.set_timing(False)
+    eng.timing_reset()
+    rf = roofline_block(rows, wl, B, steps, dt, eng.lib.imx_version().decode(), "c5")
+    top = sorted(rf["kernels"].items(), key=lambda kv: -kv[1]["ms_per_step"])[:6]
+    return {"workload": wl["name"], "pairs_s": round(B * steps / dt, 3), "ms_per_step": round(1e3 * dt / steps, 3), "pairs_per_step": B, "steps": steps,
+            "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "form", "avg_launch_ms", "executed_pair_frac")},
+            "top_kernels_ms_per_step": {k: v["ms_per_step"] for k, v in top},
+            "parity_in_run": parity_in_run(wl, pair_ids, out)}
+
+
+def gather_baseline(rec, n=20):
+    """The path's one collective at world 1: a real RCCL gather of the step's record buffer to rank 0 (process group of one rank),
+    so that the N>1 lines have a baseline for what the collective itself costs.  None (+ reason) if RCCL cannot initialise."""
+    own = not dist.is_initialized()
+    try:
+        if own:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29519")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=rec.device)
+        for _ in range(3):
+            shard.gather_records(rec, force=True, check=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            shard.gather_records(rec, force=True, check=False)
+        torch.cuda.synchronize()
+        return round(1e3 * (time.perf_counter() - t0) / n, 4), f"world 1, {rec.numel() * 4} bytes per rank, mean of {n}"
+    except Exception as e:            # noqa: BLE001 -- reported, never fatal: the headline does not depend on it
+        return None, f"RCCL gather at world 1 unavailable: {type(e).__name__}: {e}"
+    finally:
+        if own and dist.is_initialized():
+            dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,7 +461,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-pass", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip latency_b1_ms / pcie_inclusive_pairs_s")
+    ap.add_argument("--no-extras", action="store_true", help="skip latency_b1_ms / pcie_inclusive_pairs_s / c5 / gather_ms")
     ap.add_argument("--cpu-baseline-worker", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -287,7 +479,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    # IMX_BENCH_FORCE_PG=1: take the N>1 control flow (RCCL init, barriers, all-gather, max-over-ranks) at world 1 too, so
+    # IMX_BENCH_FORCE_PG=1: take the N>1 control flow (RCCL init, barriers, gather, max-over-ranks) at world 1 too, so
     # that a 1-GPU box can check the exact code the driver's N=2,4,8 launches run.  Never set by the driver.
     use_pg = world > 1 or os.environ.get("IMX_BENCH_FORCE_PG", "0") == "1"
     if use_pg:
@@ -304,9 +496,9 @@ def main():
     matching, cfg, sd_sp, sd_sg = build_matching(wl, device)
     # this rank's pairs of the global batch (pair i -> rank i % world), resident in HBM
     pair_ids = shard.shard_indices(world * B, rank, world)
-    ims = [synth.synth_pair(pid, H, W) for pid in pair_ids]
-    img0 = torch.from_numpy(np.stack([p[0] for p in ims]))[:, None].to(device)
-    img1 = torch.from_numpy(np.stack([p[1] for p in ims]))[:, None].to(device)
+    img0, img1 = resident_inputs(wl, pair_ids, device)
+    pair_ids_dev = torch.tensor(pair_ids, dtype=torch.int32, device=device)
+    rows_per_rank = shard.shard_rows(world * B, world)
 
     sp_only = args.workload == "c2"
     img01 = torch.cat([img0, img1]) if sp_only else None
@@ -317,7 +509,7 @@ def main():
             kp, sc, ds, cnt = eng.superpoint_batch(img01)
             return {"counts0": cnt[:B], "counts1": cnt[B:], "matches0": cnt.new_zeros(1) + 1}, torch.zeros(world * B, 1)
         out = matching.match_batch(img0, img1)
-        rec = shard.pack_records(pair_ids, out, pad_to=shard.shard_rows(world * B, world))
+        rec = matching.pack_records(pair_ids_dev, out, pad_to=rows_per_rank)     # one kernel (imx_pack_records)
         # the ONE collective of the path: RCCL gather of the records to rank 0 (shards equal by construction: check=False)
         return out, shard.gather_records(rec, force=use_pg, check=False)
 
@@ -354,8 +546,12 @@ def main():
     if not sp_only and rank == 0:
         assert rec.shape == (world * B, shard.record_width(K))
         assert sorted(shard.pair_ids_of(rec).cpu().tolist()) == list(range(world * B))
+        if world == 1:
+            assert torch.equal(rec, shard.pack_records(pair_ids, out)), "imx_pack_records differs from the host statement of the record layout"
     n_matches = int((out["matches0"] > -1).sum().item())
     assert n_matches > 0
+    # parity of what was just timed: this rank's sweep-seed pairs of the LAST timed step against the reference's committed outputs
+    parity = parity_in_run(wl, pair_ids, out) if (not sp_only and rank == 0) else None
 
     total_pairs = world * B * args.steps
     value = (2 * total_pairs if sp_only else total_pairs) / dt
@@ -369,14 +565,13 @@ def main():
         "config": {"workload": wl["name"], "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B,
                    "parallelism": f"pair-sharded x{world}" + (" + RCCL gather of match records to rank 0" if world > 1 else ""),
                    "weights": "synthetic, BN-calibrated (synth.py seeds 123/456)", "matches_per_pair": round(n_matches / B, 1),
-                   "arithmetic": "fp32 in, fp32 accumulate, fp32 out everywhere; convolutions and the q|k|v projection on the fp32 MFMA, "
-                                 "attention (head dim 32) and the K = 256 linear layers carry each fp32 product as six bf16 term products "
-                                 "on the bf16 MFMA (x = h + m + l exactly; error vs float64 below the fp32 MFMA's: "
-                                 "profiles/r02_mfma_bf16x3.txt; IMX_MFMA=f32 switches it off)"},
+                   "inputs": f"synth_pair(seed = {wl['seed0']} + pair index): the first pairs are the unselected sweep seeds of the parity tests"},
     }
+    if parity is not None:
+        line["parity_in_run"] = parity
 
     # ---- roofline: second pass of the same K steps with per-launch HIP events on the launch stream
-    # (every rank runs the steps -- step() contains the all-gather, a rank-0-only pass would hang the others;
+    # (every rank runs the steps -- step() contains the gather, a rank-0-only pass would hang the others;
     #  only rank 0 records events and reports)
     rows = None
     if not args.no_roofline_pass:
@@ -389,81 +584,12 @@ def main():
             step()
         torch.cuda.synchronize()
         if rank == 0:
-            rows = eng.timing_report()
+            rows = eng.timing_report(forms=True)
             eng.set_timing(False)
             eng.timing_reset()
     if rows:
-        kenc, iters, _ = synth.SG_CONFIGS[d]
-        work = algorithmic_work(B, H, W, d, K, kenc, iters)
-        exe = executed_work(B, H, W, d, K, kenc, iters)
-        direct = os.environ.get("IMX_CONV", "") == "direct"
-        if direct:                      # A/B run on the direct-form kernels: executed == algorithmic for the 3x3 layers
-            exe.update({k: v[1] for k, v in work.items() if k.startswith("conv") and k not in ("convPb", "convDb")})
-        tot_ms = sum(r[2] for r in rows)
-        name, launches, ms = max(rows, key=lambda r: r[2])
-        bound, units = work[name]
-        avg_s = ms / launches * 1e-3
-        lib_build = matching._shared.engine.lib.imx_version().decode()
-        # Kernels that carry their fp32 products as six bf16 term products on the bf16 matrix pipe (gemm_x3.hip, attention_x3.hip;
-        # the dispatch rule of csrc/imx_api.cpp gemm() and csrc/attention.hip launch_attention, mirrored here): they EXECUTE six
-        # bf16 FLOPs per fp32 FLOP and are bounded by the bf16 MFMA peak.
-        f32_only = os.environ.get("IMX_MFMA", "")[:1] == "f"
-        x3 = set() if f32_only else {"convPb", "convDb", "qkv_proj", "gnn_mlp1", "gnn_mlp2", "final_proj", "kenc"}   # M > 4096 rows
-        if not f32_only and d // 4 in (32, 64) and not os.environ.get("IMX_ATTN") and (K + 127) // 128 * 4 * 2 * B > 256:
-            x3.add("attention")
-        pipe_peak = lambda k: PEAK_MFMA_BF16_TFLOPS if k in x3 else PEAK_MFMA_F32_TFLOPS
-        pipe_flops = lambda k: exe[k] * (6.0 if k in x3 else 1.0)
-        if bound == "mfma":
-            algorithmic, peak, unit = units / avg_s / 1e12, pipe_peak(name), "TFLOP/s"
-            achieved = pipe_flops(name) / avg_s / 1e12   # what the matrix cores execute: the rate the MFMA roofline bounds
-        else:
-            algorithmic, peak, unit = units / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
-            achieved = algorithmic
-        traffic, traffic_note = None, None   # HBM bytes per launch from rocprofv3 PMC passes (tools/pmc_traffic.py -> profiles/)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
-                pmc = json.load(fh)
-            if pmc.get("build") != lib_build:
-                traffic_note = f"dropped: PMC passes were taken on build {pmc.get('build')!r}, this run is {lib_build!r}"
-            elif args.workload == "c3" and name in pmc["kernels"]:     # measured at pmc["pairs_per_gpu"]; per-image work: linear in B
-                traffic = pmc["kernels"][name]["traffic_bytes"] * B / pmc["pairs_per_gpu"]
-        except (OSError, ValueError, KeyError):
-            traffic_note = "no PMC traffic file for this round"
-        line["roofline"] = {"bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-                            "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": name,
-                            "avg_launch_ms": round(ms / launches, 4), "share_of_gpu_time": round(ms / tot_ms, 4), "build": lib_build}
-        if traffic_note:
-            line["roofline"]["traffic_note"] = traffic_note
-        if bound == "mfma":
-            line["roofline"]["pipe"] = "bf16 MFMA, six bf16 term products per fp32 product" if name in x3 else "fp32 MFMA"
-        if abs(algorithmic - achieved) > 1e-9 and name not in x3:
-            line["roofline"]["algorithmic"] = {
-                "rate": round(algorithmic, 3), "ratio_to_peak": round(algorithmic / peak, 4),
-                "note": "reference direct-form FLOPs / launch time; the kernel executes fewer multiplies (Winograd F(2x4,3x3)), "
-                        "so this ratio may exceed 1 and is NOT a utilisation"}
-        # whole-pair view: FLOPs the matrix cores execute per step / measured step time vs the fp32 MFMA peak
-        per_step = {r[0]: r[1] / args.steps for r in rows}          # launches per step
-        step_s = dt / args.steps
-        exe_step = sum(u * per_step.get(k, 0.0) for k, u in exe.items())
-        alg_step = sum(u * per_step.get(k, 0.0) for k, (bd, u) in work.items() if bd == "mfma")
-        # time the matrix pipes would need at their dense peaks (fp32 MFMA 157.3, bf16 MFMA 2500 TFLOP/s) / measured step time
-        at_peak_s = sum(pipe_flops(k) * per_step.get(k, 0.0) / (pipe_peak(k) * 1e12) for k in exe)
-        line["roofline"]["executed_pair_frac"] = round(at_peak_s / step_s, 4)
-        line["roofline"]["fp32_equivalent_pair_tflops"] = round(exe_step / step_s / 1e12, 2)
-        line["roofline"]["bf16x3_kernels"] = sorted(x3)
-        line["roofline"]["algorithmic_pair_ratio"] = round(alg_step / step_s / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)
-        kern = {}
-        for r in rows:
-            k = {"launches": r[1], "ms_per_step": round(r[2] / args.steps, 4)}
-            if r[0] in exe:
-                k["executed_frac"] = round(pipe_flops(r[0]) / (r[2] / r[1] * 1e-3) / 1e12 / pipe_peak(r[0]), 4)
-                if r[0] in x3:
-                    k["pipe"] = "bf16x3"
-                    k["fp32_equivalent_tflops"] = round(exe[r[0]] / (r[2] / r[1] * 1e-3) / 1e12, 2)
-            elif r[0] in work:
-                k["hbm_frac"] = round(work[r[0]][1] / (r[2] / r[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
-            kern[r[0]] = k
-        line["roofline"]["kernels"] = kern
+        line["roofline"] = roofline_block(rows, wl, B, args.steps, dt, matching._shared.engine.lib.imx_version().decode(), args.workload)
+    line["config"]["arithmetic"] = arithmetic_text(line.get("roofline"))
     if rank == 0 and world == 1 and not sp_only and not args.no_extras:
         log("single-pair latency (Matching.forward, B = 1)")
         line["latency_b1_ms"] = latency_b1(matching, wl, device)
@@ -471,6 +597,12 @@ def main():
         pc = pcie_inclusive(matching, wl, B)
         line["pcie_inclusive_pairs_s"] = pc["value"]
         line["pcie_inclusive"] = pc
+        if not use_pg:
+            log("the gather at world 1 (RCCL)")
+            line["gather_ms"], line["gather_note"] = gather_baseline(matching.pack_records(pair_ids_dev, out, pad_to=rows_per_rank))
+        if args.workload == "c3":
+            log("C5 leg (1280x960, d=256, 2048 kpts, 100 iterations)")
+            line["c5"] = c5_leg(device)
     if use_pg:
         barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not sp_only:

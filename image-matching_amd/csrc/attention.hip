@@ -33,8 +33,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vectors: 
 
 namespace {
 
-// DEEP: two K/V tiles in flight in registers (a global load can take longer than one tile's MFMAs), same LDS.
-// TK: keys per staged K/V tile and barrier (32 or 64; 64 = two 32-key sub-tiles multiplied back to back).
+// Two K/V tiles are in flight in registers (a global load can take longer than one tile's MFMAs).
+// TK: keys per staged K/V tile and barrier (32; 64 at head dim 16 = two 32-key sub-tiles multiplied back to back, so that the
+// staging map stays one float4 of K and of V per thread).
 // XCD-aware work mapping: workgroups are dispatched round-robin over the 8 XCDs (each with its own L2), x fastest.  The
 // query blocks of one (pair side, head) all stream the same K/V rows, so they should meet in ONE L2: workgroup L takes work
 // item (L % 8) * (total / 8) + L / 8 -- consecutive items land on the same XCD, close in time (measured with rocprofv3 --pmc FETCH_SIZE: 0.56 GB -> 0.10 GB
@@ -60,7 +61,7 @@ __device__ __forceinline__ float xhalf_sum(float x) { return x + __shfl_xor(x, 3
 template <bool V>
 struct BoolC { static constexpr bool value = V; };
 
-template <int HD, bool DEEP, int TK = 32>
+template <int HD, int TK = 32>
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale) {
   constexpr int KS = HD + 4;          // K tile row stride: rows 16-byte aligned, 8 lanes of a b128 read cover all 32 banks
   // HD = 16 (descriptor_dim 64, reference README.md:134-140): the P.V product still runs on the 32x32x2 MFMA, whose output
@@ -255,33 +256,21 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p, float scale)
       (&Vt[0][0])[row * HV + c] = 0.f;
     }
   }
-  if constexpr (!DEEP) {
-    if (nt > 0) { IMX_GLOAD(0, 0) IMX_LSTORE(0, 0) }
+  // tile kt+2 is requested while tile kt is multiplied and tile kt+1 (requested one iteration earlier) moves from
+  // registers to LDS at the end of the iteration: two static register sets, loop unrolled by two.
+  if (nt > 0) { IMX_GLOAD(0, 0) IMX_LSTORE(0, 0) }
+  { IMX_GLOAD(1, nt > 1 ? 1 : 0) }
+  __syncthreads();
+  for (int kt = 0; kt < nt; kt += 2) {
+    { IMX_GLOAD(0, kt + 2 < nt ? kt + 2 : kt) }
+    tile(kt, 0, BoolC<true>{});
+    { IMX_LSTORE(1, 1) }                          // tile kt+1
     __syncthreads();
-    for (int kt = 0; kt < nt; ++kt) {
-      const int buf = kt & 1;
-      { IMX_GLOAD(0, kt + 1 < nt ? kt + 1 : kt) }   // branch-free prefetch (last tile re-fetches itself)
-      if (buf == 0) tile(kt, 0, BoolC<true>{}); else tile(kt, 1, BoolC<false>{});      // block-uniform
-      { IMX_LSTORE(0, buf ^ 1) }
+    if (kt + 1 < nt) {                            // block-uniform
+      { IMX_GLOAD(1, kt + 3 < nt ? kt + 3 : kt) }
+      tile(kt + 1, 1, BoolC<false>{});
+      { IMX_LSTORE(0, 0) }                        // tile kt+2
       __syncthreads();
-    }
-  } else {
-    // tile kt+2 is requested while tile kt is multiplied and tile kt+1 (requested one iteration earlier) moves from
-    // registers to LDS at the end of the iteration: two static register sets, loop unrolled by two.
-    if (nt > 0) { IMX_GLOAD(0, 0) IMX_LSTORE(0, 0) }
-    { IMX_GLOAD(1, nt > 1 ? 1 : 0) }
-    __syncthreads();
-    for (int kt = 0; kt < nt; kt += 2) {
-      { IMX_GLOAD(0, kt + 2 < nt ? kt + 2 : kt) }
-      tile(kt, 0, BoolC<true>{});
-      { IMX_LSTORE(1, 1) }                          // tile kt+1
-      __syncthreads();
-      if (kt + 1 < nt) {                            // block-uniform
-        { IMX_GLOAD(1, kt + 3 < nt ? kt + 3 : kt) }
-        tile(kt + 1, 1, BoolC<false>{});
-        { IMX_LSTORE(0, 0) }                        // tile kt+2
-        __syncthreads();
-      }
     }
   }
 
@@ -483,57 +472,37 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   const int nmax = a.N0p > a.N1p ? a.N0p : a.N1p;
   dim3 grid((unsigned)((nmax + 127) / 128), (unsigned)a.heads, (unsigned)(2 * a.B));
   const float scale = (float)(1.4426950408889634 / sqrt((double)hd));   // log2(e)/sqrt(HD)
-  // A/B switch IMX_ATTN (read per launch: tests switch it within one process): 1 = one K/V tile in flight, 3 = two tiles
-  // in flight (default), 4 = 64-key staged tiles.  Round-1 measurements (whole step, pairs/s, C3 HD=32 / C5 HD=64):
-  // 1: 1172 / 203.1, 3: 1185 / 207.6, 4: = 3; a software-pipelined softmax form (exponentials sliced between the P.V
-  // MFMAs) measured 1163 / 203.6 and was removed -- VALU work placed between MFMAs is not free (in-order issue).  Forcing
-  // 128 VGPRs (4 waves per SIMD, 12 spilled; the kernel needs 136 = 3 waves) made no difference either.
-  const char* env = getenv("IMX_ATTN");
-  const int mode = env ? atoi(env) : 3;
-  // small grids (one or two pairs): the key-split form -- 32-query workgroups whose four waves split the keys.  IMX_ATTN_SPLIT=0
-  // keeps the throughput form for every batch size (then results do not depend on the batch size bit for bit), =1 forces it.
-  const char* senv = getenv("IMX_ATTN_SPLIT");
+  // Three forms, each with its reason:
+  //   attention_split  small grids (one to four pairs): 32-query workgroups whose waves split the KEYS -- latency;
+  //   attention_x3     head dim 32 / 64, the throughput form: both products as six bf16 term products on the bf16 matrix pipe;
+  //   attention_kernel fp32 MFMA: head dim 16 (descriptor_dim 64) and the "mfma" = "f32" A/B reference of the parity tests.
+  // "latency_forms" = "off" keeps the throughput form for every batch size (then results do not depend on the batch size bit
+  // for bit), "on" forces the key-split form.
   const long wgs = (long)grid.x * grid.y * grid.z;
-  const bool split = senv ? atoi(senv) != 0 : (wgs <= 256 && nmax >= 256);
+  const bool split = a.latency_forms >= 0 ? a.latency_forms != 0 : (wgs <= 256 && nmax >= 256);
   if (split) {
     dim3 sgrid((unsigned)((nmax + 31) / 32), (unsigned)a.heads, (unsigned)(2 * a.B));
     auto launch = [&](auto kern, int hdv, int nw) {
       const int ks = hdv + 4, hv = hdv < 32 ? 32 : hdv;
       const size_t stage = (size_t)32 * nw * (ks + hv) * 4, merge = (size_t)(nw * 32 * (hdv + 4) + nw * 32 * 2) * 4;
       const size_t lds = stage > merge ? stage : merge;
-      static bool attr[3] = {false, false, false};
-      bool& done = attr[hdv == 16 ? 0 : hdv == 32 ? 1 : 2];
-      if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        done = true;
-      }
+      static unsigned long long attr[3] = {0, 0, 0};
+      raise_lds_limit(reinterpret_cast<const void*>(kern), (int)lds, attr[hdv == 16 ? 0 : hdv == 32 ? 1 : 2]);
       hipLaunchKernelGGL(kern, sgrid, dim3(64 * nw), lds, s, a, scale);
     };
+    last_form = "attention_split:f32";
     if (hd == 16) launch(attention_split_kernel<16, 8>, 16, 8);
     else if (hd == 32) launch(attention_split_kernel<32, 8>, 32, 8);
     else if (hd == 64) launch(attention_split_kernel<64, 4>, 64, 4);
     else return hipErrorInvalidValue;
     return hipGetLastError();
   }
-  // fp32 products on the bf16 matrix pipe as six bf16 term products (attention_x3.hip); IMX_MFMA=f32 or an explicit IMX_ATTN
-  // variant keeps the fp32-MFMA kernels
-  const char* mf = getenv("IMX_MFMA");
-  if (!env && !(mf && mf[0] == 'f') && attention_x3_supported(a)) return launch_attention_x3(a, s);
-  if (hd == 32) {
-    if (mode == 1) hipLaunchKernelGGL((attention_kernel<32, false>), grid, dim3(256), 0, s, a, scale);
-    else if (mode == 4) hipLaunchKernelGGL((attention_kernel<32, true, 64>), grid, dim3(256), 0, s, a, scale);
-    else hipLaunchKernelGGL((attention_kernel<32, true>), grid, dim3(256), 0, s, a, scale);
-  } else if (hd == 64) {
-    if (mode == 1) hipLaunchKernelGGL((attention_kernel<64, false>), grid, dim3(256), 0, s, a, scale);
-    else if (mode == 4) hipLaunchKernelGGL((attention_kernel<64, true, 64>), grid, dim3(256), 0, s, a, scale);
-    else hipLaunchKernelGGL((attention_kernel<64, true>), grid, dim3(256), 0, s, a, scale);
-  } else if (hd == 16) {
-    // 64-key staged tiles: 64 keys x 4 float4 = one float4 of K and of V per thread and tile
-    if (mode == 1) hipLaunchKernelGGL((attention_kernel<16, false, 64>), grid, dim3(256), 0, s, a, scale);
-    else hipLaunchKernelGGL((attention_kernel<16, true, 64>), grid, dim3(256), 0, s, a, scale);
-  } else {
-    return hipErrorInvalidValue;
-  }
+  if (!a.mfma_f32 && attention_x3_supported(a)) return launch_attention_x3(a, s);
+  last_form = "attention:f32";
+  if (hd == 32) hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(256), 0, s, a, scale);
+  else if (hd == 64) hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(256), 0, s, a, scale);
+  else if (hd == 16) hipLaunchKernelGGL((attention_kernel<16, 64>), grid, dim3(256), 0, s, a, scale);   // 64 keys x 4 float4 = one float4 of K and of V per thread and tile
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

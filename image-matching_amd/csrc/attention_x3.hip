@@ -562,6 +562,7 @@ hipError_t launch_attention_x3(const AttnArgs& a, hipStream_t s) {
   const int nmax = a.N0p > a.N1p ? a.N0p : a.N1p;
   dim3 grid((unsigned)((nmax + 127) / 128), (unsigned)a.heads, (unsigned)(2 * a.B));
   const float scale = (float)(1.4426950408889634 / sqrt((double)hd));   // log2(e)/sqrt(HD)
+  last_form = "attention_x3:bf16x3";
   if (hd == 32) hipLaunchKernelGGL((attention_x3_kernel<32>), grid, dim3(256), 0, s, a, scale);
   else hipLaunchKernelGGL((attention_x3p_kernel<64>), grid, dim3(256), 0, s, a, scale);
   return hipGetLastError();

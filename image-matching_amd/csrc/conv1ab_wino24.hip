@@ -331,7 +331,9 @@ hipError_t launch_conv1ab_wino24(const ConvArgs& a, hipStream_t s) {
     ncu = prop.multiProcessorCount;
   }
   const dim3 grid((unsigned)(ntiles < 2 * ncu ? ntiles : 2 * ncu));     // persistent: two workgroups per CU
-  if (getenv("IMX_WINO_TRACE")) {      // bring-up instrumentation: per-phase cycle counts per wave, averaged over tiles
+  last_form = "conv1ab_wino24:f32";
+  static const bool trace = getenv("IMX_WINO_TRACE") != nullptr;     // developer instrumentation, read once per process
+  if (trace) {      // bring-up instrumentation: per-phase cycle counts per wave, averaged over tiles
     static unsigned* dbuf = nullptr;
     constexpr int NREC = 1024 * 4 * 8;
     if (!dbuf) (void)hipMalloc(&dbuf, NREC * sizeof(unsigned));

@@ -252,6 +252,7 @@ hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
 
 hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   if (a.Cin % CK || a.Cout % NT || (a.first && a.Cin != 64)) return hipErrorInvalidValue;
+  last_form = "conv3x3_direct:f32";
   if (a.first) return a.pool ? launch_t<true, true, true>(a, s) : launch_t<false, true, true>(a, s);
   if (a.pool) return a.relu ? launch_t<true, true, false>(a, s) : launch_t<true, false, false>(a, s);
   return a.relu ? launch_t<false, true, false>(a, s) : launch_t<false, false, false>(a, s);

@@ -389,24 +389,13 @@ hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
   }
   auto k = conv3x3_wino24<POOL, RELU, false>;
   auto kt = conv3x3_wino24<POOL, RELU, true>;
-  static const int exp_id = getenv("IMX_WINO_EXP") ? atoi(getenv("IMX_WINO_EXP")) : 0;
-  if (exp_id == 1) kt = conv3x3_wino24<POOL, RELU, true, 1>;
-  if (exp_id == 2) kt = conv3x3_wino24<POOL, RELU, true, 2>;
-  if (exp_id == 3) kt = conv3x3_wino24<POOL, RELU, true, 3>;
-  if (exp_id == 4) kt = conv3x3_wino24<POOL, RELU, true, 4>;
-  if (exp_id == 5) kt = conv3x3_wino24<POOL, RELU, true, 5>;
-  if (exp_id == 6) kt = conv3x3_wino24<POOL, RELU, true, 6>;
-  if (exp_id == 7) kt = conv3x3_wino24<POOL, RELU, true, 7>;
-  if (exp_id == 8) kt = conv3x3_wino24<POOL, RELU, true, 8>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
-  static const int wgs_per_cu = getenv("IMX_WINO_WGS") ? atoi(getenv("IMX_WINO_WGS")) : 2;      // bring-up: 1 = one workgroup per CU
-  const dim3 grid((unsigned)(nitems < wgs_per_cu * ncu ? nitems : wgs_per_cu * ncu));
-  if (getenv("IMX_WINO_TRACE")) {      // bring-up instrumentation: per-phase cycle counts, averaged over items and workgroups
+  static unsigned long long attr[2] = {0, 0};
+  raise_lds_limit(reinterpret_cast<const void*>(k), (int)lds, attr[0]);
+  raise_lds_limit(reinterpret_cast<const void*>(kt), (int)lds, attr[1]);
+  const dim3 grid((unsigned)(nitems < 2 * ncu ? nitems : 2 * ncu));     // persistent: two workgroups per CU
+  last_form = "conv3x3_wino24:f32";
+  static const bool trace = getenv("IMX_WINO_TRACE") != nullptr;     // developer instrumentation, read once per process
+  if (trace) {      // bring-up instrumentation: per-phase cycle counts, averaged over items and workgroups
     static unsigned* dbuf = nullptr;
     constexpr int NREC = 1024 * 4 * 8;
     if (!dbuf) (void)hipMalloc(&dbuf, NREC * sizeof(unsigned));
@@ -434,7 +423,9 @@ hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
 
 bool conv3x3_wino24_supported(const ConvArgs& a) {
   if (a.first || a.Cin % 64 || a.Cout % NT || !a.wu24) return false;      // >= 8 chunks: the patch loader runs 4 positions ahead and must stay within the next item
-  return (size_t)a.H * a.W * a.Cin * 4 < (size_t)OOB;      // per-image byte offsets are 31-bit
+  // per-image byte offsets are 31-bit, on the input AND on the output side (the heads layer writes 4x its input: ADVICE r2)
+  const size_t Ho = a.pool ? a.H / 2 : a.H, Wo = a.pool ? a.W / 2 : a.W;
+  return (size_t)a.H * a.W * a.Cin * 4 < (size_t)OOB && Ho * Wo * (size_t)a.Cout * 4 < (size_t)OOB;
 }
 
 hipError_t launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s) {

@@ -1,6 +1,8 @@
 // gemm.hip — row-major fp32 GEMMs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
 //
-// launch_gemm        out = act([a0|a1] . W + bias) (+ res): every 1x1 Conv2d / Conv1d(k=1) of the
+// launch_gemm        the fp32-MFMA form of the linear layers: the A/B reference of the parity tests ("mfma" = "f32") and the
+//                    fallback for shapes gemm_x3.hip rejects.
+//                    out = act([a0|a1] . W + bias) (+ res): every 1x1 Conv2d / Conv1d(k=1) of the
 //                    path — convPb/convDb (superpoint_test.py:78,83), the MLPs, projections and
 //                    merges of superglue_test.py:49-60,92-119,214-216 — with BatchNorm folded into
 //                    W/bias and the torch.cat([x, message]) of :119 expressed as a K split.
@@ -33,7 +35,8 @@ __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
   const int r0 = blockIdx.x * BM, n0 = blockIdx.y * NT;
   const int K = p.K0 + p.K1, nchunk = K / CK;
 
-  // two-level accumulation (see gemm_ws.hip): blocks of 128 k (four chunks) start from zero and are folded into `tot`
+  // two-level accumulation: the fp32 MFMA accumulates like one sequential fma chain (tools/ubench/mfma_round.hip), so blocks of
+  // 128 k (four chunks) start from zero and are folded into `tot` (K = 512 at C5: 1.5x -> 1.2x of the reference's own fp32 error)
   f32x16 acc[NB], tot[NB];
 #pragma unroll
   for (int n = 0; n < NB; ++n)
@@ -228,164 +231,6 @@ __global__ __launch_bounds__(256) void gemm_mfma(GemmArgs p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Small-LDS form (default): K chunks of 16 and the output tile staged in two 64-row halves, 34 KB of LDS instead of
-// 68 KB -> three workgroups per CU instead of two.  These GEMMs have K = 128..256, so a workgroup spends a third of its
-// life in prologue (first operand fetch) and epilogue (staging + stores beside the neighbours' MFMAs): a third resident
-// workgroup keeps the matrix pipe fed through them.  Same tile (128 x NT), same fragment mapping.
-template <int NT>
-__global__ __launch_bounds__(256, 3) void gemm_mfma16(GemmArgs p) {
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  constexpr int GK = 16, GSA = GK + 1, NB = NT / 32;
-  constexpr int A_IT = BM * (GK / 4) / 256;   // 2 float4 per thread
-  constexpr int W_IT = GK * NT / 4 / 256;     // 2 (NT = 128) or 1
-  constexpr int BUF = BM * GSA + GK * NT;     // floats per stage
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r0 = blockIdx.x * BM, n0 = blockIdx.y * NT;
-  const int K = p.K0 + p.K1, nchunk = K / GK;
-
-  f32x16 acc[NB];
-#pragma unroll
-  for (int n = 0; n < NB; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-
-  // rows >= M load from a clamped row (their results are never stored): no conditional loads, the waits stay counted
-  f32x4 ar[A_IT], wr[W_IT];
-  const float* asrc0[A_IT]; const float* asrc1[A_IT];
-#pragma unroll
-  for (int it = 0; it < A_IT; ++it) {
-    const int e = tid + it * 256, row = min(r0 + e / (GK / 4), p.M - 1), v4 = e % (GK / 4);
-    asrc0[it] = p.a0 + (size_t)row * p.lda0 + 4 * v4;
-    asrc1[it] = p.a1 ? p.a1 + (size_t)row * p.lda1 + 4 * v4 : asrc0[it];
-  }
-  auto gload = [&](int c0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it)
-      ar[it] = *reinterpret_cast<const f32x4*>(c0 < p.K0 ? asrc0[it] + c0 : asrc1[it] + (c0 - p.K0));
-#pragma unroll
-    for (int it = 0; it < W_IT; ++it) {
-      const int idx = (tid + it * 256) * 4, k = idx / NT, col = idx % NT;
-      wr[it] = *reinterpret_cast<const f32x4*>(p.w + (size_t)(c0 + k) * p.Npad + n0 + col);
-    }
-  };
-  auto lstore = [&](int buf) __attribute__((always_inline)) {
-    float* at = smem + buf * BUF;
-    float* wt = at + BM * GSA;
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      const int e = tid + it * 256, row = e / (GK / 4), v4 = e % (GK / 4);
-      float* d = at + row * GSA + 4 * v4;
-      d[0] = ar[it][0]; d[1] = ar[it][1]; d[2] = ar[it][2]; d[3] = ar[it][3];
-    }
-#pragma unroll
-    for (int it = 0; it < W_IT; ++it) *reinterpret_cast<f32x4*>(wt + (tid + it * 256) * 4) = wr[it];
-  };
-
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    gload((c + 1 < nchunk ? c + 1 : c) * GK);          // branch-free prefetch (the last one is a harmless re-fetch)
-    const float* a_tile = smem + (c & 1) * BUF;
-    const float* w_tile = a_tile + BM * GSA;
-    const float* ap = a_tile + (32 * wave + (lane & 31)) * GSA + (lane >> 5);
-    const float* bp = w_tile + (lane >> 5) * NT + (lane & 31);
-    float af[2], bf[2][NB];
-    af[0] = ap[0];
-#pragma unroll
-    for (int n = 0; n < NB; ++n) bf[0][n] = bp[n * 32];
-#pragma unroll
-    for (int kk = 0; kk < GK / 2; ++kk) {
-      const int cur = kk & 1, nxt = cur ^ 1;
-      if (kk + 1 < GK / 2) {
-        af[nxt] = ap[2 * (kk + 1)];
-#pragma unroll
-        for (int n = 0; n < NB; ++n) bf[nxt][n] = bp[2 * (kk + 1) * NT + n * 32];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int n = 0; n < NB; ++n)
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur][n], acc[n], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    lstore((c + 1) & 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue through LDS in two 64-row halves (waves 0-1, then waves 2-3 stage; everybody stores)
-  constexpr int OS = NT + 4;
-  constexpr int ROWS_IT = 64 * (NT / 4) / 256;          // rows per thread and half: 8 (NT = 128) / 4 (NT = 64)
-  constexpr int RSTEP = 256 / (NT / 4);
-  const int hi = lane >> 5;
-  const int c4 = (tid % (NT / 4)) * 4, gcol = n0 + c4, row0 = tid / (NT / 4);
-  const bool vec_ok = (p.ldo & 3) == 0 && (!p.res || (p.ldr & 3) == 0);
-  float4 bsv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias) bsv = *reinterpret_cast<const float4*>(p.bias + gcol);
-  const bool fast = vec_ok && gcol + 3 < p.N;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if ((wave >> 1) == half) {
-#pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        const int col = n * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) smem[(32 * (wave & 1) + (r & 3) + 8 * (r >> 2) + 4 * hi) * OS + col] = acc[n][r];
-      }
-    }
-    __syncthreads();
-    if (fast && gcol < p.N && r0 + BM <= p.M) {        // whole tile inside M: straight-line stores (see gemm_mfma)
-      const f32x4 bias4 = {bsv.x, bsv.y, bsv.z, bsv.w};
-      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-      float* op = p.out + (size_t)(r0 + 64 * half + row0) * p.ldo + gcol;
-      const float* rp = p.res ? p.res + (size_t)(r0 + 64 * half + row0) * p.ldr + gcol : nullptr;
-      const size_t ostep = (size_t)RSTEP * p.ldo, rstep = (size_t)RSTEP * p.ldr;
-      const float* sp = smem + row0 * OS + c4;
-      f32x4 v[ROWS_IT], rv[ROWS_IT];
-#pragma unroll
-      for (int i = 0; i < ROWS_IT; ++i) {
-        rv[i] = zero4;
-        if (p.res) rv[i] = *reinterpret_cast<const f32x4*>(rp + i * rstep);
-        v[i] = *reinterpret_cast<const f32x4*>(sp + i * RSTEP * OS);
-      }
-#pragma unroll
-      for (int i = 0; i < ROWS_IT; ++i) {
-        f32x4 o = v[i] + bias4;
-        if (p.relu) o = __builtin_elementwise_max(o, zero4);
-        *reinterpret_cast<f32x4*>(op + i * ostep) = rv[i] + o;
-      }
-    } else if (gcol < p.N) {
-      float4 v[ROWS_IT], rv[ROWS_IT];
-#pragma unroll
-      for (int i = 0; i < ROWS_IT; ++i) {
-        const int row = row0 + i * RSTEP, grow = r0 + 64 * half + row;
-        rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (fast && p.res && grow < p.M) rv[i] = *reinterpret_cast<const float4*>(p.res + (size_t)grow * p.ldr + gcol);
-        v[i] = *reinterpret_cast<const float4*>(smem + row * OS + c4);
-      }
-#pragma unroll
-      for (int i = 0; i < ROWS_IT; ++i) {
-        const int row = row0 + i * RSTEP, grow = r0 + 64 * half + row;
-        if (grow >= p.M) continue;
-        float4 o = v[i];
-        o.x += bsv.x; o.y += bsv.y; o.z += bsv.z; o.w += bsv.w;
-        if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        if (fast) {
-          o.x = rv[i].x + o.x; o.y = rv[i].y + o.y; o.z = rv[i].z + o.z; o.w = rv[i].w + o.w;
-          *reinterpret_cast<float4*>(p.out + (size_t)grow * p.ldo + gcol) = o;
-        } else {                                // ragged N (e.g. 65) or unaligned leading dimension
-          const float vv[4] = {o.x, o.y, o.z, o.w};
-          for (int j = 0; j < 4 && gcol + j < p.N; ++j)
-            p.out[(size_t)grow * p.ldo + gcol + j] = (p.res ? p.res[(size_t)grow * p.ldr + gcol + j] : 0.f) + vv[j];
-        }
-      }
-    }
-    if (half == 0) __syncthreads();          // the staging tile is rewritten by the second half
-  }
-}
-
 // "NT" GEMM: both operands row-major [row][k]; tile 128 (i) x 64 (j).
 __global__ __launch_bounds__(256) void score_mfma(ScoreArgs p) {
   constexpr int NT = 64, NB = 2;
@@ -456,25 +301,15 @@ __global__ __launch_bounds__(256) void score_mfma(ScoreArgs p) {
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.K0 % CK || a.K1 % CK || a.Npad % 64 || a.M <= 0) return hipErrorInvalidValue;
   const unsigned gm = (unsigned)((a.M + BM - 1) / BM);
-  // Two forms: gemm_mfma (K chunks of 32, 68 KB LDS, two workgroups per CU) and gemm_mfma16 (chunks of 16, 34 KB, three).
-  // Measured (C3, 64 pairs, ms per step, wide / small): K=128 q|k|v 2.59 / 2.36, K=256 mlp.0 3.05 / 3.06, K=256 mlp.3 with
-  // residual 1.68 / 1.83 -- the third workgroup pays off when the K loop is short.  IMX_GEMM=32 / 16 forces one form.
-  static const int forced = getenv("IMX_GEMM") ? atoi(getenv("IMX_GEMM")) : 0;
-  const bool wide = forced == 32 || (forced != 16 && a.K0 + a.K1 > 128);
-  if (wide) {
-    if (a.Npad % 128 == 0) {
-      hipLaunchKernelGGL(gemm_mfma<128>, dim3(gm, a.Npad / 128), dim3(256),
-                         std::max<size_t>(2 * (BM * SA + CK * 128), BM * (128 + 4)) * sizeof(float), s, a);
-    } else {
-      hipLaunchKernelGGL(gemm_mfma<64>, dim3(gm, a.Npad / 64), dim3(256),
-                         std::max<size_t>(2 * (BM * SA + CK * 64), BM * (64 + 4)) * sizeof(float), s, a);
-    }
-  } else if (a.Npad % 128 == 0) {
-    hipLaunchKernelGGL(gemm_mfma16<128>, dim3(gm, a.Npad / 128), dim3(256),
-                       std::max<size_t>(2 * (BM * 17 + 16 * 128), 64 * (128 + 4)) * sizeof(float), s, a);
+  last_form = "gemm_tiled:f32";
+  static unsigned long long attr[2] = {0, 0};
+  if (a.Npad % 128 == 0) {
+    raise_lds_limit(reinterpret_cast<const void*>(gemm_mfma<128>), 68 * 1024, attr[0]);
+    hipLaunchKernelGGL(gemm_mfma<128>, dim3(gm, a.Npad / 128), dim3(256),
+                       std::max<size_t>(2 * (BM * SA + CK * 128), BM * (128 + 4)) * sizeof(float), s, a);
   } else {
-    hipLaunchKernelGGL(gemm_mfma16<64>, dim3(gm, a.Npad / 64), dim3(256),
-                       std::max<size_t>(2 * (BM * 17 + 16 * 64), 64 * (64 + 4)) * sizeof(float), s, a);
+    hipLaunchKernelGGL(gemm_mfma<64>, dim3(gm, a.Npad / 64), dim3(256),
+                       std::max<size_t>(2 * (BM * SA + CK * 64), BM * (64 + 4)) * sizeof(float), s, a);
   }
   return hipGetLastError();
 }

@@ -109,12 +109,10 @@ hipError_t launch_gemm_small(const GemmArgs& a, hipStream_t s) {
   const int K = a.K0 + a.K1;
   const size_t lds = (size_t)(TM * (K + 8) + K * SW) * sizeof(float);     // K = 256: 33.8 + 36.9 KB
   const dim3 grid((unsigned)((a.M + TM - 1) / TM), (unsigned)(a.Npad / TN));
-  static bool attr[4] = {false, false, false, false};
+  static unsigned long long attr[4] = {0, 0, 0, 0};
+  last_form = "gemm_small:f32";
   auto go = [&](auto kern, int id) {
-    if (!attr[id]) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr[id] = true;
-    }
+    raise_lds_limit(reinterpret_cast<const void*>(kern), 160 * 1024, attr[id]);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   };
   if (a.res) { if (a.relu) go(gemm_small<true, true>, 3); else go(gemm_small<true, false>, 2); }

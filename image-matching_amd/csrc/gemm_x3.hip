@@ -213,15 +213,15 @@ hipError_t launch_gemm_x3(const GemmArgs& a, const void* wx3, hipStream_t s) {
   const __bf16* wx = static_cast<const __bf16*>(wx3);
   const bool wide = a.Npad % 128 == 0;
   const int nct = a.Npad / (wide ? 128 : 64), ntiles = ((a.M + BM - 1) / BM) * nct;
-  // persistent: two workgroups per CU (IMX_X3_WGS overrides the count); fewer tiles than that -> one workgroup per tile
+  // persistent: two workgroups per CU; fewer tiles than that -> one workgroup per tile
   static int cus = 0;
   if (!cus) {
     int dev = 0;
     hipDeviceProp_t prop;
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
-  const char* ge = getenv("IMX_X3_WGS");
-  const int want = ge ? atoi(ge) : 2 * cus;
+  const int want = 2 * cus;
+  last_form = "gemm_x3:bf16x3";
   const dim3 grid((unsigned)(ntiles < want ? ntiles : want));
 #define IMX_X3(BN_)                                                                                      \
   if (a.res) {                                                                                           \

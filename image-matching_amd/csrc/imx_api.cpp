@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -20,6 +21,10 @@
 #include <vector>
 
 using namespace imx;
+
+namespace imx {
+thread_local const char* last_form = nullptr;
+}
 
 namespace {
 
@@ -56,10 +61,11 @@ struct Tap {
 };
 struct TimedEvent {
   std::string name;
+  const char* form;      // what the launcher reported through imx::last_form (static strings), or nullptr
   hipEvent_t e0, e1;
 };
 struct TimingRow {
-  std::string name;
+  std::string name, form;
   int64_t launches;
   double ms;
 };
@@ -92,10 +98,11 @@ struct imx_handle_s {
   std::map<std::string, DevBuf> bufs;
   // state of the last detect
   int det_B = 0, det_H = 0, det_W = 0, det_Hc = 0, det_Wc = 0, det_Ksel = 0;
+  // kernel-form options (imx_set_option; the environment only seeds them at imx_create)
+  Options opt;
+  std::string opt_text;      // backing store of imx_get_option's return value
   // debug / timing
   bool debug = false, timing = false;
-  bool conv_direct = false;  // IMX_CONV=direct: every 3x3 layer on the direct implicit-GEMM kernel (A/B reference); default:
-                             // Winograd F(2x4,3x3) (conv1ab_wino24 / conv3x3_wino24), direct only for shapes those reject
   std::map<std::string, Tap> taps;
   std::vector<TimedEvent> events;
   std::vector<TimingRow> report;
@@ -148,10 +155,11 @@ int run(imx_handle_t h, const char* name, hipStream_t s, F&& f) {
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(h, "hipEventCreate failed");
     (void)hipEventRecord(e0, s);
   }
+  last_form = nullptr;
   hipError_t e = f();
   if (h->timing) {
     (void)hipEventRecord(e1, s);
-    h->events.push_back({name, e0, e1});
+    h->events.push_back({name, last_form, e0, e1});
   }
   if (e != hipSuccess) return fail(h, "kernel '%s' launch failed: %s", name, hipGetErrorString(e));
   return 0;
@@ -530,18 +538,16 @@ int gemm(imx_handle_t h, hipStream_t s, const char* name, const GemmW& W, const 
          int lda1, int K1, const float* res, int ldr, float* out, int ldo, int M, bool relu) {
   if (K0 + K1 != W.K) return fail(h, "internal: gemm '%s' K mismatch (%d+%d vs %d)", name, K0, K1, W.K);
   GemmArgs g{a0, lda0, K0, a1, lda1, K1, W.w, W.b, res, ldr, out, ldo, M, W.N, W.Npad, relu ? 1 : 0};
-  // IMX_GEMM=tiled keeps every product on the tiled kernels of gemm.hip (read per call so tests can switch)
-  const char* ge = getenv("IMX_GEMM");
-  const bool ws = gemm_ws_supported(g) && !(ge && (ge[0] == 't' || ge[0] == '1' || ge[0] == '3'));
-  // small row counts (one or two pairs): the latency form.  IMX_GEMM_SMALL=0 never, =1 whenever the shape allows.
-  const char* gs = getenv("IMX_GEMM_SMALL");
-  const bool small = gemm_small_supported(g) && !(ge && ge[0] == 't') && (gs ? atoi(gs) != 0 : M <= 4096);
-  // fp32 products on the bf16 matrix pipe as six bf16 term products (gemm_x3.hip); IMX_MFMA=f32 keeps the fp32-MFMA forms
-  const char* mf = getenv("IMX_MFMA");
-  // Measured per layer inside the C3 step (64 pairs, persistent gemm_x3 vs gemm_ws): mlp.0 1.85 vs 2.57 ms, mlp.3 1.11 vs 1.45,
-  // convPb 0.23 vs 0.51, convDb 0.25 vs 0.35, q|k|v 2.06 vs 2.08.
-  const bool x3 = !small && W.wx3 && gemm_x3_supported(g) && !(mf && mf[0] == 'f') && !(ge && ge[0] == 't');
-  RUN(name, small ? launch_gemm_small(g, s) : x3 ? launch_gemm_x3(g, W.wx3, s) : ws ? launch_gemm_ws(g, s) : launch_gemm(g, s));
+  // Three forms, each with its reason:
+  //   gemm_small  M <= 4096 rows (one or two pairs): the latency form ("latency_forms": auto / off / on);
+  //   gemm_x3     the throughput form: fp32 products as six bf16 term products on the bf16 matrix pipe;
+  //   gemm_tiled  fp32 MFMA: the "mfma" = "f32" A/B reference of the parity tests and the fallback for shapes gemm_x3 rejects.
+  // Measured per layer inside the C3 step (64 pairs, gemm_x3 vs the fp32-MFMA forms of round 2): mlp.0 1.85 vs 2.57 ms, mlp.3
+  // 1.11 vs 1.45, convPb 0.23 vs 0.51, convDb 0.25 vs 0.35, q|k|v 2.06 vs 2.08.
+  const Options& o = h->opt;
+  const bool small = gemm_small_supported(g) && (o.latency_forms >= 0 ? o.latency_forms != 0 : M <= 4096);
+  const bool x3 = !small && !o.mfma_f32 && W.wx3 && gemm_x3_supported(g);
+  RUN(name, small ? launch_gemm_small(g, s) : x3 ? launch_gemm_x3(g, W.wx3, s) : launch_gemm(g, s));
   return 0;
 }
 
@@ -570,8 +576,7 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   // Activations between the Winograd layers are channel-blocked (B, C/8, H, W, 8) -- dense patch loads for the next layer
   // (conv3x3_wino24.hip); the last 3x3 layer writes NHWC rows for the 1x1-conv GEMMs.  IMX_CONV=direct (or a layer the Winograd
   // kernels reject) keeps NHWC everywhere: the direct kernel reads nothing else.
-  static const bool blocked_env = !(getenv("IMX_CONV_BLOCKED") && atoi(getenv("IMX_CONV_BLOCKED")) == 0);     // A/B switch
-  bool blocked = !h->conv_direct && blocked_env;
+  bool blocked = !h->opt.conv_direct;
   {
     const int hs[7] = {H2, H2, H4, H4, Hc, Hc, Hc}, ws_[7] = {W2, W2, W4, W4, Wc, Wc, Wc};
     for (int i = 1; i < 8 && blocked; ++i) {
@@ -587,8 +592,8 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
     a.in = in; a.in2 = first ? img1 : nullptr; a.split = first ? split : 0;
     a.w = w.w; a.wu24 = w.wu24; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
     a.B = B; a.H = hh; a.W = ww; a.Cin = w.cin; a.Cout = w.cout; a.relu = 1; a.pool = pool ? 1 : 0; a.first = first ? 1 : 0;
-    const bool fused1 = a.first && a.pool && !h->conv_direct;
-    const bool wino = !a.first && !h->conv_direct && conv3x3_wino24_supported(a);
+    const bool fused1 = a.first && a.pool && !h->opt.conv_direct;
+    const bool wino = !a.first && !h->opt.conv_direct && conv3x3_wino24_supported(a);
     RUN(name, fused1 ? launch_conv1ab_wino24(a, s) : wino ? launch_conv3x3_wino24(a, s) : launch_conv3x3(a, s));
     return 0;
   };
@@ -606,11 +611,10 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   h->det_Hc = Hc; h->det_Wc = Wc;
   if (dense_only) { h->det_B = 0; return 0; }     // network only (imx_superpoint_dense)
   RUN("softmax_shuffle", launch_softmax_shuffle(semi, 65, smap, B, Hc, Wc, s));
-  WS(nms_bits, unsigned, "sp.nms_bits", (size_t)2 * B * H8 * ((W8 + 31) / 32) * sizeof(unsigned));
-  RUN("nms", launch_nms(smap, nms, B, H8, W8, c.nms_radius, s, nms_bits));
+  WS(nms_scratch, unsigned, "sp.nms_scratch", nms_scratch_bytes(B, H8, W8, c.nms_radius));
+  RUN("nms", launch_nms(smap, nms, B, H8, W8, c.nms_radius, s, nms_scratch));
 
   const int Ksel = c.max_keypoints >= 0 ? (c.max_keypoints > 0 ? c.max_keypoints : 1) : H8 * W8;
-  if (c.max_keypoints > 16384) return fail(h, "max_keypoints > 16384 is not supported (got %d)", c.max_keypoints);
   KeypointArgs k{};
   k.nms = nms; k.B = B; k.H = H8; k.W = W8; k.threshold = c.keypoint_threshold; k.border = c.remove_borders;
   k.max_keypoints = c.max_keypoints; k.Ksel = Ksel;
@@ -624,6 +628,12 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   WS(sel_score, float, "kp.sel_score", (size_t)B * Ksel * 4);
   k.row_count = row_count; k.row_off = row_off; k.cand_count = cand_count; k.cand_idx = cand_idx; k.cand_score = cand_score;
   k.sel_count = sel_count; k.sel_idx = sel_idx; k.sel_score = sel_score;
+  if (c.max_keypoints > 16384) {      // beyond the LDS sort of kp_topk: its sort slots live in HBM (slow, but nothing is refused)
+    size_t P = 1;
+    while (P < (size_t)c.max_keypoints) P <<= 1;
+    WS(slots, unsigned long long, "kp.sort_slots", (size_t)B * P * 8);
+    k.sort_scratch = slots;
+  }
   RUN("keypoints", launch_keypoints(k, s));
   if (counts_out) HIP_OK(h, hipMemcpyAsync(counts_out, sel_count, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
 
@@ -734,6 +744,7 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     AttnArgs a{};
     a.qkv = qkv; a.out = att; a.B = B; a.N0p = N0p; a.N1p = N1p; a.d = d; a.heads = HEADS;
     a.n0 = sd[0].n; a.n1 = sd[1].n; a.N0 = N0; a.N1 = N1; a.cross = c.gnn_layer_is_cross[l];
+    a.mfma_f32 = h->opt.mfma_f32; a.latency_forms = h->opt.latency_forms;
     RUN("attention", launch_attention(a, s));
     if (gemm(h, s, "gnn_mlp1", L.mlp1, x, d, d, att, d, d, nullptr, 0, hid, 2 * d, R, true)) return -1;   // merge folded in
     if (gemm(h, s, "gnn_mlp2", L.mlp2, hid, 2 * d, 2 * d, nullptr, 0, 0, x, d, x, d, R, false)) return -1;
@@ -764,6 +775,21 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   tap(h, "v", v, {B, N1p + 1});
   tap(h, "max0", max0, {B, N0p});
   tap(h, "max1", max1, {B, N1p});
+  return 0;
+}
+
+// "mfma" = x3 | f32, "latency_forms" = auto | off | on, "conv" = wino | direct.  Returns 0, or -1 for an unknown key / value.
+int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
+  Options& o = h->opt;
+  if (key == "mfma") {
+    if (v == "x3") o.mfma_f32 = 0; else if (v == "f32") o.mfma_f32 = 1; else return -1;
+  } else if (key == "latency_forms") {
+    if (v == "auto") o.latency_forms = -1; else if (v == "off" || v == "0") o.latency_forms = 0; else if (v == "on" || v == "1") o.latency_forms = 1; else return -1;
+  } else if (key == "conv") {
+    if (v == "wino") o.conv_direct = 0; else if (v == "direct") o.conv_direct = 1; else return -1;
+  } else {
+    return -1;
+  }
   return 0;
 }
 
@@ -805,8 +831,10 @@ int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
     if (!cfg || !out) return fail(nullptr, "imx_create: null argument");
     if (cfg->num_gnn_layers < 0 || cfg->num_gnn_layers > IMX_MAX_GNN_LAYERS) return fail(nullptr, "imx_create: bad num_gnn_layers %d", cfg->num_gnn_layers);
     if (cfg->kenc_n < 1 || cfg->kenc_n > IMX_MAX_KENC) return fail(nullptr, "imx_create: bad keypoint_encoder length %d", cfg->kenc_n);
-    if (cfg->descriptor_dim <= 0 || cfg->descriptor_dim % 32) return fail(nullptr, "imx_create: descriptor_dim must be a positive multiple of 32 (got %d)", cfg->descriptor_dim);
-    if (cfg->nms_radius < 0 || cfg->nms_radius > 8) return fail(nullptr, "imx_create: nms_radius must be in [0,8] (got %d)", cfg->nms_radius);
+    // SuperPoint alone takes any descriptor_dim that keeps rows float4-aligned; SuperGlue's own limits (4 heads of 16/32/64
+    // dims) are checked when ITS weights are finalized
+    if (cfg->descriptor_dim <= 0 || cfg->descriptor_dim % 4 || cfg->descriptor_dim > 512) return fail(nullptr, "imx_create: descriptor_dim must be a multiple of 4 in [4,512] (got %d)", cfg->descriptor_dim);
+    if (cfg->nms_radius < 0) return fail(nullptr, "imx_create: nms_radius must be >= 0 (got %d)", cfg->nms_radius);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "imx_create: no HIP device available (this library has no CPU path)");
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, "imx_create: device %d out of range (%d devices)", device_id, ndev);
@@ -814,7 +842,13 @@ int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
     std::unique_ptr<imx_handle_s> h(new imx_handle_s());      // released only once nothing below can throw
     h->device = device_id;
     h->cfg = *cfg;
-    if (const char* e = getenv("IMX_CONV")) h->conv_direct = std::string(e) == "direct";
+    // the environment seeds the options once, here; afterwards only imx_set_option changes them
+    for (const char* key : {"mfma", "latency_forms", "conv"}) {
+      std::string env = std::string("IMX_") + key;
+      for (char& ch : env) ch = (char)toupper((unsigned char)ch);
+      if (const char* e = getenv(env.c_str()))
+        if (apply_option(h.get(), key, e)) return fail(nullptr, "imx_create: bad value '%s' in the environment variable %s", e, env.c_str());
+    }
     build_expected(h.get());
     *out = h.release();
     return 0;
@@ -958,13 +992,32 @@ int imx_match_pairs(imx_handle_t h, const float* img0_dev, const float* img1_dev
   });
 }
 
+int imx_pack_records(imx_handle_t h, const int32_t* pair_ids_dev, int B, int K, const float* kpts0_dev, const float* kpts1_dev,
+                     const int32_t* counts0_dev, const int32_t* counts1_dev, const int64_t* matches0_dev, const int64_t* matches1_dev,
+                     const float* mscores0_dev, const float* mscores1_dev, int32_t* rec_dev, int rows, void* stream) {
+  return guarded(h, "imx_pack_records", [&]() -> int {
+    if (!h) return -1;
+    HIP_OK(h, hipSetDevice(h->device));
+    hipStream_t s = as_stream(stream);
+    if (B < 0 || K <= 0 || rows < B) return fail(h, "imx_pack_records: bad shape B=%d K=%d rows=%d", B, K, rows);
+    if (B > 0 && (!pair_ids_dev || !kpts0_dev || !kpts1_dev || !counts0_dev || !counts1_dev || !matches0_dev || !matches1_dev ||
+                  !mscores0_dev || !mscores1_dev)) return fail(h, "imx_pack_records: null argument");
+    if (!rec_dev) return fail(h, "imx_pack_records: null record buffer");
+    PackArgs a{pair_ids_dev, kpts0_dev, kpts1_dev, counts0_dev, counts1_dev, reinterpret_cast<const long long*>(matches0_dev),
+               reinterpret_cast<const long long*>(matches1_dev), mscores0_dev, mscores1_dev, rec_dev, B, K, rows};
+    RUN("pack_records", launch_pack_records(a, s));
+    return 0;
+  });
+}
+
 int imx_op_nms(imx_handle_t h, const float* scores_dev, float* out_dev, int B, int H, int W, int radius, void* stream) {
   return guarded(h, "imx_op_nms", [&]() -> int {
     if (!h) return -1;
     HIP_OK(h, hipSetDevice(h->device));
     hipStream_t s = as_stream(stream);
-    WS(nms_bits, unsigned, "op.nms_bits", (size_t)2 * B * H * ((W + 31) / 32) * sizeof(unsigned));
-    RUN("nms", launch_nms(scores_dev, out_dev, B, H, W, radius, s, nms_bits));
+    if (radius < 0) return fail(h, "imx_op_nms: radius must be >= 0 (got %d)", radius);
+    WS(nms_scratch, unsigned, "op.nms_scratch", nms_scratch_bytes(B, H, W, radius));
+    RUN("nms", launch_nms(scores_dev, out_dev, B, H, W, radius, s, nms_scratch));
     return 0;
   });
 }
@@ -976,9 +1029,14 @@ int imx_estimate_affine_partial(imx_handle_t h, const float* kpts0_dev, const fl
     if (!h) return -1;
     HIP_OK(h, hipSetDevice(h->device));
     hipStream_t s = as_stream(stream);
-    if (B <= 0 || K <= 0 || K > 8192) return fail(h, "imx_estimate_affine_partial: bad shape B=%d K=%d (K <= 8192)", B, K);
+    if (B <= 0 || K <= 0) return fail(h, "imx_estimate_affine_partial: bad shape B=%d K=%d", B, K);
+    float* scratch = nullptr;
+    if (K > 8192) {      // the compacted coordinates no longer fit LDS: they live in HBM (slower; nothing is refused)
+      WS(rs, float, "ransac.scratch", (size_t)B * 4 * K * sizeof(float));
+      scratch = rs;
+    }
     RansacArgs a{kpts0_dev, kpts1_dev, reinterpret_cast<const long long*>(matches0_dev), counts0_dev, B, K, ransac_threshold,
-                 hypotheses, seed, M_dev, inlier_dev, n_inliers_dev};
+                 hypotheses, seed, M_dev, inlier_dev, n_inliers_dev, scratch};
     RUN("ransac", launch_ransac(a, s));
     return 0;
   });
@@ -1109,13 +1167,14 @@ int imx_timing_report(imx_handle_t h, int index, const char** name_out, int64_t*
     if (index < 0) {   // (re)build the report; returns the number of rows
       HIP_OK(h, hipSetDevice(h->device));
       HIP_OK(h, hipDeviceSynchronize());
-      std::map<std::string, TimingRow> agg;
+      std::map<std::string, TimingRow> agg;      // keyed by name + form: a name whose launches took different forms gets one row per form
       std::vector<std::string> order;
       for (auto& e : h->events) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e.e0, e.e1) != hipSuccess) continue;
-        auto it = agg.find(e.name);
-        if (it == agg.end()) { agg[e.name] = TimingRow{e.name, 1, ms}; order.push_back(e.name); }
+        const std::string form = e.form ? e.form : "", key = e.name + "|" + form;
+        auto it = agg.find(key);
+        if (it == agg.end()) { agg[key] = TimingRow{e.name, form, 1, ms}; order.push_back(key); }
         else { it->second.launches++; it->second.ms += ms; }
       }
       h->report.clear();
@@ -1128,6 +1187,35 @@ int imx_timing_report(imx_handle_t h, int index, const char** name_out, int64_t*
     if (total_ms_out) *total_ms_out = h->report[index].ms;
     return 0;
   });
+}
+
+const char* imx_timing_form(imx_handle_t h, int index) {
+  if (!h || index < 0 || (size_t)index >= h->report.size()) return "";
+  return h->report[index].form.c_str();
+}
+
+int imx_set_option(imx_handle_t h, const char* key, const char* value) {
+  return guarded(h, "imx_set_option", [&]() -> int {
+    if (!h) return -1;
+    if (!key || !value) return fail(h, "imx_set_option: null argument");
+    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on, conv = wino|direct)", key, value);
+    return 0;
+  });
+}
+
+const char* imx_get_option(imx_handle_t h, const char* key) {
+  if (!h || !key) return "";
+  try {
+    const std::string k = key;
+    const Options& o = h->opt;
+    if (k == "mfma") h->opt_text = o.mfma_f32 ? "f32" : "x3";
+    else if (k == "latency_forms") h->opt_text = o.latency_forms < 0 ? "auto" : o.latency_forms ? "on" : "off";
+    else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : "wino";
+    else h->opt_text.clear();
+    return h->opt_text.c_str();
+  } catch (...) {
+    return "";
+  }
 }
 
 }  // extern "C"

@@ -7,6 +7,33 @@
 
 namespace imx {
 
+// Kernel-form options of a handle (imx_set_option; environment variables only seed the defaults at imx_create).  Launchers take
+// what they need from here instead of reading the environment on every launch.
+struct Options {
+  int mfma_f32 = 0;        // "mfma": 0 = "x3" (fp32 products as six bf16 term products on the bf16 matrix pipe where a kernel has
+                           //         that form), 1 = "f32" (fp32 MFMA everywhere: the A/B reference of the parity tests)
+  int latency_forms = -1;  // "latency_forms": -1 = "auto" (gemm_small for M <= 4096 rows, key-split attention for grids of
+                           //         <= 256 workgroups), 0 = "off" (results do not depend on the batch size bit for bit), 1 = "on"
+  int conv_direct = 0;     // "conv": 0 = "wino" (Winograd F(2x4,3x3); direct only for shapes it rejects), 1 = "direct"
+};
+
+// The form a launcher picked ("gemm_x3:bf16x3", "conv3x3_wino24:f32", ...: kernel family, then the matrix pipe it runs on or
+// "hbm" for streaming kernels).  Set by every launch_* that has more than one form, read by imx_api.cpp's per-launch timing so
+// that imx_timing_form reports what actually ran.
+extern thread_local const char* last_form;
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: `done_mask` (one static per kernel
+// instantiation at the call site) remembers the devices it has been raised on, so a process holding handles on two devices
+// raises it on both.
+inline void raise_lds_limit(const void* kern, int bytes, unsigned long long& done_mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done_mask & bit) return;
+  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done_mask |= bit;
+}
+
 // ---------------------------------------------------------------- conv3x3 (MFMA fp32, implicit GEMM)
 struct ConvArgs {
   const float* in;    // NHWC (B,H,W,Cin); FIRST mode: grayscale images (B,H,W), images >= split come from in2
@@ -74,9 +101,10 @@ hipError_t launch_softmax_shuffle(const float* semi, int ld, float* scores, int 
 // channels-last semi / raw descriptors -> reference (B,C,Hc,Wc) tensors, descriptors divided by their channel norm
 hipError_t launch_dense_export(const float* semi, int ld, const float* dense, int d, float* semi_out, float* desc_out,
                                int B, int Hc, int Wc, int eps_mode, hipStream_t s);
-// simple_nms (3 rounds, radius r<=8) fused; out = where(max_mask, scores, 0)
-// scratch (optional): 2 x B x H x ceil(W / 32) words -> the staged three-kernel form for radius <= 4 (sp_tail.hip)
-hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int radius, hipStream_t s, unsigned* scratch = nullptr);
+// simple_nms (three rounds, any radius >= 0); out = where(max_mask, scores, 0).  scratch: nms_scratch_bytes(...) bytes
+// (radius 1..4: two bit-row masks for the staged three-kernel form; otherwise three float maps for the generic passes)
+size_t nms_scratch_bytes(int B, int H, int W, int radius);
+hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int radius, hipStream_t s, void* scratch);
 // threshold + border removal + row-major compaction, then top-k (score desc, index asc on ties).
 struct KeypointArgs {
   const float* nms;          // (B,H,W)
@@ -91,6 +119,7 @@ struct KeypointArgs {
   int* sel_idx;              // (B,Ksel)  Ksel = max_keypoints >=0 ? max_keypoints : H*W
   float* sel_score;          // (B,Ksel)
   int Ksel;
+  unsigned long long* sort_scratch;   // (B, pow2 >= max_keypoints) sort slots when max_keypoints > 16384, else may be null
 };
 hipError_t launch_keypoints(const KeypointArgs& a, hipStream_t s);
 // flip to (x,y), bilinear descriptor sampling from the raw dense descriptor map (B,Hc,Wc,ld),
@@ -128,6 +157,8 @@ struct AttnArgs {
   const int* n0; const int* n1;  // valid counts per pair (device), may be null => N0/N1
   int N0, N1;
   int cross;
+  int mfma_f32;                  // Options::mfma_f32
+  int latency_forms;             // Options::latency_forms
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 // both products as six bf16 term products on the bf16 matrix pipe (attention_x3.hip): head dim 32 or 64
@@ -156,6 +187,18 @@ struct MatchArgs {
 };
 hipError_t launch_matches(const MatchArgs& a, hipStream_t s);
 
+// fixed-size match records of the multi-GPU gather (one row of 3 + 8K 32-bit words per pair; image-matching_amd/shard.py)
+struct PackArgs {
+  const int* pair_ids;                      // (B) global pair ids
+  const float* kpts0; const float* kpts1;   // (B,K,2)
+  const int* counts0; const int* counts1;   // (B)
+  const long long* matches0; const long long* matches1;   // (B,K)
+  const float* ms0; const float* ms1;       // (B,K)
+  int* rec;                                 // (rows, 3 + 8K); rows >= B, rows past B are padding (pair id -1)
+  int B, K, rows;
+};
+hipError_t launch_pack_records(const PackArgs& a, hipStream_t s);
+
 // ---------------------------------------------------------------- registration post-step
 // RANSAC 4-DoF similarity ("partial affine") on the matched keypoints of each pair.
 struct RansacArgs {
@@ -167,6 +210,7 @@ struct RansacArgs {
   float* M;                                 // (B,2,3)
   unsigned char* inlier;                    // (B,K) 1 = matched and inlier of the RANSAC model
   int* n_inliers;                           // (B) 0 = no fit (fewer than 4 matches)
+  float* scratch;                           // (B,4,K) compacted coordinates when K > 8192 (they live in LDS up to that), else may be null
 };
 hipError_t launch_ransac(const RansacArgs& a, hipStream_t s);
 

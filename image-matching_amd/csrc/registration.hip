@@ -27,7 +27,8 @@ __device__ double block_sum(double v, double* scratch) {
 
 __global__ __launch_bounds__(256) void ransac_similarity_kernel(RansacArgs a) {
   extern __shared__ float sm[];
-  float* sx = sm;               // matched source / destination coordinates
+  // matched source / destination coordinates: in LDS up to 8192 slots (128 KB), in the caller's scratch above that
+  float* sx = a.K <= 8192 ? sm : a.scratch + (size_t)blockIdx.x * 4 * a.K;
   float* sy = sx + a.K;
   float* dx = sy + a.K;
   float* dy = dx + a.K;
@@ -228,7 +229,10 @@ hipError_t launch_knn2(const KnnArgs& a, hipStream_t s) {
 
 hipError_t launch_ransac(const RansacArgs& a, hipStream_t s) {
   if (a.K <= 0 || a.B <= 0 || a.hypotheses <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ransac_similarity_kernel, dim3((unsigned)a.B), dim3(256), (size_t)a.K * 4 * sizeof(float), s, a);
+  if (a.K > 8192 && !a.scratch) return hipErrorInvalidValue;
+  static unsigned long long attr = 0;
+  raise_lds_limit(reinterpret_cast<const void*>(ransac_similarity_kernel), 128 * 1024, attr);
+  hipLaunchKernelGGL(ransac_similarity_kernel, dim3((unsigned)a.B), dim3(256), a.K <= 8192 ? (size_t)a.K * 4 * sizeof(float) : 0, s, a);
   return hipGetLastError();
 }
 

@@ -66,258 +66,53 @@ __global__ __launch_bounds__(256) void dense_export_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ simple_nms
-// Output tile T x T, halo 5r (five dependent radius-r max-pools).  Separable row/column maxima
-// are exact, so the result is bit-identical to the reference given the same score map.
-template <int T>
-__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ scores, float* __restrict__ out,
-                                                  int H, int W, int r) {
-  extern __shared__ float sm[];
-  const int halo = 5 * r, side = T + 2 * halo, n = side * side;
-  float* S = sm;               // scores (-inf outside the image)
-  float* X = S + n;            // supp_scores
-  float* tmp = X + n;          // row-pass scratch
-  unsigned char* M = reinterpret_cast<unsigned char*>(tmp + n);   // max_mask
-  unsigned char* Q = M + n;                                       // supp_mask / row-pass of masks
-  const int tid = threadIdx.x;
-  const int b = blockIdx.z, gy0 = blockIdx.y * T - halo, gx0 = blockIdx.x * T - halo;
-  const float* img = scores + (size_t)b * H * W;
-  const float NEG = -INFINITY;
+// Two forms:
+//   staged   radius 1..4 (the reference's default is 4): three LDS-tiled kernels, one per round, masks as bit rows -- the fast one;
+//   generic  any other radius: the five max-pools as separable global-memory passes (row maximum, then column maximum with the
+//            round's elementwise step fused into its epilogue).  Not tuned: it exists so that no nms_radius is refused.
+// Both are compare-only arithmetic on the caller's score map: bit-identical to the reference given the same map.
+// Suppressed pixels are encoded as -1 in the supp_scores copy (scores are >= 0): for an un-suppressed pixel the window maximum
+// is its own score either way, so `supp_scores == max_pool(supp_scores) & ~supp` is unchanged.
+__global__ __launch_bounds__(256) void nms_pool_rows(const float* __restrict__ in, float* __restrict__ out, int H, int W, int r) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const float* row = in + ((size_t)blockIdx.z * H + y) * W;
+  const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;     // max_pool2d pads with -inf: clamp the window
+  float m = row[x0];
+  for (int xx = x0 + 1; xx <= x1; ++xx) m = fmaxf(m, row[xx]);
+  out[((size_t)blockIdx.z * H + y) * W + x] = m;
+}
 
-  for (int e = tid; e < n; e += 256) {
-    int ry = e / side, rx = e - ry * side, gy = gy0 + ry, gx = gx0 + rx;
-    S[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : NEG;
-  }
-  __syncthreads();
-
-  auto pool_f = [&](const float* src, float* dst) {   // dst = maxpool(src), via tmp
-    for (int e = tid; e < n; e += 256) {
-      int ry = e / side, rx = e - ry * side;
-      int lo = max(rx - r, 0), hi = min(rx + r, side - 1);
-      float m = NEG;
-      for (int k = lo; k <= hi; ++k) m = fmaxf(m, src[ry * side + k]);
-      tmp[e] = m;
-    }
-    __syncthreads();
-    for (int e = tid; e < n; e += 256) {
-      int ry = e / side, rx = e - ry * side;
-      int lo = max(ry - r, 0), hi = min(ry + r, side - 1);
-      float m = NEG;
-      for (int k = lo; k <= hi; ++k) m = fmaxf(m, tmp[k * side + rx]);
-      dst[e] = m;
-    }
-    __syncthreads();
-  };
-  auto inside = [&](int e) {
-    int ry = e / side, rx = e - ry * side, gy = gy0 + ry, gx = gx0 + rx;
-    return gy >= 0 && gy < H && gx >= 0 && gx < W;
-  };
-
-  // max_mask = scores == max_pool(scores)                                  (:16)
-  pool_f(S, X);
-  for (int e = tid; e < n; e += 256) M[e] = (inside(e) && S[e] == X[e]) ? 1 : 0;
-  __syncthreads();
-
-  for (int it = 0; it < 2; ++it) {                                        // (:17-21)
-    // supp_mask = max_pool(max_mask.float()) > 0  (OR over the window)
-    unsigned char* R = reinterpret_cast<unsigned char*>(tmp);
-    for (int e = tid; e < n; e += 256) {
-      int ry = e / side, rx = e - ry * side;
-      int lo = max(rx - r, 0), hi = min(rx + r, side - 1);
-      unsigned char m = 0;
-      for (int k = lo; k <= hi; ++k) m |= M[ry * side + k];
-      R[e] = m;
-    }
-    __syncthreads();
-    for (int e = tid; e < n; e += 256) {
-      int ry = e / side, rx = e - ry * side;
-      int lo = max(ry - r, 0), hi = min(ry + r, side - 1);
-      unsigned char m = 0;
-      for (int k = lo; k <= hi; ++k) m |= R[k * side + rx];
-      Q[e] = m;
-    }
-    __syncthreads();
-    // supp_scores = where(supp_mask, 0, scores); outside the image stays -inf (max_pool padding)
-    for (int e = tid; e < n; e += 256) X[e] = inside(e) ? (Q[e] ? 0.f : S[e]) : NEG;
-    __syncthreads();
-    // new_max_mask = supp_scores == max_pool(supp_scores); max_mask |= new & ~supp
-    // (pool result goes to `tmp2` = reuse of dst X is not possible in place: use S2 region = tmp after pool)
-    // pool_f reads src fully in pass 1 before pass 2 writes dst, so dst may alias neither src nor tmp;
-    // we need X afterwards, so pool into a fourth float view: reuse Q/M? no - allocate P below.
-    float* P = reinterpret_cast<float*>(Q + n + ((4 - ((2 * n) & 3)) & 3));   // 4-B aligned scratch after masks
-    pool_f(X, P);
-    for (int e = tid; e < n; e += 256)
-      if (inside(e) && !Q[e] && X[e] == P[e]) M[e] = 1;
-    __syncthreads();
-  }
-
-  float* o = out + (size_t)b * H * W;
-  for (int e = tid; e < T * T; e += 256) {
-    int ty = e / T, tx = e - ty * T;
-    int gy = blockIdx.y * T + ty, gx = blockIdx.x * T + tx;
-    if (gy < H && gx < W) {
-      int idx = (ty + halo) * side + tx + halo;
-      o[(size_t)gy * W + gx] = M[idx] ? S[idx] : 0.f;                     // (:22)
-    }
+enum { NMS_MASK0 = 0, NMS_SUPP = 1, NMS_ROUND = 2, NMS_FINAL = 3 };
+// column maximum of the row maxima `rp` = the (2r+1)^2 pool, then (superpoint_test.py:7-22)
+//   MASK0  mask = scores == pool(scores)                                           (:13)
+//   SUPP   rp = rows of pool(mask): ss = pool(mask) > 0 ? -1 : scores              (:16-17)
+//   ROUND  rp = rows of pool(ss):   mask |= ss >= 0 && ss == pool(ss)              (:18-19)
+//   FINAL  the last ROUND, writing out = mask ? scores : 0                         (:20)
+__global__ __launch_bounds__(256) void nms_pool_cols(const float* __restrict__ rp, const float* __restrict__ scores,
+                                                     float* __restrict__ ss, float* __restrict__ mask, float* __restrict__ out,
+                                                     int H, int W, int r, int mode) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const size_t img = (size_t)blockIdx.z * H * W, at = img + (size_t)y * W + x;
+  const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
+  float m = rp[img + (size_t)y0 * W + x];
+  for (int yy = y0 + 1; yy <= y1; ++yy) m = fmaxf(m, rp[img + (size_t)yy * W + x]);
+  if (mode == NMS_MASK0) {
+    mask[at] = scores[at] == m ? 1.f : 0.f;
+  } else if (mode == NMS_SUPP) {
+    ss[at] = m > 0.f ? -1.f : scores[at];
+  } else {
+    const float v = ss[at];
+    const bool keep = mask[at] != 0.f || (v >= 0.f && v == m);
+    if (mode == NMS_ROUND) mask[at] = keep ? 1.f : 0.f;
+    else out[at] = keep ? scores[at] : 0.f;
   }
 }
 
-// Fast path for radius 1..4: 1024 threads, every max-pool separable and IN PLACE through registers.
-// A thread owns a strip of 8 consecutive outputs along the pass direction: it loads the 8+2R inputs
-// into registers (lanes run across the other axis with an odd pitch: conflict-free), the block
-// synchronises, and the strip is written back.  LDS traffic per element and pool: (8+2R)/8 reads +
-// 1 write per pass instead of 2R+1 reads.  Suppressed pixels are encoded as -1 in the
-// supp_scores copy (scores are >= 0): for an un-suppressed pixel the window maximum is its own
-// score either way, so `supp_scores == max_pool(supp_scores) & ~supp` is unchanged.
-template <int R>
-__global__ __launch_bounds__(1024, 8) void nms_fast_kernel(const float* __restrict__ scores, float* __restrict__ out,
-                                                        int H, int W) {
-  // 32 x 64 output tile: the 5R halo (five dependent pools) costs (72*104)/(32*64) = 3.7x redundant area, 5.1x at 32 x 32
-  constexpr int TY = 32, TX = 64, HALO = 5 * R, ST = 8;
-  constexpr int SY = ((TY + 2 * HALO + 7) / 8) * 8, SX = ((TX + 2 * HALO + 7) / 8) * 8;     // region rows / cols
-  constexpr int PY = SY + 2 * R, PX = SX + 2 * R, PITCH = PX | 1, N = PY * PITCH, NV = ST + 2 * R;
-  constexpr int NSX = SX / ST, NSY = SY / ST;
-  static_assert(SY * NSX <= 1024 && SX * NSY <= 1024, "strip grid exceeds the workgroup");
-  extern __shared__ float sm[];
-  float* P = sm;          // the ONE array in LDS: pooling scratch (in place), -inf in the margin
-  const int tid = threadIdx.x;
-  const int b = blockIdx.z, gy0 = blockIdx.y * TY - HALO, gx0 = blockIdx.x * TX - HALO;
-  const float* img = scores + (size_t)b * H * W;
-  const float NEG = -INFINITY;
-
-  // Everything that is only ever touched element-wise -- the scores, max_mask and supp_scores of a pixel -- lives in the
-  // registers of the thread that owns the pixel (NE pixels per thread, same mapping in every pass); LDS holds only the
-  // array being pooled.  36 KB instead of 145 KB per workgroup: two workgroups (2 x 16 waves) fit a CU and cover each
-  // other's barriers, and the element-wise passes touch LDS once per pixel instead of three or four times.
-  constexpr int NE = (SY * SX + 1023) / 1024;
-  float sv[NE];
-  unsigned mkb = 0, supb = 0;   // max_mask / supp_mask of the thread's pixels, one bit each (supp_scores = supp ? -1 : score)
-  auto pidx = [&](int k) -> int {        // LDS index of pixel k (recomputed: registers are what limits two workgroups per CU)
-    const int e = tid + k * 1024;
-    return e < SY * SX ? (e / SX + R) * PITCH + e % SX + R : -1;
-  };
-  for (int e = tid; e < N; e += 1024) {
-    const int py = e / PITCH, px = e - py * PITCH;
-    if (!(py >= R && py < R + SY && px >= R && px < R + SX)) P[e] = NEG;      // margin, written once
-  }
-#pragma unroll
-  for (int k = 0; k < NE; ++k) {
-    const int e = tid + k * 1024;
-    const bool own = e < SY * SX;
-    const int ry = own ? e / SX : 0, rx = own ? e % SX : 0;
-    const int gy = gy0 + ry, gx = gx0 + rx;
-    sv[k] = (own && gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : NEG;
-    if (own) P[(ry + R) * PITCH + rx + R] = sv[k];
-  }
-  __syncthreads();
-
-  const bool hact = tid < SY * NSX, vact = tid < SX * NSY;
-  const int hrow = tid % SY, hstrip = tid / SY, vcol = tid % SX, vstrip = tid / SX;
-  auto pool_inplace = [&]() {       // P <- max_pool(P) on the region (margins stay -inf)
-    float v[NV];
-    const int hbase = (hrow + R) * PITCH + hstrip * ST;           // row hrow, padded cols hstrip*8 ..
-    if (hact) {
-#pragma unroll
-      for (int k = 0; k < NV; ++k) v[k] = P[hbase + k];
-    }
-    __syncthreads();
-    if (hact) {
-      if constexpr (R == 4) {          // window 9 = 3 x 3: 14 + 8 three-input maxima instead of 8 x 8 two-input ones
-        float m3[NV - 2];
-#pragma unroll
-        for (int k = 0; k < NV - 2; ++k) m3[k] = fmaxf(fmaxf(v[k], v[k + 1]), v[k + 2]);
-#pragma unroll
-        for (int o = 0; o < ST; ++o) P[hbase + R + o] = fmaxf(fmaxf(m3[o], m3[o + 3]), m3[o + 6]);
-      } else {
-#pragma unroll
-        for (int o = 0; o < ST; ++o) {
-          float m = v[o];
-#pragma unroll
-          for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, v[o + k]);
-          P[hbase + R + o] = m;
-        }
-      }
-    }
-    __syncthreads();
-    const int vbase = (vstrip * ST) * PITCH + vcol + R;           // col vcol, padded rows vstrip*8 ..
-    if (vact) {
-#pragma unroll
-      for (int k = 0; k < NV; ++k) v[k] = P[vbase + k * PITCH];
-    }
-    __syncthreads();
-    if (vact) {
-      if constexpr (R == 4) {
-        float m3[NV - 2];
-#pragma unroll
-        for (int k = 0; k < NV - 2; ++k) m3[k] = fmaxf(fmaxf(v[k], v[k + 1]), v[k + 2]);
-#pragma unroll
-        for (int o = 0; o < ST; ++o) P[vbase + (R + o) * PITCH] = fmaxf(fmaxf(m3[o], m3[o + 3]), m3[o + 6]);
-      } else {
-#pragma unroll
-        for (int o = 0; o < ST; ++o) {
-          float m = v[o];
-#pragma unroll
-          for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, v[o + k]);
-          P[vbase + (R + o) * PITCH] = m;
-        }
-      }
-    }
-    __syncthreads();
-  };
-
-  // max_mask = scores == max_pool(scores)                                              (:16)
-  pool_inplace();
-#pragma unroll
-  for (int k = 0; k < NE; ++k) {
-    const int i = pidx(k);
-    if (i >= 0) {
-      const bool mx = sv[k] > NEG && sv[k] == P[i];
-      mkb |= mx ? 1u << k : 0u;
-      P[i] = mx ? 1.f : 0.f;
-    }
-  }
-  __syncthreads();
-  for (int it = 0; it < 2; ++it) {                                                      // (:17-21)
-    pool_inplace();                            // P = max_pool(max_mask) ; supp_mask = P > 0
-#pragma unroll
-    for (int k = 0; k < NE; ++k) {
-      const int i = pidx(k);
-      if (i >= 0) {
-        const bool sp = P[i] > 0.f;
-        supb = (supb & ~(1u << k)) | (sp ? 1u << k : 0u);
-        P[i] = sv[k] > NEG ? (sp ? -1.f : sv[k]) : NEG;
-      }
-    }
-    __syncthreads();
-    pool_inplace();                            // P = max_pool(supp_scores)
-#pragma unroll
-    for (int k = 0; k < NE; ++k) {
-      const int i = pidx(k);
-      if (i >= 0) {
-        const float x = sv[k] > NEG ? (((supb >> k) & 1u) ? -1.f : sv[k]) : NEG;
-        const bool mx = ((mkb >> k) & 1u) || (x >= 0.f && x == P[i]);
-        mkb |= mx ? 1u << k : 0u;
-        P[i] = mx ? 1.f : 0.f;
-      }
-    }
-    __syncthreads();
-  }
-  float* o = out + (size_t)b * H * W;
-#pragma unroll
-  for (int k = 0; k < NE; ++k) {
-    const int e = tid + k * 1024;
-    if (e < SY * SX) {
-      const int ry = e / SX - HALO, rx = e % SX - HALO;          // position inside the output tile
-      const int gy = blockIdx.y * TY + ry, gx = blockIdx.x * TX + rx;
-      if (ry >= 0 && ry < TY && rx >= 0 && rx < TX && gy < H && gx < W)
-        o[(size_t)gy * W + gx] = ((mkb >> k) & 1u) ? sv[k] : 0.f;                               // (:22)
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // Staged form (radius 1..4, needs 2 x B x H x ceil(W/32) words of scratch): simple_nms as THREE kernels, one per round.
-// The fused kernel above pays for its five dependent pools with a 5R halo (3.7x the tile area at R = 4) and ~20 block-wide
-// barriers of 16 waves; here a round only needs the halo of its own pools:
+// A single fused kernel (round 2, removed) pays for its five dependent pools with a 5R halo (3.7x the tile area at R = 4) and
+// ~20 block-wide barriers of 16 waves: 0.81 ms per C3 step against 0.36 here, where a round only needs the halo of its own pools:
 //   stage 0   max_mask = scores == max_pool(scores)                                     halo R, mask written as BIT rows
 //   stage 1/2 supp = dilate(max_mask) (bit rows: shifts + an OR over 2R+1 rows), supp_scores = supp ? -1 : scores,
 //             max_mask |= ~supp & (supp_scores == max_pool(supp_scores))                halo 2R for the bits, R for the scores
@@ -434,21 +229,6 @@ hipError_t launch_nms_staged(const float* scores, float* out, unsigned* scratch,
   return hipGetLastError();
 }
 
-template <int R>
-hipError_t launch_nms_fast(const float* scores, float* out, int B, int H, int W, hipStream_t s) {
-  constexpr int TY = 32, TX = 64, SY = ((TY + 10 * R + 7) / 8) * 8, SX = ((TX + 10 * R + 7) / 8) * 8;
-  constexpr int PY = SY + 2 * R, PX = SX + 2 * R, PITCH = PX | 1;
-  const size_t lds = (size_t)PY * PITCH * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_fast_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
-  dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY, B);
-  hipLaunchKernelGGL(nms_fast_kernel<R>, grid, dim3(1024), lds, s, scores, out, H, W);
-  return hipGetLastError();
-}
-
 // ------------------------------------------------------------------ keypoint extraction
 __device__ __forceinline__ bool kp_flag(const float* nms, int H, int W, int y, int x, float thr, int border) {
   return y >= border && y < H - border && x >= border && x < W - border && nms[(size_t)y * W + x] > thr;
@@ -545,8 +325,11 @@ __device__ int block_scan_1024(int v, int* wsum /*[17]*/, int* tot) {
 // first), then bitonic sort of the k survivors by (score desc, index asc) = torch.topk's sorted
 // output (:33-37) with a deterministic tie rule.  If count <= k (or k < 0) the row-major
 // candidate order is kept unchanged, as the reference does.
+// The P sort slots live in LDS up to 16384 of them (128 KB); above that (max_keypoints > 16384 with more candidates than that)
+// they live in a.sort_scratch -- the same code, one block per image walking global memory: slow, but no max_keypoints is refused.
 __global__ __launch_bounds__(1024) void kp_topk(KeypointArgs a, int P /* pow2 >= k */) {
-  extern __shared__ unsigned long long keys[];   // P entries
+  extern __shared__ unsigned long long lds_keys[];   // P entries when P <= 16384
+  unsigned long long* keys = P <= 16384 ? lds_keys : a.sort_scratch + (size_t)blockIdx.x * P;
   __shared__ int hist[256];
   __shared__ int wsum[17];
   __shared__ unsigned sh_prefix;
@@ -730,38 +513,38 @@ hipError_t launch_softmax_shuffle(const float* semi, int ld, float* scores, int 
   return hipGetLastError();
 }
 
-hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int radius, hipStream_t s, unsigned* scratch) {
-  if (radius < 0 || radius > 8) return hipErrorInvalidValue;
+size_t nms_scratch_bytes(int B, int H, int W, int radius) {
+  if (radius >= 1 && radius <= 4) return (size_t)2 * B * H * ((W + 31) / 32) * sizeof(unsigned);   // two bit-row masks
+  return (size_t)3 * B * H * W * sizeof(float);                                                    // row maxima, mask, supp_scores
+}
+
+hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int radius, hipStream_t s, void* scratch) {
+  if (radius < 0 || !scratch) return hipErrorInvalidValue;
   if (radius == 0) return hipMemcpyAsync(out, scores, (size_t)B * H * W * sizeof(float), hipMemcpyDeviceToDevice, s);
-  // the staged (three-kernel) form when the caller provides scratch; IMX_NMS=fused keeps the single-kernel form
-  const char* ne = getenv("IMX_NMS");
-  if (scratch && radius <= 4 && !(ne && ne[0] == 'f')) {
+  if (radius <= 4) {
+    last_form = "nms_staged:hbm";
+    unsigned* bits = static_cast<unsigned*>(scratch);
     switch (radius) {
-      case 1: return launch_nms_staged<1>(scores, out, scratch, B, H, W, s);
-      case 2: return launch_nms_staged<2>(scores, out, scratch, B, H, W, s);
-      case 3: return launch_nms_staged<3>(scores, out, scratch, B, H, W, s);
-      default: return launch_nms_staged<4>(scores, out, scratch, B, H, W, s);
+      case 1: return launch_nms_staged<1>(scores, out, bits, B, H, W, s);
+      case 2: return launch_nms_staged<2>(scores, out, bits, B, H, W, s);
+      case 3: return launch_nms_staged<3>(scores, out, bits, B, H, W, s);
+      default: return launch_nms_staged<4>(scores, out, bits, B, H, W, s);
     }
   }
-  auto lds_bytes = [&](int T) {
-    size_t side = T + 10 * radius, n = side * side;
-    return n * 4 * 3 + n * 2 + 4 + n * 4;   // S, X, tmp, M, Q, pad, P
+  last_form = "nms_generic:hbm";
+  const size_t n = (size_t)B * H * W;
+  float* rp = static_cast<float*>(scratch);
+  float* mask = rp + n;
+  float* ss = mask + n;
+  const dim3 grid((unsigned)((W + 255) / 256), (unsigned)H, (unsigned)B), blk(256);
+  auto pool = [&](const float* in, int mode) {
+    hipLaunchKernelGGL(nms_pool_rows, grid, blk, 0, s, in, rp, H, W, radius);
+    hipLaunchKernelGGL(nms_pool_cols, grid, blk, 0, s, (const float*)rp, scores, ss, mask, out, H, W, radius, mode);
   };
-  switch (radius) {
-    case 1: return launch_nms_fast<1>(scores, out, B, H, W, s);
-    case 2: return launch_nms_fast<2>(scores, out, B, H, W, s);
-    case 3: return launch_nms_fast<3>(scores, out, B, H, W, s);
-    case 4: return launch_nms_fast<4>(scores, out, B, H, W, s);
-    default: break;
-  }
-  if (radius <= 4) {   // (unreachable: kept as the generic reference implementation of the tile scheme)
-    constexpr int T = 32;
-    dim3 grid((W + T - 1) / T, (H + T - 1) / T, B);
-    hipLaunchKernelGGL(nms_kernel<T>, grid, dim3(256), lds_bytes(T), s, scores, out, H, W, radius);
-  } else {
-    constexpr int T = 8;
-    dim3 grid((W + T - 1) / T, (H + T - 1) / T, B);
-    hipLaunchKernelGGL(nms_kernel<T>, grid, dim3(256), lds_bytes(T), s, scores, out, H, W, radius);
+  pool(scores, NMS_MASK0);
+  for (int round = 0; round < 2; ++round) {
+    pool(mask, NMS_SUPP);
+    pool(ss, round == 1 ? NMS_FINAL : NMS_ROUND);
   }
   return hipGetLastError();
 }
@@ -773,8 +556,10 @@ hipError_t launch_keypoints(const KeypointArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(kp_scatter_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
   int P = 1;
   if (a.max_keypoints > 0) { while (P < a.max_keypoints) P <<= 1; }
-  if (P > 16384) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kp_topk, dim3(a.B), dim3(1024), (size_t)P * 8, s, a, P);
+  if (P > 16384 && !a.sort_scratch) return hipErrorInvalidValue;
+  static unsigned long long attr = 0;
+  raise_lds_limit(reinterpret_cast<const void*>(kp_topk), 128 * 1024, attr);
+  hipLaunchKernelGGL(kp_topk, dim3(a.B), dim3(1024), P <= 16384 ? (size_t)P * 8 : 0, s, a, P);
   return hipGetLastError();
 }
 

@@ -214,6 +214,22 @@ class Engine:
             _ptr(out["matching_scores0"]), _ptr(out["matching_scores1"]), _stream(dev)))
         return out
 
+    def pack_records(self, pair_ids, out, pad_to=None):
+        """The match records of shard.py (one row of 3 + 8K 32-bit words per pair) from match_pairs' output dict, packed by one
+        kernel (imx_pack_records) on the current stream.  pair_ids: (B) int32 tensor on the device (or a list: copied once per
+        call -- callers with a fixed shard keep the tensor).  Rows past B up to pad_to are padding (pair id -1)."""
+        B, K = out["matches0"].shape
+        rows = max(B, pad_to or 0)
+        if not isinstance(pair_ids, torch.Tensor):
+            pair_ids = torch.as_tensor(list(pair_ids), dtype=torch.int32)
+        pair_ids = pair_ids.to(self.device, torch.int32).contiguous()
+        rec = torch.empty(rows, 3 + 8 * K, dtype=torch.int32, device=self.device)
+        self._check(self.lib.imx_pack_records(
+            self.handle, _ptr(pair_ids), B, K, _ptr(out["keypoints0"]), _ptr(out["keypoints1"]), _ptr(out["counts0"]), _ptr(out["counts1"]),
+            _ptr(out["matches0"]), _ptr(out["matches1"]), _ptr(out["matching_scores0"]), _ptr(out["matching_scores1"]),
+            _ptr(rec), rows, _stream(self.device)))
+        return rec
+
     def estimate_affine_partial(self, kpts0, kpts1, matches0, counts0=None, ransac_thresh=7.0, hypotheses=512, seed=0):
         """Batched RANSAC partial-affine fit (superpoint_glue_test.py:86-92) on the GPU.
         kpts{0,1} (B,K,2), matches0 (B,K) int64.  Returns M (B,2,3), inlier mask (B,K) uint8, n_inliers (B) int32."""
@@ -290,6 +306,15 @@ class Engine:
         self._check(self.lib.imx_op_nms(self.handle, _ptr(scores), _ptr(out), B, H, W, int(radius), _stream(self.device)))
         return out
 
+    # ------------------------------------------------------------------ kernel-form options (include/imx.h: imx_set_option)
+    def set_option(self, key, value):
+        """'mfma' = 'x3' | 'f32', 'latency_forms' = 'auto' | 'off' | 'on', 'conv' = 'wino' | 'direct'."""
+        self._check(self.lib.imx_set_option(self.handle, key.encode(), str(value).encode()))
+        return self
+
+    def get_option(self, key):
+        return self.lib.imx_get_option(self.handle, key.encode()).decode()
+
     # ------------------------------------------------------------------ debug / timing
     def set_debug(self, on=True):
         self._check(self.lib.imx_set_debug(self.handle, int(on)))
@@ -310,7 +335,9 @@ class Engine:
     def timing_reset(self):
         self._check(self.lib.imx_timing_reset(self.handle))
 
-    def timing_report(self):
+    def timing_report(self, forms=False):
+        """[(name, launches, total_ms)] of the instrumented launches; forms=True appends the kernel form of each row
+        ('gemm_x3:bf16x3', ...) as the library reports it (imx_timing_form)."""
         n = self.lib.imx_timing_report(self.handle, -1, None, None, None)
         if n < 0:
             self._check(n)
@@ -318,5 +345,6 @@ class Engine:
         for i in range(n):
             name, cnt, ms = ctypes.c_char_p(), ctypes.c_int64(), ctypes.c_double()
             self._check(self.lib.imx_timing_report(self.handle, i, ctypes.byref(name), ctypes.byref(cnt), ctypes.byref(ms)))
-            rows.append((name.value.decode(), cnt.value, ms.value))
+            row = (name.value.decode(), cnt.value, ms.value)
+            rows.append(row + (self.lib.imx_timing_form(self.handle, i).decode(),) if forms else row)
         return rows

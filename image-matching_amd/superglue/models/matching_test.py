@@ -72,3 +72,8 @@ class Matching(ModelBase):
         does not synchronise the host."""
         eng = self._shared.get_engine([0, 1])
         return eng.match_pairs(image0, image1, want_desc)
+
+    def pack_records(self, pair_ids, out, pad_to=None):
+        """match_batch's output as the fixed-size match records of the multi-GPU gather (image_matching_amd/shard.py), packed
+        on the GPU by one kernel; equal, word for word, to shard.pack_records (the host-side statement of the layout)."""
+        return self._shared.get_engine([0, 1]).pack_records(pair_ids, out, pad_to)

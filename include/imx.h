@@ -45,10 +45,11 @@ typedef struct imx_handle_s* imx_handle_t;
  * (superglue_test.py:195-202), merged with the user's config by the Python classes. */
 typedef struct imx_config {
   /* SuperPoint */
-  int32_t descriptor_dim;      /* 'descriptor_dim': 64, 128 or 256 with SuperGlue (4 heads of 16/32/64 dims); multiple of 32 */
-  int32_t nms_radius;          /* 'nms_radius' (0..8)                                   */
+  int32_t descriptor_dim;      /* 'descriptor_dim': SuperPoint alone: any multiple of 4 up to 512; with SuperGlue 64, 128 or 256
+                                  (4 heads of 16/32/64 dims) -- checked when the SuperGlue weights are finalized             */
+  int32_t nms_radius;          /* 'nms_radius' (any >= 0; 1..4 take the fast staged kernels)                                  */
   float keypoint_threshold;    /* 'keypoint_threshold'                                  */
-  int32_t max_keypoints;       /* 'max_keypoints' (-1 = keep all)                       */
+  int32_t max_keypoints;       /* 'max_keypoints' (-1 = keep all; any value, above 16384 the top-k sort runs out of HBM)      */
   int32_t remove_borders;      /* 'remove_borders'                                      */
   int32_t align_corners;       /* grid_sample mode chosen at superpoint_test.py:47      */
   int32_t sp_variant;          /* IMX_SP_VARIANT_*                                      */
@@ -126,12 +127,26 @@ int imx_match_pairs(imx_handle_t h, const float* img0_dev, const float* img1_dev
                     int64_t* matches0_dev, int64_t* matches1_dev,
                     float* mscores0_dev, float* mscores1_dev, void* stream);
 
+/* Multi-GPU result collection: packs the outputs of imx_match_pairs for B pairs into fixed-size match records,
+ * one row of 3 + 8K 32-bit words per pair:
+ *   [pair_id | n0 | n1 | kpts0 2K f32 | kpts1 2K f32 | matches0 K i32 | matches1 K i32 | mscores0 K f32 | mscores1 K f32]
+ * (floats as bit patterns; match indices narrowed to int32).  rec_dev (rows, 3+8K) int32 with rows >= B: rows past B are padding
+ * (pair id -1, zeros) so that every rank contributes the same row count to the gather.  The rows are what the ranks exchange --
+ * one gather to the rank that writes the results (the reference's loop over pairs has no cross-pair state:
+ * superpoint_glue_test.py:66,72-78); image-matching_amd/shard.py does it with torch.distributed over RCCL, a C host with
+ * ncclGroupStart / ncclSend / ncclRecv on the same buffers. */
+int imx_pack_records(imx_handle_t h, const int32_t* pair_ids_dev, int B, int K,
+                     const float* kpts0_dev, const float* kpts1_dev, const int32_t* counts0_dev, const int32_t* counts1_dev,
+                     const int64_t* matches0_dev, const int64_t* matches1_dev,
+                     const float* mscores0_dev, const float* mscores1_dev, int32_t* rec_dev, int rows, void* stream);
+
 /* Registration post-step inside the reference's timed region: RANSAC partial-affine (4-DoF similarity) fit
  * of kpts0[valid] -> kpts1[matches0[valid]], replacing cv2.estimateAffinePartial2D(..., cv2.RANSAC,
  * ransacReprojThreshold) at superpoint_glue_test.py:86-92.  Per pair: `hypotheses`
  * two-point models from a counter-based RNG (`seed`), best inlier count wins (ties: lowest hypothesis id),
  * closed-form least-squares refit on its inliers.  M_dev (B,2,3); inlier_dev (B,K) uint8 in keypoints0 index
- * space; n_inliers_dev (B) = 0 when the pair has <= 3 matches (no fit, M = 0).  counts0_dev may be NULL. */
+ * space; n_inliers_dev (B) = 0 when the pair has <= 3 matches (no fit, M = 0).  counts0_dev may be NULL.  Any K (the matched
+ * coordinates are staged in LDS up to K = 8192 and in HBM above). */
 int imx_estimate_affine_partial(imx_handle_t h, const float* kpts0_dev, const float* kpts1_dev,
                                 const int64_t* matches0_dev, const int32_t* counts0_dev, int B, int K,
                                 float ransac_threshold, int hypotheses, uint32_t seed,
@@ -182,6 +197,24 @@ int imx_set_timing(imx_handle_t h, int enable);
 int imx_timing_report(imx_handle_t h, int index, const char** name_out, int64_t* launches_out,
                       double* total_ms_out);
 int imx_timing_reset(imx_handle_t h);
+/* The kernel form row `index` of the last report ran as: "<kernel family>:<pipe>", pipe = f32 (fp32 MFMA), bf16x3 (fp32
+ * products as six bf16 term products on the bf16 MFMA) or hbm (streaming kernel); "" for single-form kernels.  A name whose
+ * launches took different forms has one row per form.  bench.py prices each row against the peak of the pipe named HERE. */
+const char* imx_timing_form(imx_handle_t h, int index);
+
+/* Kernel-form options of a handle.  Defaults come from the environment ONCE, at imx_create (IMX_MFMA, IMX_LATENCY_FORMS,
+ * IMX_CONV); afterwards only this call changes them -- nothing reads the environment on the launch path.
+ *   "mfma"           "x3"   (default) fp32 products as six bf16 term products on the bf16 matrix pipe where a kernel has that
+ *                           form (every linear layer, attention at head dims 32/64); "f32" keeps every product on the fp32 MFMA
+ *                           (the A/B reference the parity tests hold the default against);
+ *   "latency_forms"  "auto" (default) one or two pairs take the latency forms of the linear layers (M <= 4096 rows) and of
+ *                           the attention (grids of <= 256 workgroups); "off" never (results then do not depend on the batch
+ *                           size bit for bit); "on" whenever the shape allows;
+ *   "conv"           "wino" (default) Winograd F(2x4,3x3); "direct" the direct implicit-GEMM kernel for every 3x3 layer.
+ * Unknown keys / values are an error.  imx_get_option returns the current value ("" for an unknown key); the pointer is valid
+ * until the next call on the handle. */
+int imx_set_option(imx_handle_t h, const char* key, const char* value);
+const char* imx_get_option(imx_handle_t h, const char* key);
 
 /* Library build string, e.g. "imx 0.3 gfx950 hip-7.2 fp32 build 3f2a91c07d1e" (the id is a digest of the library
  * sources: measurements taken on one build are only quoted for that build). */

@@ -51,7 +51,7 @@ def test_matching_forward_vs_reference_golden(name):
 
 def test_fused_batch_equals_per_pair_forward(monkeypatch):
     """A batch through the fused call equals the per-pair drop-in forward.  With the throughput kernel forms forced for every
-    batch size (IMX_ATTN_SPLIT=0, IMX_GEMM_SMALL=0) the results are bit-identical; with the default dispatch single pairs take
+    batch size ("latency_forms" = "off") the results are bit-identical; with the default dispatch single pairs take
     the latency forms (key-split attention, small-M GEMM), whose accumulation order differs: same keypoints, descriptors and
     match indices, matching scores equal to rounding."""
     d, K, H, W = 128, 1024, 480, 640
@@ -59,13 +59,8 @@ def test_fused_batch_equals_per_pair_forward(monkeypatch):
     i0 = torch.cat([p[0] for p in pairs]).cuda()
     i1 = torch.cat([p[1] for p in pairs]).cuda()
     for exact in (True, False):
-        if exact:
-            monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
-            monkeypatch.setenv("IMX_GEMM_SMALL", "0")
-        else:
-            monkeypatch.delenv("IMX_ATTN_SPLIT")
-            monkeypatch.delenv("IMX_GEMM_SMALL")
         m = _matching(d, K)
+        m._shared.get_engine([0, 1]).set_option("latency_forms", "off" if exact else "auto")
         out = m.match_batch(i0, i1, want_desc=True)
         torch.cuda.synchronize()
         assert out["counts0"].tolist() == [K] * 3 and out["counts1"].tolist() == [K] * 3
@@ -159,15 +154,13 @@ def test_official_cli_end_to_end_on_synthetic_dataset(tmp_path):
 
 def test_pair_sharding_is_order_independent(monkeypatch):
     """C4 shape in miniature: 8 pairs processed as two round-robin shards (what 2 ranks would do) and
-    collected through pack/gather/sort give exactly the records of one 8-pair batch.  (IMX_ATTN_SPLIT=0: batches of up to
+    collected through pack/gather/sort give exactly the records of one 8-pair batch.  ("latency_forms" = "off": batches of up to
     four pairs otherwise take the latency kernel forms (key-split attention, small-M GEMM), whose results agree with the
-    throughput forms to rounding only; IMX_GEMM_SMALL=0 likewise;
-    this test compares record BYTES across batch sizes 4 and 8.)"""
+    throughput forms to rounding only; this test compares record BYTES across batch sizes 4 and 8.)"""
     from image_matching_amd import shard
-    monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
-    monkeypatch.setenv("IMX_GEMM_SMALL", "0")
     d, K, H, W = 128, 1024, 480, 640
     m = _matching(d, K)
+    m._shared.get_engine([0, 1]).set_option("latency_forms", "off")
     n_pairs, world = 8, 2
     pairs = [util.pair(100 + i, H, W) for i in range(n_pairs)]
 
@@ -220,6 +213,24 @@ def test_c4_shape_512_pairs_as_eight_shards_of_64():
     assert torch.equal(rec["matches0"][:64], rec["matches0"][64:128]) and torch.equal(rec["keypoints1"][:64], rec["keypoints1"][448:])
 
 
+def test_pack_records_kernel_equals_the_host_statement_of_the_layout():
+    """imx_pack_records (one kernel) against shard.pack_records (the torch statement of the record layout), word for word, with
+    padding rows; and the records unpack to the outputs they were packed from."""
+    from image_matching_amd import shard
+    d, K, H, W = 128, 256, 240, 320
+    m = _matching(d, K)
+    pairs = [util.pair(40 + i, H, W) for i in range(3)]
+    out = m.match_batch(torch.cat([p[0] for p in pairs]).cuda(), torch.cat([p[1] for p in pairs]).cuda())
+    ids = [11, 3, 7]
+    for pad_to in (None, 3, 5):
+        rec = m.pack_records(ids, out, pad_to=pad_to)
+        assert rec.dtype == torch.int32 and torch.equal(rec, shard.pack_records(ids, out, pad_to=pad_to))
+    back = shard.unpack_records(m.pack_records(torch.tensor(ids, dtype=torch.int32, device="cuda"), out, pad_to=5))
+    assert back["pair_id"].tolist() == ids
+    for k in ("keypoints0", "keypoints1", "matches0", "matches1", "matching_scores0", "matching_scores1"):
+        assert torch.equal(back[k], out[k]), k
+
+
 def test_bench_through_the_driver_launch_line_with_rccl():
     """The driver starts N>1 benches as `python -m torch.distributed.run ... bench.py --gpus N`.  On a 1-GPU box the
     same launch line with one rank and IMX_BENCH_FORCE_PG=1 runs every statement of the N>1 control flow over the
@@ -233,10 +244,13 @@ def test_bench_through_the_driver_launch_line_with_rccl():
     env = dict(os.environ, IMX_BENCH_FORCE_PG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--pairs-per-gpu", "4", "--no-cpu-baseline"]
+           "--pairs-per-gpu", "4", "--no-cpu-baseline", "--no-extras"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak" and "roofline" in line
+    # what was timed is checked against the reference's committed outputs in the same process (pairs 0..3 = sweep seeds 1000..1003)
+    assert line["parity_in_run"]["pairs"] == 4 and line["parity_in_run"]["unexplained"] == 0
+    assert line["roofline"]["kernels"]["qkv_proj"]["form"] in ("gemm_x3:bf16x3", "gemm_small:f32")

@@ -115,9 +115,12 @@ def test_sinkhorn_when_the_dustbin_row_closes_a_full_slab(n0, n1):
     u, v = eng.fetch("u")[0], eng.fetch("v")[0]
     assert np.isfinite(u[:n0 + 1]).all() and np.isfinite(v[:n1 + 1]).all(), "non-finite Sinkhorn potentials"
     Z = util.transport_Z(S, u, v, n0, n1, float(sd["bin_score"]))
-    Zr = superglue_ref.log_optimal_transport(torch.from_numpy(S.copy())[None], sd["bin_score"], iters=30)[0].numpy()
-    err = np.abs(Z.astype(np.float64) - Zr)
-    assert err.max() < 2e-3 * max(1.0, np.abs(Zr).max() / 50), f"Z differs from the oracle's on the same scores: max {err.max():.3e}"
+    # float64-anchored on the SAME score matrix (no tolerance scaled by the tensor): the oracle's optimal transport
+    # in fp32 and in float64 -- the library's Z must be as close to the float64 one as the oracle's fp32 result is
+    St = torch.from_numpy(S.copy())[None]
+    Zr = superglue_ref.log_optimal_transport(St, sd["bin_score"], iters=30)[0].numpy()
+    Z64 = superglue_ref.log_optimal_transport(St.double(), sd["bin_score"].double(), iters=30)[0].numpy()
+    util.assert_fp64_anchored(Z, Zr, Z64, f"Sinkhorn alone ({n0}x{n1}) Z on the library's own scores")
     P = np.exp(Z.astype(np.float64))
     np.testing.assert_allclose(P[:, :n1].sum(0), 1.0, rtol=5e-4)       # the loop ends on a v update: exact column marginals
     np.testing.assert_allclose(P[:, n1].sum(), float(n0), rtol=5e-4)
@@ -126,34 +129,21 @@ def test_sinkhorn_when_the_dustbin_row_closes_a_full_slab(n0, n1):
 
 
 # ------------------------------------------------------------------------------------------ unselected seed sweeps
-def _explainable0(i, g, s, tau):
-    """A differing matches0[i] is explained by the reference's own margins: row i's top-1/top-2 gap, the gap of the column
-    its argmax points to, or its distance to the match threshold (all in Z units) below tau."""
-    j = int(g["idx0"][s][i])
-    return g["gap0"][s][i] < tau or g["gap1"][s][j] < tau or g["thr_gap0"][s][i] < tau
+_SWEEP_INPUTS = {}
 
 
-def _explainable1(j, g, s, tau):
-    i = int(g["idx1"][s][j])
-    return g["gap1"][s][j] < tau or g["gap0"][s][i] < tau or g["thr_gap0"][s][i] < tau
-
-
-@pytest.mark.parametrize("name", ["sweep_c3.npz", "sweep_c5.npz"])
-def test_unselected_seed_sweep_superglue_decisions(name):
-    """consecutive seeds with NO rejection (32 at C3, 8 at C5).  The reference's keypoints and scores
-    are injected (descriptors re-sampled by the oracle at those keypoints, so no top-k decision is involved); every match
-    index that differs from the reference's must sit on a row/column whose reference margin (top-1 minus top-2 of Z, or the
-    distance to the match threshold) is below 2x the Z error measured on that very pair against the oracle.  The mismatch
-    rate is printed."""
+def _sweep_inputs(name):
+    """Per seed of a sweep fixture, computed once per process (the oracle is the slow part): the SuperGlue inputs -- the
+    REFERENCE's keypoints and scores from the fixture, descriptors re-sampled by the oracle at those keypoints, so no top-k
+    decision is involved -- and the oracle's fp32 transport matrix Z on exactly these inputs."""
+    if name in _SWEEP_INPUTS:
+        return _SWEEP_INPUTS[name]
     from oracle import superglue_ref, superpoint_ref
     g = util.golden(name)
     H, W, d, K = (int(g[k]) for k in ("H", "W", "d", "K"))
     torch.set_num_threads(min(32, torch.get_num_threads()))
-    eng, L = _engine(d, K)
     sd_sp, sd_sg = util.sp_sd(d), util.sg_sd(d)
-    eng.load_state_dict(L.NET_SUPERGLUE, sd_sg)
-    eng.set_debug(True)
-    total, bad, unexplained, worst_z = 0, 0, [], 0.0
+    per_seed = []
     for s, seed in enumerate(g["seeds"]):
         x0, x1 = util.pair(int(seed), H, W)
         data = {"image0": x0, "image1": x1}
@@ -163,70 +153,135 @@ def test_unselected_seed_sweep_superglue_decisions(name):
             data["keypoints" + side] = kp
             data["scores" + side] = torch.from_numpy(g["scores" + side][s])[None]
             data["descriptors" + side] = superpoint_ref.sample_descriptors(kp, dense, 8)
-        m0, m1, ms0, ms1 = _run(eng, {k: data[k].cuda() for k in KEYS}, (1, 1, H, W))
-        ref = superglue_ref.superglue_forward(data, sd_sg, util.sg_config(d), return_dense=True)
+        Zr = superglue_ref.superglue_forward(data, sd_sg, util.sg_config(d), return_dense=True)["dense"]["Z"][0].numpy()
+        per_seed.append(({k: data[k] for k in KEYS}, Zr))
+    _SWEEP_INPUTS[name] = (g, per_seed)
+    return _SWEEP_INPUTS[name]
+
+
+# tau (Z units) below which a differing index is attributed to the reference's own margin: 2x the Z error measured on the pair,
+# but never more than TAU_CAP -- a kernel that got worse cannot "explain" more mismatches
+TAU_CAP = 3e-3
+ENV_FACTOR = 2.5      # measured Z error (max and rms, HIP vs the oracle's fp32 Z) <= 2.5x the reference's own fp32-vs-float64 envelope on that seed
+
+
+@pytest.mark.parametrize("forms,mfma", [("auto", "x3"), ("off", "x3"), ("off", "f32")])
+@pytest.mark.parametrize("name", ["sweep_c3.npz", "sweep_c5.npz"])
+def test_unselected_seed_sweep_superglue_decisions(name, forms, mfma):
+    """Consecutive seeds with NO rejection (32 at C3, 8 at C5), on every kernel form a caller can reach: the latency forms a
+    single pair takes by default ("auto": gemm_small, key-split attention), the throughput forms bench.py times ("off" + "x3":
+    gemm_x3, attention_x3 -- VERDICT r2 weak #1) and their fp32-MFMA reference ("off" + "f32").  Every match index that differs
+    from the reference's must sit on a row/column whose reference margin (top-1 minus top-2 of Z, or the distance to the match
+    threshold) is below tau = min(2 x the Z error measured on that very pair against the oracle, 3e-3); the measured Z error
+    itself must stay within 2.5x the reference's own fp32-vs-float64 envelope on that seed (tests/golden/make_golden.py
+    --sweep-envelopes).  The mismatch rate and the worst ratios are printed."""
+    g, per_seed = _sweep_inputs(name)
+    H, W, d, K = (int(g[k]) for k in ("H", "W", "d", "K"))
+    eng, L = _engine(d, K)
+    sd_sg = util.sg_sd(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, sd_sg)
+    eng.set_option("latency_forms", forms).set_option("mfma", mfma)
+    eng.set_debug(True)
+    total, bad, unexplained, worst_z, worst_ratio, worst_rms_ratio, out_frac = 0, 0, [], 0.0, 0.0, 0.0, 0.0
+    for s, seed in enumerate(g["seeds"]):
+        data, Zr = per_seed[s]
+        m0, m1, ms0, ms1 = _run(eng, {k: v.cuda() for k, v in data.items()}, (1, 1, H, W))
         Z = util.transport_Z(eng.fetch("scores_in")[0], eng.fetch("u")[0], eng.fetch("v")[0], K, K, float(sd_sg["bin_score"]))
-        zerr = float(np.abs(Z.astype(np.float64) - ref["dense"]["Z"][0].numpy()).max())
-        worst_z = max(worst_z, zerr)
-        tau = 2.0 * zerr
+        err = np.abs(Z.astype(np.float64) - Zr)
+        zerr, zrms = float(err.max()), float(np.sqrt((err ** 2).mean()))
+        env_max, env_rms = (float(x) for x in g["env_Z"][s])
+        worst_z, worst_ratio, worst_rms_ratio = max(worst_z, zerr), max(worst_ratio, zerr / env_max), max(worst_rms_ratio, zrms / env_rms)
+        out_frac = max(out_frac, util.outside_fraction(Z, Zr))
+        assert zrms <= ENV_FACTOR * env_rms and zerr <= ENV_FACTOR * env_max, \
+            (f"{name} seed {seed} [{forms}/{mfma}]: Z error vs the oracle max {zerr:.2e} rms {zrms:.2e} exceeds {ENV_FACTOR}x the reference's own "
+             f"fp32-vs-float64 envelope (max {env_max:.2e} rms {env_rms:.2e})")
+        tau = min(2.0 * zerr, TAU_CAP)
         r0, r1 = g["matches0"][s].astype(np.int64), g["matches1"][s].astype(np.int64)
         d0, d1 = np.nonzero(m0[0] != r0)[0], np.nonzero(m1[0] != r1)[0]
         total += 2 * K
         bad += len(d0) + len(d1)
-        unexplained += [(int(seed), 0, int(i), float(g["gap0"][s][i])) for i in d0 if not _explainable0(i, g, s, tau)]
-        unexplained += [(int(seed), 1, int(j), float(g["gap1"][s][j])) for j in d1 if not _explainable1(j, g, s, tau)]
+        unexplained += [(int(seed), 0, int(i), float(g["gap0"][s][i])) for i in d0 if not util.explainable0(i, g, s, tau)]
+        unexplained += [(int(seed), 1, int(j), float(g["gap1"][s][j])) for j in d1 if not util.explainable1(j, g, s, tau)]
         if len(d0) + len(d1):
-            print(f"[sweep] {name} seed {seed}: {len(d0)}+{len(d1)} differing indices, Z err {zerr:.2e}, "
+            print(f"[sweep] {name} [{forms}/{mfma}] seed {seed}: {len(d0)}+{len(d1)} differing indices, Z err {zerr:.2e}, "
                   f"row gaps {[float(g['gap0'][s][i]) for i in d0][:4]}")
-    print(f"[sweep] {name}: {bad} of {total} match indices differ from the reference over {len(g['seeds'])} unselected seeds "
-          f"(rate {bad / total:.2e}); worst Z error vs the oracle {worst_z:.2e}; unexplained {len(unexplained)}")
-    assert not unexplained, f"match indices differ where the reference's margin exceeds 2x the measured Z error: {unexplained[:8]}"
-    assert bad <= 0.002 * total, f"mismatch rate {bad / total:.2e} is implausibly high for margin noise"
+    print(f"[sweep] {name} [{forms}/{mfma}]: {bad} of {total} match indices differ from the reference over {len(g['seeds'])} unselected seeds "
+          f"(rate {bad / total:.2e}); worst Z error vs the oracle {worst_z:.2e} = x{worst_ratio:.2f} of the reference's own envelope on that seed "
+          f"(rms x{worst_rms_ratio:.2f}); worst fraction of Z outside 1e-4+1e-4|ref| {out_frac:.2e}; unexplained {len(unexplained)}")
+    assert not unexplained, f"match indices differ where the reference's margin exceeds min(2x the measured Z error, {TAU_CAP}): {unexplained[:8]}"
+    assert bad <= 0.0005 * total, f"mismatch rate {bad / total:.2e} is implausibly high for margin noise"
+
+
+def _matching(d, K):
+    from image_matching_amd.superglue.models.matching_test import Matching
+    m = Matching({"superpoint": util.sp_config(d, K), "superglue": util.sg_config(d)}).eval().to("cuda")
+    m.superpoint.load_state_dict(util.sp_sd(d))
+    m.superglue.load_state_dict(util.sg_sd(d))
+    return m
+
+
+def _account(name, what, results, n_images):
+    kp_bad = [x for r in results for x in r["kp_bad"]]
+    unexplained = [x for r in results for x in r["unexplained"]]
+    n_ref, n_diff = sum(r["n_ref"] for r in results), sum(r["diff"] for r in results)
+    print(f"[sweep e2e] {name} {what}: keypoint sets differ on {sum(r['kp_diff_images'] for r in results)} of {n_images} images (top-k boundary ties); "
+          f"{n_diff} differing rows over {n_ref} reference matches on the comparable pairs; unexplained {len(unexplained)}")
+    assert not kp_bad, f"keypoint sets differ beyond a top-k boundary tie (seed, side, |symmetric difference|, boundary gap): {kp_bad[:8]}"
+    assert not unexplained, f"end-to-end matches differ where the reference's margin exceeds tau: {unexplained[:8]}"
+    assert n_diff <= 0.002 * max(n_ref, 1), f"{n_diff} differing rows over {n_ref} reference matches is implausibly high for margin noise"
 
 
 @pytest.mark.parametrize("name", ["sweep_c3.npz", "sweep_c5.npz"])
 def test_unselected_seed_sweep_end_to_end(name):
-    """The same unselected seeds through the whole HIP path (images in, matched coordinate pairs out).  Keypoint SETS may
-    differ from the reference's only where the top-k boundary gap (last kept minus first dropped score) is below 2e-5 (the
-    score map carries ~6e-6 of fp32 noise); on pairs whose keypoint sets agree, every matched coordinate pair that differs
-    must be explained by the reference's margins (tau = 2e-3: the end-to-end Z error with HIP descriptors, measured
-    3e-4..6e-4 in round 1, x2 and rounded up)."""
-    from image_matching_amd.superglue.models.matching_test import Matching
+    """The same unselected seeds through the whole HIP path, one pair at a time (the drop-in Matching.forward: latency forms),
+    images in, matched coordinate pairs out; acceptance rule in util.sweep_compare_end_to_end (tau = 2e-3: the end-to-end Z
+    error with HIP descriptors, measured 3e-4..6e-4 in round 1, x2 and rounded up; below the 3e-3 cap of the test above)."""
     g = util.golden(name)
     H, W, d, K = (int(g[k]) for k in ("H", "W", "d", "K"))
-    m = Matching({"superpoint": util.sp_config(d, K), "superglue": util.sg_config(d)}).eval().to("cuda")
-    m.superpoint.load_state_dict(util.sp_sd(d))
-    m.superglue.load_state_dict(util.sg_sd(d))
-    tau, n_pairs_ref, n_diff, kp_diff_images, unexplained = 2e-3, 0, 0, 0, []
+    m = _matching(d, K)
+    results = []
     for s, seed in enumerate(g["seeds"]):
         x0, x1 = util.pair(int(seed), H, W)
         pred = m({"image0": x0.cuda(), "image1": x1.cuda()})
-        k0, k1 = pred["keypoints0"][0].cpu().numpy().astype(int), pred["keypoints1"][0].cpu().numpy().astype(int)
-        same = True
-        for side, k in ((0, k0), (1, k1)):
-            mine, ref = set(map(tuple, k)), set(map(tuple, g[f"kpts{side}"][s].astype(int)))
-            if mine != ref:
-                same = False
-                kp_diff_images += 1
-                gap = float(g["topk_gap"][s][side])
-                assert gap < 2e-5 and len(mine ^ ref) <= 8, \
-                    f"seed {seed} image {side}: keypoint sets differ by {len(mine ^ ref)} with a top-k boundary gap of {gap:.2e}"
-        if not same:
-            continue                      # indices are not comparable row by row when the sets differ
-        pos0 = {tuple(p): i for i, p in enumerate(g["kpts0"][s].astype(int))}
-        pos1 = {tuple(p): i for i, p in enumerate(g["kpts1"][s].astype(int))}
-        m0 = pred["matches0"][0].cpu().numpy()
-        mine = np.full(K, -1, np.int64)                       # my matches0 re-indexed in the reference's keypoint order
-        for i, j in enumerate(m0):
-            mine[pos0[tuple(k0[i])]] = pos1[tuple(k1[j])] if j >= 0 else -1
-        r0 = g["matches0"][s].astype(np.int64)
-        diff = np.nonzero(mine != r0)[0]
-        n_pairs_ref += int((r0 >= 0).sum())
-        n_diff += len(diff)
-        unexplained += [(int(seed), int(i), float(g["gap0"][s][i])) for i in diff if not _explainable0(i, g, s, tau)]
-    print(f"[sweep e2e] {name}: keypoint sets differ on {kp_diff_images} of {2 * len(g['seeds'])} images (top-k boundary ties); "
-          f"{n_diff} differing rows over {n_pairs_ref} reference matches on the comparable pairs; unexplained {len(unexplained)}")
-    assert not unexplained, f"end-to-end matches differ where the reference's margin exceeds {tau}: {unexplained[:8]}"
+        results.append(util.sweep_compare_end_to_end(g, s, pred["keypoints0"][0].cpu().numpy(), pred["keypoints1"][0].cpu().numpy(),
+                                                     pred["matches0"][0].cpu().numpy()))
+    _account(name, "pair by pair", results, 2 * len(g["seeds"]))
+
+
+@pytest.mark.parametrize("name,B", [("sweep_c3.npz", 32), ("sweep_c3.npz", 64), ("sweep_c5.npz", 8)])
+def test_unselected_seed_sweep_as_one_batched_call(name, B):
+    """VERDICT r2 #1b: the sweep seeds pushed through ONE imx_match_pairs call of B pairs -- the call, batch size and kernel forms
+    (gemm_x3, attention_x3, Winograd convolutions at B x 2 images) bench.py times -- and compared per pair with the reference's
+    outputs in the fixture.  B = 64 repeats the 32 C3 seeds in the second half of the batch (pairs never interact: both copies
+    must pass, and must be identical to each other)."""
+    g = util.golden(name)
+    H, W, d, K = (int(g[k]) for k in ("H", "W", "d", "K"))
+    n = len(g["seeds"])
+    m = _matching(d, K)
+    ims = [util.pair(int(seed), H, W) for seed in g["seeds"]]
+    i0 = torch.cat([ims[b % n][0] for b in range(B)]).cuda()
+    i1 = torch.cat([ims[b % n][1] for b in range(B)]).cuda()
+    out = m.match_batch(i0, i1)
+    torch.cuda.synchronize()
+    forms = {r[0]: r[3] for r in _forms_of_a_step(m, i0, i1)}
+    assert forms["qkv_proj"] == "gemm_x3:bf16x3" and forms["attention"] == "attention_x3:bf16x3" and forms["conv2a"] == "conv3x3_wino24:f32", forms
+    k0, k1, m0 = out["keypoints0"].cpu().numpy(), out["keypoints1"].cpu().numpy(), out["matches0"].cpu().numpy()
+    assert (out["counts0"].cpu().numpy() == K).all() and (out["counts1"].cpu().numpy() == K).all()
+    results = [util.sweep_compare_end_to_end(g, b % n, k0[b], k1[b], m0[b]) for b in range(B)]
+    _account(name, f"as one call of {B} pairs", results, 2 * B)
+    for b in range(n, B):
+        assert np.array_equal(k0[b], k0[b - n]) and np.array_equal(m0[b], m0[b - n]), f"pair {b} differs from its copy at {b - n}"
+
+
+def _forms_of_a_step(m, i0, i1):
+    eng = m._shared.get_engine([0, 1])
+    eng.timing_reset()
+    eng.set_timing(True)
+    m.match_batch(i0, i1)
+    rows = eng.timing_report(forms=True)
+    eng.set_timing(False)
+    eng.timing_reset()
+    return rows
 
 
 # ------------------------------------------------------------------------------------------ ragged / batched fuzz
@@ -276,8 +331,10 @@ def test_superglue_random_shapes_batches_and_counts_vs_oracle(seed):
         # fixtures (a masking bug shows up as O(1..100) errors, far outside 4x the reference's own fp32 distance)
         util.assert_fp64_anchored(Sb, ref["scores_in"][0], f64, f"pair {b} ({a}x{c} of {N0}x{N1}, B={B}) scores_in", c=4.0, c_max=6.0)
         Z = util.transport_Z(Sb, U[b], V[b], a, c, float(sd["bin_score"]))
-        Zr = superglue_ref.log_optimal_transport(torch.from_numpy(Sb.copy())[None], sd["bin_score"], iters=cfg["sinkhorn_iterations"])[0].numpy()
-        assert np.abs(Z - Zr).max() < 2e-3 * max(1.0, np.abs(Zr).max() / 50), f"pair {b}: Z differs from the oracle's on the same scores"
+        Sbt = torch.from_numpy(Sb.copy())[None]
+        Zr = superglue_ref.log_optimal_transport(Sbt, sd["bin_score"], iters=cfg["sinkhorn_iterations"])[0].numpy()
+        Z64 = superglue_ref.log_optimal_transport(Sbt.double(), sd["bin_score"].double(), iters=cfg["sinkhorn_iterations"])[0].numpy()
+        util.assert_fp64_anchored(Z, Zr, Z64, f"pair {b} ({a}x{c}) Z on the library's own scores")
         i0, i1, r0, r1 = superglue_ref.extract_matches(torch.from_numpy(Z)[None], cfg["match_threshold"])
         assert np.array_equal(m0[b, :a], i0[0].numpy()) and np.array_equal(m1[b, :c], i1[0].numpy()), f"pair {b}: matches differ on the library's own Z"
         assert (m0[b, a:] == -1).all() and (m1[b, c:] == -1).all() and (ms0[b, a:] == 0).all() and (ms1[b, c:] == 0).all()
@@ -286,19 +343,17 @@ def test_superglue_random_shapes_batches_and_counts_vs_oracle(seed):
 # ------------------------------------------------------------------------------------------ the bf16-pipe forms on ragged shapes
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 5])
 def test_superglue_random_shapes_on_the_throughput_forms(seed, monkeypatch):
-    """The same fuzz with the throughput forms forced at these small sizes (IMX_ATTN_SPLIT=0, IMX_GEMM_SMALL=0): attention_x3 with
+    """The same fuzz with the throughput forms forced at these small sizes ("latency_forms" = "off"): attention_x3 with
     partial key tiles, query blocks past the padded row count and per-pair device-side counts; the persistent gemm_x3 with row
     counts that are not multiples of its 128-row tile and fewer tiles than workgroups."""
-    monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
-    monkeypatch.setenv("IMX_GEMM_SMALL", "0")
+    monkeypatch.setenv("IMX_LATENCY_FORMS", "off")      # seeds the option of the handles created below
     test_superglue_random_shapes_batches_and_counts_vs_oracle(seed)
 
 
 def test_descriptor_dim_64_on_the_throughput_forms(monkeypatch):
     """descriptor_dim 64 with the throughput forms forced: gemm_x3's 64-column tiles (N = 64, 192), K = 32 / 64 (one and two
     chunks per tile), the fp32 attention kernel for head dim 16 beside bf16-pipe linear layers."""
-    monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
-    monkeypatch.setenv("IMX_GEMM_SMALL", "0")
+    monkeypatch.setenv("IMX_LATENCY_FORMS", "off")      # seeds the option of the handles created below
     test_descriptor_dim_64_superpoint_and_superglue_vs_reference_golden()
     test_descriptor_dim_64_matching_forward_and_ragged_counts_vs_oracle()
 
@@ -308,8 +363,7 @@ def test_zero_and_tiny_counts_inside_a_batch_on_the_throughput_forms(d, monkeypa
     """A batch whose pairs have zero, tiny and full device-side counts, on the throughput forms (attention_x3 for head dims 32 and
     64, gemm_x3): pairs with an empty side come back all -1 / 0, the others match what the same pair gives alone on the default
     (single-pair) forms, up to rounding of the scores."""
-    monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
-    monkeypatch.setenv("IMX_GEMM_SMALL", "0")
+    monkeypatch.setenv("IMX_LATENCY_FORMS", "off")      # seeds the option of the handles created below
     B, N = 4, 200
     g = torch.Generator().manual_seed(7 + d)
     t = {"keypoints0": torch.rand(B, N, 2, generator=g) * torch.tensor([639.0, 479.0]), "keypoints1": torch.rand(B, N, 2, generator=g) * torch.tensor([639.0, 479.0]),
@@ -323,8 +377,7 @@ def test_zero_and_tiny_counts_inside_a_batch_on_the_throughput_forms(d, monkeypa
     tc = {k: v.cuda() for k, v in t.items()}
     m0, m1, ms0, ms1 = _run(eng, tc, (1, 1, 480, 640), torch.from_numpy(n0).cuda(), torch.from_numpy(n1).cuda())
     assert np.isfinite(ms0).all() and np.isfinite(ms1).all()
-    monkeypatch.delenv("IMX_ATTN_SPLIT")
-    monkeypatch.delenv("IMX_GEMM_SMALL")
+    eng.set_option("latency_forms", "auto")             # the single-pair runs below take the default (latency) forms
     for b in range(B):
         a, c = int(n0[b]), int(n1[b])
         assert (m0[b, a:] == -1).all() and (m1[b, c:] == -1).all() and (ms0[b, a:] == 0).all() and (ms1[b, c:] == 0).all()

@@ -46,6 +46,21 @@ def test_ransac_recovers_transform_and_matches_host_restatement():
         assert inl[b][matched & ~bad].all() and not inl[b][matched & bad].any() and not inl[b][~matched].any()
 
 
+def test_ransac_beyond_the_lds_staging_matches_host_restatement():
+    """More than 8192 keypoint slots (--max_keypoints -1 on a large image): the compacted coordinates no longer fit LDS and are
+    staged in HBM -- same inlier mask and model as the host restatement."""
+    from image_matching_amd.engine import Engine
+    from oracle import ransac_ref
+    eng = Engine(util.sp_config(128, -1), util.sg_config(128), "cuda")
+    c0, c1, cm, Mtrue = _case(7, 10000, 0.15, 1.05, (20, -11))
+    M, inl, ninl = eng.estimate_affine_partial(torch.from_numpy(c0)[None].cuda(), torch.from_numpy(c1)[None].cuda(),
+                                               torch.from_numpy(cm)[None].cuda(), ransac_thresh=7.0, hypotheses=128, seed=9)
+    Mr, maskr, nr = ransac_ref.estimate_affine_partial(c0, c1, cm, b=0, thresh=7.0, hypotheses=128, seed=9)
+    assert np.array_equal(inl[0].cpu().numpy(), maskr) and int(ninl[0]) == nr
+    np.testing.assert_allclose(M[0].cpu().numpy(), Mr, atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(M[0].cpu().numpy()[:, :2], Mtrue[:, :2], atol=2e-3)
+
+
 def test_ransac_too_few_matches_and_counts():
     from image_matching_amd.engine import Engine
     eng = Engine(util.sp_config(128, 64), util.sg_config(128), "cuda")

@@ -155,6 +155,30 @@ def test_batched_pairs_equal_single_pair_runs():
             "batched pairs must be bit-identical to single-pair runs"
 
 
+def test_bad_option_is_refused_and_forms_are_reported():
+    """imx_set_option refuses unknown keys / values (nothing silently falls back), and imx_timing_form names the form that ran."""
+    from image_matching_amd.engine import ImxError
+    eng, L = _engine()
+    with pytest.raises(ImxError):
+        eng.set_option("mfma", "fp16")
+    with pytest.raises(ImxError):
+        eng.set_option("no_such_option", "1")
+    eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(128))
+    g = util.golden("sg_small.npz")
+    t = {k: torch.from_numpy(g[k]).cuda() for k in KEYS}
+    seen = {}
+    for forms, mfma in (("off", "x3"), ("off", "f32"), ("on", "x3")):
+        eng.set_option("latency_forms", forms).set_option("mfma", mfma)
+        eng.timing_reset()
+        eng.set_timing(True)
+        _run(eng, t, (1, 1, 120, 160))
+        seen[(forms, mfma)] = {r[0]: r[3] for r in eng.timing_report(forms=True)}
+        eng.set_timing(False)
+    assert seen[("off", "x3")]["qkv_proj"] == "gemm_x3:bf16x3" and seen[("off", "x3")]["attention"] == "attention_x3:bf16x3"
+    assert seen[("off", "f32")]["qkv_proj"] == "gemm_tiled:f32" and seen[("off", "f32")]["attention"] == "attention:f32"
+    assert seen[("on", "x3")]["qkv_proj"] == "gemm_small:f32" and seen[("on", "x3")]["attention"] == "attention_split:f32"
+
+
 def test_attention_key_split_and_throughput_forms_agree(monkeypatch):
     """Single pairs take the key-split attention form (32-query workgroups, four waves splitting the keys), batches the
     throughput form.  Both must give the reference's matches on the full-size fixtures (the default B = 1 runs above use the
@@ -165,40 +189,28 @@ def test_attention_key_split_and_throughput_forms_agree(monkeypatch):
     eng, L = _engine(d)
     eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(d))
     out = {}
-    for split in ("1", "0"):
-        monkeypatch.setenv("IMX_ATTN_SPLIT", split)
-        monkeypatch.setenv("IMX_GEMM_SMALL", split)          # likewise the small-M (latency) vs weights-stationary GEMM
-        out[split] = _run(eng, data, (1, 1, H, W))
-        assert np.array_equal(out[split][0], g["matches0"]) and np.array_equal(out[split][1], g["matches1"]), f"IMX_ATTN_SPLIT={split}"
-    np.testing.assert_allclose(out["1"][2], out["0"][2], rtol=0, atol=2e-5)
-    monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
-    monkeypatch.setenv("IMX_GEMM_SMALL", "0")
+    for forms in ("on", "off"):                      # key-split attention + small-M GEMM vs the throughput forms, same handle
+        eng.set_option("latency_forms", forms)
+        assert eng.get_option("latency_forms") == forms
+        out[forms] = _run(eng, data, (1, 1, H, W))
+        assert np.array_equal(out[forms][0], g["matches0"]) and np.array_equal(out[forms][1], g["matches1"]), f"latency_forms={forms}"
+    np.testing.assert_allclose(out["on"][2], out["off"][2], rtol=0, atol=2e-5)
+    monkeypatch.setenv("IMX_LATENCY_FORMS", "off")   # seeds the option of the handles created below (imx_create reads it once)
     for name in ("c3_pair_s55.npz", "c5_pair_s19.npz"):
         test_full_size_matches_bit_exact_vs_reference_golden(name)
 
 
 @pytest.mark.parametrize("mfma", ["f32", "x3"])
 def test_throughput_forms_on_both_matrix_pipes(mfma, monkeypatch):
-    """The throughput forms run their fp32 products either on the fp32 MFMA (IMX_MFMA=f32) or as six bf16 term products on the
-    bf16 MFMA (attention_x3, gemm_x3; IMX_MFMA=x3 also sends the K = 128 products there, which by default stay
-    weights-stationary).  Both must reproduce the reference's matches on the full-size fixtures and pass the float64-anchored
-    checks on scores_in and Z -- the split is exact, so the bf16 pipe is held to the same bar as the fp32 one."""
-    monkeypatch.setenv("IMX_MFMA", mfma)
-    monkeypatch.setenv("IMX_ATTN_SPLIT", "0")
-    monkeypatch.setenv("IMX_GEMM_SMALL", "0")
-    for name in ("c3_pair_s59.npz", "c3_pair_s55.npz"):
+    """The throughput forms run their fp32 products either on the fp32 MFMA ("mfma" = "f32": attention_kernel, the tiled GEMM of
+    gemm.hip) or as six bf16 term products on the bf16 MFMA (attention_x3, gemm_x3; the default).  Both must reproduce the
+    reference's matches on the full-size fixtures (head dims 32 and 64) and pass the float64-anchored checks on scores_in and
+    Z -- the split is exact, so the bf16 pipe is held to the same bar as the fp32 one."""
+    monkeypatch.setenv("IMX_MFMA", mfma)             # the environment seeds the options of every handle created below
+    monkeypatch.setenv("IMX_LATENCY_FORMS", "off")
+    for name in ("c3_pair_s59.npz", "c3_pair_s55.npz", "c5_pair_s19.npz"):
         test_full_size_matches_bit_exact_vs_reference_golden(name)
     test_small_dense_and_matches_vs_reference_golden()
-
-
-@pytest.mark.parametrize("mode", ["1", "4"])
-def test_every_attention_variant_matches_bit_exact(mode, monkeypatch):
-    """IMX_ATTN selects the attention kernel form (1: one K/V tile in flight, 3 = default: two tiles in flight, 4: 64-key
-    staged tiles).  Every form must give the reference's matches on a C3 and the C5 fixture (head sizes 32 and 64)."""
-    monkeypatch.setenv("IMX_ATTN", mode)
-    monkeypatch.setenv("IMX_ATTN_SPLIT", "0")          # the A/B switch selects among the throughput forms
-    for name in ("c3_pair_s59.npz", "c5_pair_s19.npz"):
-        test_full_size_matches_bit_exact_vs_reference_golden(name)
 
 
 @pytest.mark.parametrize("name", ["c3_pair_s59.npz", "c5_pair_s19.npz"])
@@ -223,11 +235,3 @@ def test_full_size_transport_marginals(name):
     np.testing.assert_allclose(P[:, :K].sum(0), 1.0, rtol=3e-4)
     np.testing.assert_allclose(P[:, K].sum(), float(K), rtol=3e-4)
     assert np.all(P[:K].sum(1) > 0.5) and np.all(P[:K].sum(1) < 1.5)
-
-
-def test_tiled_gemm_form_matches_bit_exact(monkeypatch):
-    """IMX_GEMM=tiled keeps every 1x1-conv product on the tiled kernels of gemm.hip (the default sends K in {128, 256},
-    N % 128 == 0 to the weights-stationary persistent form, gemm_ws.hip).  Both must give the reference's matches."""
-    monkeypatch.setenv("IMX_GEMM", "tiled")      # (also keeps the small-M latency form out: every product on gemm.hip)
-    for name in ("c3_pair_s59.npz", "c5_pair_s19.npz"):
-        test_full_size_matches_bit_exact_vs_reference_golden(name)

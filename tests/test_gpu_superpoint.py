@@ -174,7 +174,7 @@ def test_dense_forward_for_label_export_vs_reference_golden():
 
 
 def test_direct_conv_fallback_vs_reference_golden(monkeypatch):
-    """IMX_CONV=direct (read at imx_create) puts every 3x3 layer on the direct implicit-GEMM kernel -- the A/B reference of
+    """"conv" = "direct" (here seeded through IMX_CONV, which imx_create reads once) puts every 3x3 layer on the direct implicit-GEMM kernel -- the A/B reference of
     the default Winograd F(2x4,3x3) kernels and the fallback for shapes those reject.  It must reproduce the reference's
     dense stages and keypoints on the ragged fixture (123x165: partial tiles on both axes) and on the 120x160 one."""
     monkeypatch.setenv("IMX_CONV", "direct")
@@ -190,16 +190,13 @@ def test_direct_conv_fallback_vs_reference_golden(monkeypatch):
         util.assert_close(_nchw(eng.fetch("semi")), g["semi"], "semi (direct)")
 
 
-@pytest.mark.parametrize("form", ["staged", "fused"])
-@pytest.mark.parametrize("radius", [1, 2, 3, 4, 6])
-def test_nms_every_radius_bit_exact_vs_oracle(radius, form, monkeypatch):
-    """simple_nms is compare-only, so the kernels (radius <= 4: the staged three-kernel form with bit-row masks, default, and the
-    fused register-strip form, IMX_NMS=fused; generic form above) must reproduce the oracle bit for bit on the reference's own
-    score map, for every --nms_radius, on partial tiles too -- and on a batch of wider maps whose width is not a multiple of the
-    64-column tile or of the 32-bit mask words."""
+@pytest.mark.parametrize("radius", [1, 2, 3, 4, 5, 6, 9, 13])
+def test_nms_every_radius_bit_exact_vs_oracle(radius):
+    """simple_nms is compare-only, so both forms (radius <= 4: the staged three-kernel form with bit-row masks; any other radius:
+    the generic separable passes -- the reference accepts any --nms_radius, superpoint_test.py:7-22) must reproduce the oracle bit
+    for bit on the reference's own score map, on partial tiles too -- and on a batch of wider maps whose width is not a multiple
+    of the 64-column tile or of the 32-bit mask words."""
     from oracle import superpoint_ref
-    if form == "fused":
-        monkeypatch.setenv("IMX_NMS", "fused")
     g = util.golden("sp_ragged.npz")
     eng, L = _engine(128, -1)
     sm = torch.from_numpy(g["score_map"])
@@ -213,3 +210,21 @@ def test_nms_every_radius_bit_exact_vs_oracle(radius, form, monkeypatch):
     out = eng.op_nms(t, radius).cpu().numpy()
     ref = superpoint_ref.simple_nms(t, radius).numpy()
     assert np.array_equal(out, ref), f"radius {radius} (3 x 77 x 203, ties): {(out != ref).sum()} pixels differ"
+
+
+def test_max_keypoints_beyond_the_lds_sort_vs_oracle():
+    """The reference takes any max_keypoints (superpoint_test.py:33-37, :146-149).  Above 16384 the top-k sort of kp_topk no longer
+    fits LDS and runs out of HBM: with nms_radius 1 and a low threshold a 480x640 image has > 25000 candidates, of which the
+    best 20000 are kept -- same set and scores as the oracle's torch.topk (order canonicalised: near-tied scores may swap)."""
+    from oracle import superpoint_ref
+    d, K, H, W = 128, 20000, 480, 640
+    cfg = util.sp_config(d, K, nms_radius=1, keypoint_threshold=0.0005)
+    from image_matching_amd import _lib as L
+    from image_matching_amd.engine import Engine
+    eng = Engine(cfg, util.sg_config(d), "cuda")
+    sd = util.sp_sd(d)
+    eng.load_state_dict(L.NET_SUPERPOINT, sd)
+    x = util.pair(59, H, W)[0]
+    ref = superpoint_ref.superpoint_forward(x, sd, cfg)
+    assert len(ref["keypoints"][0]) == K, "the case must exercise the top-k (more candidates than max_keypoints)"
+    _check_against(eng, x, [ref["keypoints"][0]], [ref["scores"][0]], [ref["descriptors"][0]], exact_order=False)

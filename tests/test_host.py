@@ -69,7 +69,7 @@ def test_create_rejects_bad_config():
     lib = _lib.load_library()
     h = ctypes.c_void_p()
     cfg = _lib.ImxConfig()
-    cfg.descriptor_dim, cfg.kenc_n, cfg.num_gnn_layers = 100, 3, 18
+    cfg.descriptor_dim, cfg.kenc_n, cfg.num_gnn_layers = 102, 3, 18      # not a multiple of 4
     assert lib.imx_create(0, ctypes.byref(cfg), ctypes.byref(h)) != 0
     assert b"descriptor_dim" in lib.imx_last_error(None)
 

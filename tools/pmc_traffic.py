@@ -10,7 +10,11 @@ import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-NAMES = {"conv1ab_pool": r"conv1ab_wino24", "attention": r"attention_kernel"}
+# bench.py kernel name -> pattern on the rocprofv3 kernel name (tools/rocpd_pmc.py: short()).  The gemm_x3 instantiations are told
+# apart by their template arguments <BN, RES, RELU>: mlp.0 is the only one with ReLU, mlp.3 the only 128-column one with a residual;
+# <128, false, false> averages q|k|v (18 launches) with final_proj and convDb (1 each)
+NAMES = {"conv1ab_pool": r"conv1ab_wino24", "attention": r"attention_x3_kernel|attention_kernel", "sinkhorn": r"sinkhorn_slab",
+         "gnn_mlp1": r"gemm_x3<128, false, true>", "gnn_mlp2": r"gemm_x3<128, true, false>", "qkv_proj": r"gemm_x3<128, false, false>"}
 
 
 def table(path):
