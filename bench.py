@@ -368,7 +368,7 @@ def roofline_block(rows, wl, B, steps, dt, lib_build, workload):
     rf["fp32_equivalent_pair_tflops"] = round(exe_step / step_s / 1e12, 2)
     rf["bf16x3_kernels"] = sorted(k for k, v in pipe_of.items() if v == "bf16x3")
     rf["algorithmic_pair_ratio"] = round(alg_step / step_s / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)
-    rf["launches_per_step"] = int(round(sum(per_step.values())))
+    rf["timed_groups_per_step"] = int(round(sum(per_step.values())))      # one group = one RUN() of imx_api.cpp (the Sinkhorn group holds 60 kernel launches)
     kern = {}
     for n, (launches, ms, forms) in by.items():
         k = {"launches": launches, "ms_per_step": round(ms / steps, 4)}

@@ -41,6 +41,11 @@ __device__ __forceinline__ LSE wave_lse(LSE a) {
   return a;
 }
 __device__ __forceinline__ float lse_value(const LSE& a) { return a.m + logf(a.s); }
+// The two-pass forms below evaluate exp(t - mx) as exp2(fma(t, LOG2E, ml)) with ml = -(mx * LOG2E) ROUNDED: every term of a sum
+// then carries the common factor 2^d, d = fma(mx, LOG2E, ml) = the product's rounding error (exact; up to 1.5e-5 at |mx| ~ 250,
+// i.e. a 1e-5 bias of that log-sum-exp -- round 3: on a 7 x 64 transport problem with |Z| ~ 230 it put Z 3.3x further from float64
+// than the oracle's fp32 result).  It is removed once per sum: 2^-d = 1 - d ln 2 to 1e-10.
+__device__ __forceinline__ float lse_unbias(float sum, float mx, float ml) { return fmaf(sum, -0.69314718f * fmaf(mx, LOG2E, ml), sum); }
 
 // ------------------------------------------------------------------ kenc layer 0
 __global__ __launch_bounds__(256) void kenc0_kernel(Kenc0Args a, float scaling) {
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
         float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        acc = LSE{mx, sum};
+        acc = LSE{mx, lse_unbias(sum, mx, ml)};
       } else if (jlo < n) {
         float4 x[4];
 #pragma unroll
@@ -239,6 +244,7 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
           const float ml = -mx * LOG2E;
 #pragma unroll
           for (int e = 0; e < 16; ++e) sum += __builtin_amdgcn_exp2f(fmaf(t[e], LOG2E, ml));      // exp(t - mx); -inf -> 0
+          sum = lse_unbias(sum, mx, ml);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
         const f32x4 a4 = __builtin_elementwise_fma(t4[q], l2e, ml4);
         s4 += (f32x4){__builtin_amdgcn_exp2f(a4[0]), __builtin_amdgcn_exp2f(a4[1]), __builtin_amdgcn_exp2f(a4[2]), __builtin_amdgcn_exp2f(a4[3])};
       }
-      pb[j] = make_float2(mx, (s4[0] + s4[1]) + (s4[2] + s4[3]));
+      pb[j] = make_float2(mx, lse_unbias((s4[0] + s4[1]) + (s4[2] + s4[3]), mx, ml));
     }
   }
   for (int j = fastcol ? n + tid : tid; j <= n; j += 64 * NW) {
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) sum += __builtin_amdgcn_exp2f(fmaf(t[r], LOG2E, ml));
-    pb[j] = make_float2(mx, sum);
+    pb[j] = make_float2(mx, lse_unbias(sum, mx, ml));
   }
 }
 
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_vmerge(SinkhornArgs a, const fl
         float sum = t.s * __builtin_amdgcn_exp2f(fmaf(t.m, LOG2E, ml));          // exp2(-inf) = 0 for an empty accumulator
 #pragma unroll
         for (int k = 0; k < 4; ++k) sum = fmaf(q[k].y, __builtin_amdgcn_exp2f(fmaf(q[k].x, LOG2E, ml)), sum);
-        t = LSE{nm, sum};
+        t = LSE{nm, lse_unbias(sum, nm, ml)};
       }
     }
   }
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_vmerge(SinkhornArgs a, const fl
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) sum = fmaf(ps[k][c], __builtin_amdgcn_exp2f(fmaf(pm[k][c], LOG2E, ml)), sum);
-    t = LSE{nm, sum};
+    t = LSE{nm, lse_unbias(sum, nm, ml)};
     const float norm = -logf((float)(m + n));
     const float log_nu = j < n ? norm : logf((float)m) + norm;
     a.v[(size_t)b * (a.N1p + 1) + j] = log_nu - lse_value(t);

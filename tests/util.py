@@ -62,19 +62,44 @@ def assert_fp64_anchored(hip, ref32, f64, what, c=2.0, c_max=2.5):
     the reference module (tests/golden/make_golden.py: sg_dense_f64) and the HIP result must be as close to it
     as the reference's fp32 result is: rms error within a factor c, max error within c_max -- neither scaled by the
     tensor.  (The maximum over ~10^5 samples of a heavy-tailed error is a noisy statistic: the SAME arithmetic under two
-    attention tilings measured 1.9x and 2.2x on C5 while the rms moved 1.46x -> 1.63x; the rms is the robust one.)"""
-    hip, ref32, f64 = (np.asarray(x.detach().cpu() if isinstance(x, torch.Tensor) else x, dtype=np.float64) for x in (hip, ref32, f64))
-    assert hip.shape == f64.shape == ref32.shape, f"{what}: shapes {hip.shape} {ref32.shape} {f64.shape}"
-    eh, er = np.abs(hip - f64), np.abs(ref32 - f64)
-    mh, mr = eh.max(), er.max()
-    rh, rr = np.sqrt((eh ** 2).mean()), np.sqrt((er ** 2).mean())
+    attention tilings measured 1.9x and 2.2x on C5 while the rms moved 1.46x -> 1.63x; the rms is the robust one.)
+    `ref32` may be a LIST of fp32 evaluations of the same quantity (e.g. the oracle on permuted inputs): the envelope is then the
+    largest of their errors -- one fp32 evaluation of a small problem is a single draw of the rounding noise and can be
+    several times luckier than the next (round 3: a 7 x 64 transport problem whose oracle fp32 error was 4e-5 rms where
+    1e-4 is typical at that |Z|)."""
+    as64 = lambda x: np.asarray(x.detach().cpu() if isinstance(x, torch.Tensor) else x, dtype=np.float64)
+    refs = [as64(r) for r in (ref32 if isinstance(ref32, (list, tuple)) else [ref32])]
+    hip, f64 = as64(hip), as64(f64)
+    assert hip.shape == f64.shape == refs[0].shape, f"{what}: shapes {hip.shape} {refs[0].shape} {f64.shape}"
+    eh = np.abs(hip - f64)
+    mh, rh = eh.max(), np.sqrt((eh ** 2).mean())
+    mr = max(np.abs(r - f64).max() for r in refs)
+    rr = max(np.sqrt(((r - f64) ** 2).mean()) for r in refs)
     print(f"[fp64-anchored] {what}: max err hip {mh:.3e} vs reference-fp32 {mr:.3e} (x{mh / mr:.2f}); "
           f"rms hip {rh:.3e} vs {rr:.3e} (x{rh / rr:.2f}); max|f64| {np.abs(f64).max():.1f}; "
-          f"outside 1e-4+1e-4|ref|: hip-vs-reference {outside_fraction(hip, ref32):.2e}, hip-vs-f64 {outside_fraction(hip, f64):.2e}, "
-          f"reference-vs-f64 {outside_fraction(ref32, f64):.2e}")
+          f"outside 1e-4+1e-4|ref|: hip-vs-reference {outside_fraction(hip, refs[0]):.2e}, hip-vs-f64 {outside_fraction(hip, f64):.2e}, "
+          f"reference-vs-f64 {outside_fraction(refs[0], f64):.2e}" + (f" (envelope over {len(refs)} fp32 evaluations)" if len(refs) > 1 else ""))
     assert rh <= c * rr and mh <= c_max * mr, (f"{what}: HIP is further from the float64 evaluation than {c}x (rms) / {c_max}x (max) the "
                                                f"reference's own fp32 result: max {mh:.3e} vs {mr:.3e}, rms {rh:.3e} vs {rr:.3e}")
     return mh / mr, rh / rr
+
+
+def sinkhorn_fp32_evaluations(S, alpha, iters, n_perm=4, seed=0):
+    """The oracle's fp32 optimal transport on S and on `n_perm` row/column permutations of S (mapped back): log-domain Sinkhorn is
+    permutation-equivariant, so these are independent draws of the SAME computation's fp32 rounding noise; plus the float64 result."""
+    from oracle import superglue_ref
+    St = torch.as_tensor(np.ascontiguousarray(S))[None]
+    a = torch.as_tensor(alpha)
+    Z64 = superglue_ref.log_optimal_transport(St.double(), a.double(), iters=iters)[0].numpy()
+    outs = [superglue_ref.log_optimal_transport(St, a.float(), iters=iters)[0].numpy()]
+    g = torch.Generator().manual_seed(seed)
+    m, n = S.shape
+    for _ in range(n_perm):
+        pr, pc = torch.randperm(m, generator=g), torch.randperm(n, generator=g)
+        Zp = superglue_ref.log_optimal_transport(St[:, pr][:, :, pc], a.float(), iters=iters)[0]
+        ir, ic = torch.cat([torch.argsort(pr), torch.tensor([m])]), torch.cat([torch.argsort(pc), torch.tensor([n])])   # the dustbins stay last
+        outs.append(Zp[ir][:, ic].numpy())
+    return outs, Z64
 
 
 def outside_fraction(a, b, atol=ATOL, rtol=RTOL):
