@@ -14,7 +14,8 @@ struct Options {
                            //         that form), 1 = "f32" (fp32 MFMA everywhere: the A/B reference of the parity tests)
   int latency_forms = -1;  // "latency_forms": -1 = "auto" (gemm_small for M <= 4096 rows, key-split attention for grids of
                            //         <= 256 workgroups), 0 = "off" (results do not depend on the batch size bit for bit), 1 = "on"
-  int conv_direct = 0;     // "conv": 0 = "wino" (Winograd F(2x4,3x3); direct only for shapes it rejects), 1 = "direct"
+  int conv_direct = 0;     // "conv": 0 = "wino" (Winograd F(2x4,3x3) on the fp32 MFMA; direct only for shapes it rejects), 1 = "direct"
+  int conv_wx3 = 0;        // "conv" = "wx3": the Winograd layers after the first as six bf16 term products on the bf16 pipe (conv3x3_wx3.hip)
 };
 
 // The form a launcher picked ("gemm_x3:bf16x3", "conv3x3_wino24:f32", ...: kernel family, then the matrix pipe it runs on or
@@ -41,6 +42,8 @@ struct ConvArgs {
   int split;
   const float* w;     // [9][Cin][Cout]  (BN folded)
   const float* wu24;  // Winograd F(2x4,3x3) weights G2 g G4^T: [Cout/64][Cin/8][12 quads][4 co-blocks][64 lanes][4] (conv1ab_wino24.hip, conv3x3_wino24.hip)
+  const void* wux3;   // the same Winograd weights as three bf16 planes per value in MFMA A-fragment order (conv3x3_wx3.hip):
+                      // [Cout/64][Cin/16][4 rows i][6 columns j][2 co blocks][3 planes][64 lanes][8]
   const float* bias;  // [Cout]
   const float* w1;    // FIRST mode: conv1a weights [9][64] and bias [64] (BN folded), Cin == 64
   const float* b1;
@@ -59,6 +62,11 @@ hipError_t launch_conv1ab_wino24(const ConvArgs& a, hipStream_t s); // fused con
 // Cin % 64 == 0, Cout % 64 == 0, not first.
 bool conv3x3_wino24_supported(const ConvArgs& a);                   // false (e.g. an image of >= 2 GB per layer): callers fall back to the direct form
 hipError_t launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s); // Winograd F(2x4,3x3), persistent, in-stream transform
+
+// Winograd F(2x4,3x3) with every fp32 product as six bf16 term products on the bf16 matrix pipe; channel-blocked input,
+// Cin % 16 == 0, Cout % 64 == 0, not first
+bool conv3x3_wx3_supported(const ConvArgs& a);
+hipError_t launch_conv3x3_wx3(const ConvArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- GEMM (MFMA fp32): 1x1 conv / linear
 // out[r][n] = act( sum_k A[r][k] * W[k][n] + bias[n] ) (+ res[r][n]);  A = [a0 | a1] column concat.

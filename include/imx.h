@@ -210,7 +210,9 @@ const char* imx_timing_form(imx_handle_t h, int index);
  *   "latency_forms"  "auto" (default) one or two pairs take the latency forms of the linear layers (M <= 4096 rows) and of
  *                           the attention (grids of <= 256 workgroups); "off" never (results then do not depend on the batch
  *                           size bit for bit); "on" whenever the shape allows;
- *   "conv"           "wino" (default) Winograd F(2x4,3x3); "direct" the direct implicit-GEMM kernel for every 3x3 layer.
+ *   "conv"           "wino" (default) Winograd F(2x4,3x3) on the fp32 MFMA; "wx3" the same arithmetic with its products as six bf16
+ *                           term products on the bf16 pipe for every 3x3 layer after the first (as accurate; slower as of this build);
+ *                           "direct" the direct implicit-GEMM kernel for every 3x3 layer.
  * Unknown keys / values are an error.  imx_get_option returns the current value ("" for an unknown key); the pointer is valid
  * until the next call on the handle. */
 int imx_set_option(imx_handle_t h, const char* key, const char* value);

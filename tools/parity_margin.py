@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """How much of the 1e-4 + 1e-4*|ref| tolerance do the shipped kernels use?  Dense SuperPoint stages against the reference
-goldens (tests/golden/sp_small.npz, sp_ragged.npz), for the default kernels and the F(2x2,3x3) fallbacks."""
+goldens (tests/golden/sp_small.npz, sp_ragged.npz), for the default kernels (Winograd on the bf16 pipe), the same arithmetic on the fp32 MFMA, and the direct form."""
 import os
 import subprocess
 import sys
@@ -31,7 +31,8 @@ for name in ("sp_small.npz", "sp_ragged.npz"):
         out.append("%%s %%.3f" %% (k, r))
     print(name, " ".join(out))
 ''' % ROOT
-for label, env in (("default (F(2x4,3x3))", {}), ("IMX_CONV=direct", {"IMX_CONV": "direct"})):
+for label, env in (("default (F(2x4,3x3) on the fp32 MFMA)", {}), ("IMX_CONV=wx3 (F(2x4,3x3), fp32 products as six bf16 term products)", {"IMX_CONV": "wx3"}),
+                   ("IMX_CONV=direct", {"IMX_CONV": "direct"})):
     r = subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, **env), capture_output=True, text=True)
     print(label)
     print("  " + "\n  ".join(l for l in r.stdout.strip().splitlines()) if r.returncode == 0 else r.stderr[-800:])
