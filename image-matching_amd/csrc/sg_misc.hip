@@ -243,8 +243,8 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
         if (mx > -INFINITY) {
           const float ml = -mx * LOG2E;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) sum += __builtin_amdgcn_exp2f(fmaf(t[e], LOG2E, ml));      // exp(t - mx); -inf -> 0
-          sum = lse_unbias(sum, mx, ml);
+          for (int e = 0; e < 16; ++e) sum += __builtin_amdgcn_exp2f((t[e] - mx) * LOG2E);      // exp(t - mx); -inf -> 0
+          (void)ml;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -314,8 +314,9 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
     const float ml = -mx * LOG2E;                                     // rows >= 1: mx is finite
     float sum = 0.f;
 #pragma unroll
-    for (int r = 0; r < R; ++r) sum += __builtin_amdgcn_exp2f(fmaf(t[r], LOG2E, ml));
-    pb[j] = make_float2(mx, lse_unbias(sum, mx, ml));
+    for (int r = 0; r < R; ++r) sum += __builtin_amdgcn_exp2f((t[r] - mx) * LOG2E);
+    (void)ml;
+    pb[j] = make_float2(mx, sum);
   }
 }
 
@@ -344,10 +345,11 @@ __global__ __launch_bounds__(1024) void sinkhorn_vmerge(SinkhornArgs a, const fl
       const float nm = fmaxf(fmaxf(t.m, fmaxf(q[0].x, q[1].x)), fmaxf(q[2].x, q[3].x));
       if (nm > -INFINITY) {
         const float ml = -nm * LOG2E;
-        float sum = t.s * __builtin_amdgcn_exp2f(fmaf(t.m, LOG2E, ml));          // exp2(-inf) = 0 for an empty accumulator
+        float sum = t.s * __builtin_amdgcn_exp2f((t.m - nm) * LOG2E);          // exp2(-inf) = 0 for an empty accumulator
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sum = fmaf(q[k].y, __builtin_amdgcn_exp2f(fmaf(q[k].x, LOG2E, ml)), sum);
-        t = LSE{nm, lse_unbias(sum, nm, ml)};
+        for (int k = 0; k < 4; ++k) sum = fmaf(q[k].y, __builtin_amdgcn_exp2f((q[k].x - nm) * LOG2E), sum);
+        (void)ml;
+        t = LSE{nm, sum};
       }
     }
   }
@@ -361,8 +363,9 @@ __global__ __launch_bounds__(1024) void sinkhorn_vmerge(SinkhornArgs a, const fl
     const float ml = -nm * LOG2E;                                                  // finite: slab 0 always contributes
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) sum = fmaf(ps[k][c], __builtin_amdgcn_exp2f(fmaf(pm[k][c], LOG2E, ml)), sum);
-    t = LSE{nm, lse_unbias(sum, nm, ml)};
+    for (int k = 0; k < 16; ++k) sum = fmaf(ps[k][c], __builtin_amdgcn_exp2f((pm[k][c] - nm) * LOG2E), sum);
+    (void)ml;
+    t = LSE{nm, sum};
     const float norm = -logf((float)(m + n));
     const float log_nu = j < n ? norm : logf((float)m) + norm;
     a.v[(size_t)b * (a.N1p + 1) + j] = log_nu - lse_value(t);
