@@ -14,7 +14,7 @@ SP_VARIANT_BN, SP_VARIANT_OFFICIAL = 0, 1
 EXPORTS = (
     "imx_create", "imx_destroy", "imx_last_error", "imx_load_weight", "imx_finalize_weights",
     "imx_superpoint_detect", "imx_superpoint_describe", "imx_superpoint_dense", "imx_superglue_forward",
-    "imx_match_pairs", "imx_pack_records", "imx_estimate_affine_partial", "imx_knn_ratio_match", "imx_ingest_resize_u8", "imx_warp_affine_u8", "imx_op_nms", "imx_set_debug", "imx_debug_fetch", "imx_set_timing",
+    "imx_match_pairs", "imx_pack_records", "imx_gather_records", "imx_estimate_affine_partial", "imx_knn_ratio_match", "imx_ingest_resize_u8", "imx_warp_affine_u8", "imx_op_nms", "imx_set_debug", "imx_debug_fetch", "imx_set_timing",
     "imx_timing_report", "imx_timing_reset", "imx_timing_form", "imx_set_option", "imx_get_option", "imx_version",
 )
 
@@ -71,6 +71,7 @@ def load_library():
                                           vp, vp, f32p, f32p, vp]
     lib.imx_match_pairs.argtypes = [vp, f32p, f32p, i32, i32, i32] + [vp] * 12 + [vp]
     lib.imx_pack_records.argtypes = [vp, vp, i32, i32] + [vp] * 9 + [i32, vp]
+    lib.imx_gather_records.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp]
     lib.imx_estimate_affine_partial.argtypes = [vp, f32p, f32p, vp, vp, i32, i32, ctypes.c_float, i32, ctypes.c_uint32, f32p, vp, vp, vp]
     lib.imx_knn_ratio_match.argtypes = [vp, i32, f32p, i64, i64, i64, vp, i32, f32p, i64, i64, i64, vp, i32, ctypes.c_float, vp, f32p, f32p, vp]
     lib.imx_ingest_resize_u8.argtypes = [vp, vp, i32, i32, i32, i64, f32p, i32, i32, vp]

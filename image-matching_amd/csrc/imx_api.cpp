@@ -6,6 +6,7 @@
 #include "imx_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cctype>
 #include <cmath>
@@ -1052,6 +1053,74 @@ int imx_pack_records(imx_handle_t h, const int32_t* pair_ids_dev, int B, int K, 
                reinterpret_cast<const long long*>(matches1_dev), mscores0_dev, mscores1_dev, rec_dev, B, K, rows};
     RUN("pack_records", launch_pack_records(a, s));
     return 0;
+  });
+}
+
+// RCCL entry points, resolved at the first call from the RCCL already in the process (a torch process has its own copy loaded;
+// a C host links one), else from librccl.so: libimx.so itself carries no link-time dependency on a particular RCCL build.
+namespace {
+struct Rccl {
+  int (*CommCount)(void*, int*) = nullptr;
+  int (*CommUserRank)(void*, int*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+const Rccl& rccl() {
+  static Rccl r = [] {
+    Rccl t;
+    void* lib = nullptr;
+    auto sym = [&](const char* name) -> void* {
+      if (void* p = dlsym(RTLD_DEFAULT, name)) return p;
+      if (!lib) {
+        for (const char* so : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"})
+          if ((lib = dlopen(so, RTLD_NOW | RTLD_GLOBAL))) break;
+      }
+      return lib ? dlsym(lib, name) : nullptr;
+    };
+    t.CommCount = reinterpret_cast<decltype(t.CommCount)>(sym("ncclCommCount"));
+    t.CommUserRank = reinterpret_cast<decltype(t.CommUserRank)>(sym("ncclCommUserRank"));
+    t.GroupStart = reinterpret_cast<decltype(t.GroupStart)>(sym("ncclGroupStart"));
+    t.GroupEnd = reinterpret_cast<decltype(t.GroupEnd)>(sym("ncclGroupEnd"));
+    t.Send = reinterpret_cast<decltype(t.Send)>(sym("ncclSend"));
+    t.Recv = reinterpret_cast<decltype(t.Recv)>(sym("ncclRecv"));
+    t.GetErrorString = reinterpret_cast<decltype(t.GetErrorString)>(sym("ncclGetErrorString"));
+    t.ok = t.CommCount && t.CommUserRank && t.GroupStart && t.GroupEnd && t.Send && t.Recv;
+    return t;
+  }();
+  return r;
+}
+}  // namespace
+
+int imx_gather_records(imx_handle_t h, const int32_t* rec_dev, int rows, int width, int32_t* out_dev, int dst, void* nccl_comm, void* stream) {
+  return guarded(h, "imx_gather_records", [&]() -> int {
+    if (!h) return -1;
+    HIP_OK(h, hipSetDevice(h->device));
+    if (!nccl_comm || !rec_dev || rows < 0 || width <= 0) return fail(h, "imx_gather_records: bad arguments");
+    const Rccl& n = rccl();
+    if (!n.ok) return fail(h, "imx_gather_records: no RCCL in this process and librccl.so could not be loaded");
+    int world = 0, rank = 0, rc = 0;
+    auto chk = [&](int e, const char* what) { if (e && !rc) { rc = e; fail(h, "imx_gather_records: %s failed: %s", what, n.GetErrorString ? n.GetErrorString(e) : "RCCL error"); } };
+    chk(n.CommCount(nccl_comm, &world), "ncclCommCount");
+    chk(n.CommUserRank(nccl_comm, &rank), "ncclCommUserRank");
+    if (rc) return -1;
+    if (dst < 0 || dst >= world) return fail(h, "imx_gather_records: destination rank %d outside the communicator (%d ranks)", dst, world);
+    if (rank == dst && !out_dev) return fail(h, "imx_gather_records: the destination rank needs an output buffer");
+    const size_t count = (size_t)rows * width;
+    constexpr int kInt32 = 2;                       // ncclInt32
+    hipStream_t s = as_stream(stream);
+    // one group: every rank sends its rows to `dst`; `dst` posts one receive per rank into its slot (rank order = gather order)
+    chk(n.GroupStart(), "ncclGroupStart");
+    if (count) {
+      chk(n.Send(rec_dev, count, kInt32, dst, nccl_comm, s), "ncclSend");
+      if (rank == dst)
+        for (int r = 0; r < world; ++r) chk(n.Recv(out_dev + (size_t)r * count, count, kInt32, r, nccl_comm, s), "ncclRecv");
+    }
+    chk(n.GroupEnd(), "ncclGroupEnd");
+    return rc ? -1 : 0;
   });
 }
 

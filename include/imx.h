@@ -140,6 +140,14 @@ int imx_pack_records(imx_handle_t h, const int32_t* pair_ids_dev, int B, int K,
                      const int64_t* matches0_dev, const int64_t* matches1_dev,
                      const float* mscores0_dev, const float* mscores1_dev, int32_t* rec_dev, int rows, void* stream);
 
+/* The one collective of the path, for hosts without torch.distributed: every rank's (rows, width) int32 record buffer
+ * (imx_pack_records; the same `rows` on every rank) is collected on rank `dst` -- out_dev there (world*rows, width), ordered by
+ * rank; ignored on the other ranks -- as ONE group of ncclSend / ncclRecv over xGMI, enqueued on `stream`.  nccl_comm: an
+ * ncclComm_t the host created with RCCL (ncclCommInitRank); rank and world size are read from it.  The RCCL entry points are
+ * resolved at run time from the RCCL already loaded in the process (else librccl.so). */
+int imx_gather_records(imx_handle_t h, const int32_t* rec_dev, int rows, int width, int32_t* out_dev, int dst,
+                       void* nccl_comm, void* stream);
+
 /* Registration post-step inside the reference's timed region: RANSAC partial-affine (4-DoF similarity) fit
  * of kpts0[valid] -> kpts1[matches0[valid]], replacing cv2.estimateAffinePartial2D(..., cv2.RANSAC,
  * ransacReprojThreshold) at superpoint_glue_test.py:86-92.  Per pair: `hypotheses`

@@ -82,3 +82,47 @@ def test_reloading_weights_does_not_leak_device_memory():
     x = util.pair(3, 120, 160)[0].cuda()
     kp, sc, ds, n = eng.superpoint(x)            # and the reloaded weights work
     assert n[0] > 0
+
+
+def test_gather_records_through_the_c_abi_over_rccl():
+    """imx_gather_records: the path's one collective for hosts without torch.distributed.  A communicator of one rank is created
+    with RCCL directly (ctypes: ncclGetUniqueId / ncclCommInitRank -- what a C host does), the records of a small batch are packed by
+    imx_pack_records and gathered to rank 0 through the C ABI; the result equals the buffer that went in."""
+    import ctypes
+    import glob
+    import os
+    import torch
+    from image_matching_amd import _lib as L, shard
+    from image_matching_amd.superglue.models.matching_test import Matching
+    from tests import util
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["/opt/rocm/lib/librccl.so"]
+    rccl = next((ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL) for c in cands if os.path.exists(c)), None)
+    assert rccl is not None, "no RCCL library found"
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid, comm = UniqueId(), ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        d, K, H, W = 128, 256, 240, 320
+        m = Matching({"superpoint": util.sp_config(d, K), "superglue": util.sg_config(d)}).eval().to("cuda")
+        m.superpoint.load_state_dict(util.sp_sd(d))
+        m.superglue.load_state_dict(util.sg_sd(d))
+        pairs = [util.pair(60 + i, H, W) for i in range(2)]
+        out = m.match_batch(torch.cat([p[0] for p in pairs]).cuda(), torch.cat([p[1] for p in pairs]).cuda())
+        rec = m.pack_records([5, 9], out, pad_to=3)
+        eng = m._shared.get_engine([0, 1])
+        got = torch.full_like(rec, -7)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = eng.lib.imx_gather_records(eng.handle, ctypes.c_void_p(rec.data_ptr()), rec.shape[0], rec.shape[1],
+                                        ctypes.c_void_p(got.data_ptr()), 0, comm, st)
+        assert rc == 0, eng.lib.imx_last_error(eng.handle).decode()
+        torch.cuda.synchronize()
+        assert torch.equal(got, rec) and shard.unpack_records(got)["pair_id"].tolist() == [5, 9]
+        assert eng.lib.imx_gather_records(eng.handle, ctypes.c_void_p(rec.data_ptr()), 3, rec.shape[1], None, 0, comm, st) != 0   # dst without a buffer
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
