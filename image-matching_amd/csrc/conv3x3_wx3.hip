@@ -245,7 +245,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wx3(ConvArgs p, const __bf16* 
   // ---- U fragments: ring of TWO j-steps (cob x plane = six 1 KB loads each; a third does not fit the register file next to the
   //      B operands and a raw chunk in flight), straight from L2 into registers
   const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void*)ux, 0, ncog * nchunk * UCH * 2, 0x00020000);
-  bf16x8 Ar[2][2][3];
+  constexpr int NA = (EXP >= 4) ? 3 : 2;       // EXP 4 / 5: a ring of three j-steps (5: and no raw-patch loads)
+  bf16x8 Ar[NA][2][3];
   auto ubase = [&](const Cursor& c) -> int {                // byte offset of (cog, chunk, row i = wave)
     return __builtin_amdgcn_readfirstlane((((c.cog * nchunk + c.chunk) * 4 + wave) * 6 * UJ) * 2);
   };
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wx3(ConvArgs p, const __bf16* 
   lnext(); gload(lc);                           // chunk 2 stays in registers
   int ub = ubase(cc);
   aload(0, ub, 0); aload(1, ub, 1);
+  if (NA == 3) aload(2, ub, 2);
   bf16x8 B[6][3];
   f32x4 vh[3][2];
   __syncthreads();
@@ -369,9 +371,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wx3(ConvArgs p, const __bf16* 
       for (int t = 0; t < 6; ++t)
 #pragma unroll
         for (int cob = 0; cob < 2; ++cob)
-          acc[j][cob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ar[j & 1][cob][PA[t]], B[j][PB[t]],
+          acc[j][cob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ar[j % NA][cob][PA[t]], B[j][PB[t]],
                                                                 (decltype(first)::value && t == 0) ? zero16 : acc[j][cob], 0, 0, 0);
-      if (EXP != 1) aload(j & 1, j + 2 < 6 ? ubc : ubn, (j + 2) % 6);      // refill the slot just consumed, two j-steps ahead
+      if (EXP != 1) aload(j % NA, j + NA < 6 ? ubc : ubn, (j + NA) % 6);      // refill the slot just consumed, NA j-steps ahead
     }
   };
   auto phase = [&](float* rstore, const float* rnext, auto first) __attribute__((always_inline)) {
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wx3(ConvArgs p, const __bf16* 
       __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // four VALU beneath it
     }
     if constexpr (TRACE) { __builtin_amdgcn_sched_barrier(0); IMX_TS(5) }
-    if (EXP != 3) lstore(rstore);               // chunk s+2 (requested at the end of the previous phase) -> the buffer chunk s lived in
+    if (EXP != 3 && EXP != 5) lstore(rstore);               // chunk s+2 (requested at the end of the previous phase) -> the buffer chunk s lived in
     __builtin_amdgcn_sched_group_barrier(0x200, G::LPT, 0);   // ... AFTER the first half's MFMAs: the loads need the time
     __builtin_amdgcn_sched_barrier(0);          // the raw-chunk registers die here: the transform below needs the room
     IMX_TS(1)
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wx3(ConvArgs p, const __bf16* 
     IMX_TS(2)
     ub = ubn;
     lnext();                                    // (branches from here on: a new item re-binds the loader)
-    if (EXP != 3) gload(lc);                    // chunk s+3: in flight across the barrier and the next first half
+    if (EXP != 3 && EXP != 5) gload(lc);                    // chunk s+3: in flight across the barrier and the next first half
     IMX_TS(3)
     if (cc.chunk == nchunk - 1) {               // block-uniform
       epilogue(ci);
@@ -468,6 +470,8 @@ hipError_t launch_t(const ConvArgs& a, hipStream_t s) {
     if (exp_id == 1) kt = conv3x3_wx3<TYW, TXW, POOL, RELU, true, 1>;
     if (exp_id == 2) kt = conv3x3_wx3<TYW, TXW, POOL, RELU, true, 2>;
     if (exp_id == 3) kt = conv3x3_wx3<TYW, TXW, POOL, RELU, true, 3>;
+    if (exp_id == 4) kt = conv3x3_wx3<TYW, TXW, POOL, RELU, true, 4>;
+    if (exp_id == 5) kt = conv3x3_wx3<TYW, TXW, POOL, RELU, true, 5>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     static unsigned* dbuf = nullptr;
     constexpr int NREC = 1024 * 4 * 8;
