@@ -258,3 +258,23 @@ def test_max_keypoints_beyond_the_lds_sort_vs_oracle():
     ref = superpoint_ref.superpoint_forward(x, sd, cfg)
     assert len(ref["keypoints"][0]) == K, "the case must exercise the top-k (more candidates than max_keypoints)"
     _check_against(eng, x, [ref["keypoints"][0]], [ref["scores"][0]], [ref["descriptors"][0]], exact_order=False)
+
+
+def test_descriptor_dim_not_a_multiple_of_32_superpoint_alone_vs_oracle():
+    """The reference's SuperPoint takes any descriptor_dim (superpoint_test.py:57-63, :83); only SuperGlue needs 4 heads.  A 100-wide
+    descriptor head (convDb N = 100: a partial 64-column tile, 400-byte rows) against the oracle: same keypoints, descriptors at
+    1e-4; and SuperGlue weights for that width are refused with a message, not mis-computed."""
+    from oracle import superpoint_ref
+    from image_matching_amd import _lib as L
+    from image_matching_amd.engine import Engine, ImxError
+    d, K, H, W = 100, 300, 120, 160
+    cfg = util.sp_config(d, K)
+    eng = Engine(cfg, {"descriptor_dim": d, "keypoint_encoder": [32, 64], "weights": None, "sinkhorn_iterations": 10, "match_threshold": 0.2}, "cuda")
+    sd = util.sp_sd(d)
+    eng.load_state_dict(L.NET_SUPERPOINT, sd)
+    x = torch.cat(util.pair(21, H, W))
+    ref = superpoint_ref.superpoint_forward(x, sd, cfg)
+    _check_against(eng, x, ref["keypoints"], ref["scores"], ref["descriptors"])
+    from image_matching_amd import synth
+    with pytest.raises((ImxError, Exception)):
+        eng.load_state_dict(L.NET_SUPERGLUE, util.to_torch(synth.make_superglue_state_dict(d, [32, 64])))
