@@ -55,11 +55,7 @@ struct Item { int b, y0, x0, cob; };
 template <bool V>
 struct BoolC { static constexpr bool value = V; };
 
-// EXP (trace builds only, IMX_WINO_EXP=n): timing experiments that DROP one ingredient of the phase (results are garbage):
-//   1 no in-stream input transform   2 no U-panel (B operand) loads   3 no raw patch loads / stores   4 no A-operand LDS reads
-//   5 MFMAs + barrier only           6 no barrier                  7 raw patch loads made CONTIGUOUS (same bytes, dense lines)
-//   8 HALF of the U-panel loads (odd quads keep stale registers)
-template <bool POOL, bool RELU, bool TRACE, int EXP = 0>
+template <bool POOL, bool RELU, bool TRACE>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x, int tiles_y, int nitems, unsigned* trace) {
   // TRACE: s_memtime deltas summed over the stream (bring-up instrumentation, IMX_WINO_TRACE=1)
   unsigned tph[4] = {0, 0, 0, 0};
@@ -137,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
   // Input layout.  NHWC: a pixel's 8-channel chunk is 32 bytes of a Cin*4-byte record, so a wave's patch load touches 64
   // different 128-byte lines for 1 KB of payload and the 2 x 56 KB per phase of U + patch traffic evicts them from the 32 KB
   // L1 before the next chunk reuses them (measured: dense loads of the same volume shorten a phase from 3450 to 3050 cycles,
-  // IMX_WINO_EXP=7).  Channel-blocked (B, Cin/8, H, W, 8): the chunk's plane holds consecutive pixels' 32 bytes back to back --
+  // a round-2 timing experiment).  Channel-blocked (B, Cin/8, H, W, 8): the chunk's plane holds consecutive pixels' 32 bytes back to back --
   // a patch row of 18 pixels is 576 contiguous bytes.  The chunk's plane offset rides in the SGPR operand.
   const bool inb = p.in_blocked != 0;
   const int pxb = inb ? CK * 4 : Cin * 4;                       // bytes from one pixel to the next
@@ -148,12 +144,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
     for (int k = 0; k < 2; ++k) {
       const int gy = it.y0 + lpy[k], gx = it.x0 + lpx[k];
       goff[k] = (live && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (unsigned)((gy * W + gx) * pxb + lhalf[k] * 16) : OOB;
-      if (EXP == 7) goff[k] = live ? (unsigned)((((it.y0 * W + it.x0) * Cin) + (tid + k * 256) * 4) * 4) : OOB;      // dense 16 B per lane
     }
   };
   // two register sets, one per stream-position parity: a patch is requested FOUR positions ahead and has two full phases
   // to arrive (under this kernel's L2 load a request takes 3-4 k cycles, about one phase: with one set -- requested one phase
-  // before its use -- removing the raw path altogether shortened a phase by 670 of 3500 cycles, IMX_WINO_EXP=3)
+  // before its use -- removing the raw path altogether shortened a phase by 670 of 3500 cycles: a round-2 timing experiment)
   f32x4 rr[2][2];
   auto issue_load = [&](int set) {
     const int so = __builtin_amdgcn_readfirstlane(lchunk * chunk_step);
@@ -244,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
   // (Cin % 32 == 0), so the parity of a stream position is the parity of its chunk index and items end after an odd phase.
   auto phase = [&](auto parc, int c) __attribute__((always_inline)) {
     constexpr int par = decltype(parc)::value ? 1 : 0;
-    if (EXP != 6) __syncthreads();               // V[par] and raw[par ^ 1] (position s+1) complete; the buffers written below are free
+    __syncthreads();               // V[par] and raw[par ^ 1] (position s+1) complete; the buffers written below are free
     IMX_TS(0)
     {
       // B panel of position s+1: next chunk of this item, or chunk 0 of the next item's output block
@@ -263,22 +258,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
 #pragma unroll
       for (int g = 0; g < NQ; ++g) {
         const int cu = g & 1, nx = cu ^ 1;
-        if (g + 1 < NQ && EXP != 4 && EXP != 5) af[nx] = *reinterpret_cast<const f32x4*>(vr + (g + 1) * QSL * 4);
-        if (EXP == 4 || EXP == 5) af[nx] = af[cu];
+        if (g + 1 < NQ) af[nx] = *reinterpret_cast<const f32x4*>(vr + (g + 1) * QSL * 4);
         acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][0], af[cu][0], acc[2 * g], 0, 0, 0);
         acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][2], af[cu][2], acc[2 * g + 1], 0, 0, 0);
         acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][1], af[cu][1], acc[2 * g], 0, 0, 0);
         acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][3], af[cu][3], acc[2 * g + 1], 0, 0, 0);
-        if (EXP != 2 && EXP != 5 && !(EXP == 8 && (g & 1))) bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
-        if (g == 0 && EXP != 1 && EXP != 5) {
+        bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
+        if (g == 0) {
 #pragma unroll
           for (int bb = 0; bb < 6; ++bb) { va[bb] = *reinterpret_cast<const f32x2*>(pa + bb * RSC); vb[bb] = *reinterpret_cast<const f32x2*>(pb + bb * RSC); }
         }
-        if (g == 1 && EXP != 3 && EXP != 5) {                // position s+2's patch (requested in phase s-2): registers -> raw[par];
+        if (g == 1) {                // position s+2's patch (requested in phase s-2): registers -> raw[par];
           store_raw(par, par);                               // then request position s+4 into the same register set
           issue_load(par);
         }
-        if (EXP == 1 || EXP == 5) continue;
         if (g == 3) {
 #pragma unroll
           for (int bb = 0; bb < 6; ++bb) o[bb] = pk_fma(sg2, vb[bb], va[bb]);   // down the rows: F(2,3), row i

@@ -1058,6 +1058,7 @@ int imx_pack_records(imx_handle_t h, const int32_t* pair_ids_dev, int B, int K, 
 
 // RCCL entry points, resolved at the first call from the RCCL already in the process (a torch process has its own copy loaded;
 // a C host links one), else from librccl.so: libimx.so itself carries no link-time dependency on a particular RCCL build.
+extern "C++" {
 namespace {
 struct Rccl {
   int (*CommCount)(void*, int*) = nullptr;
@@ -1094,6 +1095,7 @@ const Rccl& rccl() {
   return r;
 }
 }  // namespace
+}  // extern "C++"
 
 int imx_gather_records(imx_handle_t h, const int32_t* rec_dev, int rows, int width, int32_t* out_dev, int dst, void* nccl_comm, void* stream) {
   return guarded(h, "imx_gather_records", [&]() -> int {
