@@ -466,6 +466,12 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args.workload, args.cpu_baseline_worker)
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner to the C stdout when a communicator is
+    # created (flushed at exit, i.e. AFTER a Python print), so file descriptor 1 is pointed at stderr for the whole run and the
+    # line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -609,7 +615,8 @@ def main():
         log("cpu baseline (oracle on host cores)")
         line["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
     if use_pg:
         dist.destroy_process_group()
 

@@ -1,8 +1,8 @@
 // gemm_small.hip — the 1x1-conv / linear product for SMALL row counts (a single pair: M = 2 x 1024 keypoint rows), where latency,
 // not throughput, is what counts (BASELINE configs[2]; superglue_test.py:49-60,92-119,214-216).
 //
-// The weights-stationary form (gemm_ws.hip) keeps a workgroup's W columns in registers for the whole K and amortises that load over
-// many 64-row tiles; with M = 2048 a launch has 32-96 workgroups of ONE tile each, every one of them first pulling 64-128 KB of
+// A weights-stationary form (a workgroup's W columns in registers for the whole K, amortised over many 64-row tiles; round 2's
+// gemm_ws.hip, removed in round 3) has 32-96 workgroups of ONE tile each at M = 2048, every one of them first pulling 64-128 KB of
 // W through 128 dword loads per lane: 11-16 us per launch, 54 launches per pair.  Here the work is cut the other way: a
 // workgroup owns a 32 x 32 output tile (four waves of 16 x 16 on v_mfma_f32_16x16x4_f32), stages its whole A (32 x K) and W
 // (K x 32) panels in LDS with every load in flight at once (one barrier), and multiplies from LDS: 256-768 workgroups per
@@ -22,7 +22,7 @@ template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void gemm_small(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int K = p.K0 + p.K1;
-  const int SA = K + 8;            // A panel row stride: (K/4 + 2) 16-byte slots = 2 mod 16 for K % 64 == 0 (conflict-free ds_read_b128, see gemm_ws.hip)
+  const int SA = K + 8;            // A panel row stride: (K/4 + 2) 16-byte slots = 2 mod 16 for K % 64 == 0 (conflict-free ds_read_b128)
   float* As = sm;                  // [32][SA]
   float* Ws = sm + TM * SA;        // [K][SW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -82,10 +82,6 @@ struct GemmArgs {
 };
 // (K0, K1) % 32 == 0.
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
-// weights-stationary persistent form (gemm_ws.hip): K in {128, 256} with Npad % 128 == 0 or K == 512 with Npad % 64 == 0; N == Npad,
-// float4-aligned leading dimensions
-bool gemm_ws_supported(const GemmArgs& a);
-hipError_t launch_gemm_ws(const GemmArgs& a, hipStream_t s);
 // fp32 products as six bf16 term products on the bf16 matrix pipe (gemm_x3.hip): wx3 = the weights as three bf16 terms per value in
 // B-fragment order [Npad/32][K/16][3][64][8]; (K0, K1) % 32 == 0, Npad % 64 == 0, float4-aligned leading dimensions
 bool gemm_x3_supported(const GemmArgs& a);

@@ -247,10 +247,31 @@ def test_bench_through_the_driver_launch_line_with_rccl():
            "--pairs-per-gpu", "4", "--no-cpu-baseline", "--no-extras"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]     # stdout = the JSON line only (RCCL's banner goes to stderr)
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak" and "roofline" in line
     # what was timed is checked against the reference's committed outputs in the same process (pairs 0..3 = sweep seeds 1000..1003)
     assert line["parity_in_run"]["pairs"] == 4 and line["parity_in_run"]["unexplained"] == 0
     assert line["roofline"]["kernels"]["qkv_proj"]["form"] in ("gemm_x3:bf16x3", "gemm_small:f32")
+
+
+def test_bench_default_invocation_prints_exactly_one_line():
+    """`python bench.py` as the driver runs it at N = 1 (extras on: the world-1 RCCL gather initialises a communicator, whose
+    version banner RCCL writes to the C stdout): stdout must hold the JSON line and nothing else."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--pairs-per-gpu", "4", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "latency_b1_ms", "gather_ms", "c5"):
+        assert key in line, key
+    assert line["gather_ms"] is not None, line.get("gather_note")
