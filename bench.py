@@ -38,9 +38,13 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# the host driver of this pool supports dmabuf IPC only: without this RCCL's cross-process buffer registration fails with
+# `hipIpcGetMemHandle: invalid argument` (exported by the image already; kept here for a launch from a bare environment)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np                      # noqa: E402
+import torch                            # noqa: E402
+import torch.distributed as dist        # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
