@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
 #pragma unroll
   for (int q = 0; q < 24; ++q) acc[q] = w24_zero4();
   const f32x2 k8 = {8.f, 8.f};
-  // ---- store offsets.  FASTW (the output width is a whole number of tiles: every SuperPoint layer at 640x480 and
+  // ---- store offsets.  FASTW (the width is a whole number of tiles: every SuperPoint layer at 640x480 and
   //      1280x960): a lane's byte offsets relative to its item's first pixel never change.  The item part (tile origin,
   //      output block) goes into the BASE of a per-item buffer descriptor whose range is what is left of the image from
   //      there, so rows below the image are out of range and dropped by the hardware (the SGPR offset operand of a buffer
@@ -219,7 +219,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
   //      chunk's plane instead of past the end, so the fast path there also needs the height to be a whole number of tiles.
   const int Ho_k = POOL ? H >> 1 : H, Wo_k = POOL ? W >> 1 : W;
   const bool outb = p.out_blocked != 0;
-  const bool fastw = (Wo_k % (POOL ? OW / 2 : OW)) == 0 && (!outb || (Ho_k % (POOL ? OH / 2 : OH)) == 0);
+  // The conditions are on the INPUT size: with floor pooling an odd-sized input (H = 8k+1, W = 16k+1, ...) has a partial last
+  // tile row / column whose pooled outputs do not exist although Ho / Wo are whole numbers of pooled tiles (round 3, found by
+  // the shape fuzz: 113x96 -> 56x48 wrote pooled rows 56..59 into the next channel plane, 48x49 -> 24x24 wrapped columns 24..31
+  // into the next row).
+  const bool fastw = (W % OW) == 0 && (!outb || (H % OH) == 0);
   const int lwr = (lane & 15) >> 2, lwc = lane & 3;
   const int opx = outb ? CK * 4 : Cout * 4;                                  // bytes from one output pixel to the next
   const int chl = outb ? (cb * 2 + (lane >> 5)) * (Ho_k * Wo_k * CK * 4) + ((lane >> 4) & 1) * 16 : (cb * 16 + 4 * (lane >> 4)) * 4;

@@ -302,7 +302,7 @@ def _forms_of_a_step(m, i0, i1):
 
 
 # ------------------------------------------------------------------------------------------ ragged / batched fuzz
-@pytest.mark.parametrize("seed", list(range(10)))
+@pytest.mark.parametrize("seed", util.fuzz_seeds(list(range(10))))
 def test_superglue_random_shapes_batches_and_counts_vs_oracle(seed):
     """Random batch sizes (1-3), keypoint capacities (1-420) and per-pair device-side counts, d = 128: the masked paths of every
     SuperGlue kernel form (key-split and throughput attention, small-M and weights-stationary GEMM, Sinkhorn slabs, match
@@ -358,7 +358,7 @@ def test_superglue_random_shapes_batches_and_counts_vs_oracle(seed):
 
 
 # ------------------------------------------------------------------------------------------ the bf16-pipe forms on ragged shapes
-@pytest.mark.parametrize("seed", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("seed", util.fuzz_seeds([0, 1, 2, 3, 5]))
 def test_superglue_random_shapes_on_the_throughput_forms(seed, monkeypatch):
     """The same fuzz with the throughput forms forced at these small sizes ("latency_forms" = "off"): attention_x3 with
     partial key tiles, query blocks past the padded row count and per-pair device-side counts; the persistent gemm_x3 with row

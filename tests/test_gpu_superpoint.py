@@ -278,3 +278,82 @@ def test_descriptor_dim_not_a_multiple_of_32_superpoint_alone_vs_oracle():
     from image_matching_amd import synth
     with pytest.raises((ImxError, Exception)):
         eng.load_state_dict(L.NET_SUPERGLUE, util.to_torch(synth.make_superglue_state_dict(d, [32, 64])))
+
+
+@pytest.mark.parametrize("seed", util.fuzz_seeds([0, 1, 2, 3, 4, 5, 6, 7]))
+def test_superpoint_random_shapes_and_configs_vs_oracle(seed):
+    """Random image sizes (not multiples of 8: the pools floor, superpoint_test.py:113-116), batch sizes,
+    nms_radius, remove_borders, keypoint_threshold and max_keypoints.  The dense stages against the oracle on the same input at
+    1e-4 (score map 1e-5); then the compare-only tail -- simple_nms, threshold, border removal, top-k, descriptor sampling -- must
+    equal the oracle's tail run on the LIBRARY's own score map and dense descriptors exactly (keypoint sets and scores; sampled
+    descriptors at 1e-4), so a near-tie in the map cannot excuse a difference."""
+    from oracle import superpoint_ref
+    from image_matching_amd import _lib as L
+    from image_matching_amd.engine import Engine
+    rng = np.random.RandomState(4321 + seed)
+    d = 128
+    B = int(rng.randint(1, 4))
+    H, W = int(rng.randint(24, 331)), int(rng.randint(24, 421))
+    if seed % 4 == 0:
+        H, W = int(rng.randint(8, 41)), int(rng.randint(8, 41))           # down to one 8x8 cell
+    radius = int(rng.choice([0, 1, 2, 3, 4, 4, 4, 5, 7]))
+    border = int(rng.choice([0, 2, 4, 4, 8, 16]))
+    thr = float(rng.choice([0.0005, 0.002, 0.005, 0.005, 0.015]))
+    K = int(rng.choice([-1, 1, 30, 200, 1024, 5000]))
+    cfg = util.sp_config(d, K, nms_radius=radius, remove_borders=border, keypoint_threshold=thr)
+    eng = Engine(cfg, util.sg_config(d), "cuda")
+    sd = util.sp_sd(d)
+    eng.load_state_dict(L.NET_SUPERPOINT, sd)
+    eng.set_debug(True)
+    x = torch.cat([util.pair(300 + 7 * seed + b, H, W)[b & 1] for b in range(B)])
+    what = f"seed {seed}: B={B} {H}x{W} r={radius} border={border} thr={thr} K={K}"
+    kpts, scores, desc, n = eng.superpoint(x.cuda())
+    ref = superpoint_ref.superpoint_forward(x, sd, cfg, return_dense=True)
+    H8, W8 = (H // 8) * 8, (W // 8) * 8
+    util.assert_close(_nchw(eng.fetch("semi")), ref["semi"].numpy(), what + " semi")
+    raw = _nchw(eng.fetch("desc_raw"))
+    dense = raw / np.linalg.norm(raw, axis=1, keepdims=True)
+    util.assert_close(dense, ref["desc"].numpy(), what + " dense descriptors")
+    own_map = eng.fetch("score_map")
+    assert own_map.shape == (B, H8, W8), what
+    util.assert_close(own_map, ref["score_map"].numpy(), what + " score map", atol=1e-5)
+    # the tail, on the library's own map
+    own_nms = superpoint_ref.simple_nms(torch.from_numpy(own_map), radius)
+    assert np.array_equal(eng.fetch("nms"), own_nms.numpy()), what + ": NMS differs from simple_nms on the library's own score map"
+    for b in range(B):
+        k_ref, s_ref = superpoint_ref.extract_keypoints(own_nms[b], thr, border, K)
+        assert n[b] == len(k_ref), f"{what} image {b}: {n[b]} keypoints, oracle tail {len(k_ref)}"
+        if n[b] == 0:
+            continue
+        km, sm, dm = kpts[b, :n[b]].cpu().numpy(), scores[b, :n[b]].cpu().numpy(), desc[b, :n[b]].t().cpu().numpy()
+        d_ref = superpoint_ref.sample_descriptors(k_ref[None], torch.from_numpy(dense[b:b + 1]), 8, False)[0].numpy()
+        a, r = util.canon_keypoints(km, sm, dm), util.canon_keypoints(k_ref.numpy(), s_ref.numpy(), d_ref)
+        if not np.array_equal(a[0], r[0]):
+            # legal only as a tie at the top-k boundary: every keypoint on one side only carries the boundary score
+            sa, sr = {tuple(p) for p in a[0].tolist()}, {tuple(p) for p in r[0].tolist()}
+            lowest = float(s_ref.min())
+            odd = [p for p in sa ^ sr if float(own_nms[b][int(p[1]), int(p[0])]) != lowest]
+            assert not odd, f"{what} image {b}: keypoint sets differ beyond a top-k boundary tie: {odd[:5]}"
+            continue
+        assert np.array_equal(a[1], r[1]), f"{what} image {b}: scores are not the map's values"
+        util.assert_close(a[2], r[2], f"{what} image {b} descriptors")
+        if 0 <= K < 10 ** 9 and n[b] == K:
+            assert np.all(np.diff(sm) <= 0), what + ": top-k output must be sorted by descending score"
+
+
+@pytest.mark.parametrize("H,W", [(226, 192), (193, 197), (294, 388), (130, 66)])
+def test_odd_sizes_whose_pooled_sizes_are_whole_tiles(H, W):
+    """Round-3 regression (found by the shape fuzz above).  With floor pooling an input of 113x96 pools to 56x48 and one of 48x49 to
+    24x24: whole numbers of pooled tiles although the INPUT has a partial last tile row / column.  conv3x3_wino24's unmasked store
+    path keyed on the pooled size, so the partial tiles' outputs landed in the next channel plane (rows) or wrapped into the next
+    image row (columns).  x4 and semi against the oracle at 1e-4 on such sizes."""
+    from oracle import superpoint_ref
+    eng, L = _engine(128, 100)
+    sd = util.sp_sd(128)
+    eng.load_state_dict(L.NET_SUPERPOINT, sd)
+    eng.set_debug(True)
+    x = torch.cat(util.pair(77, H, W))
+    eng.superpoint(x.cuda())
+    ref = superpoint_ref.superpoint_forward(x, sd, util.sp_config(128, 100), return_dense=True)
+    util.assert_close(_nchw(eng.fetch("x4")), ref["x4"].numpy(), f"{H}x{W} x4")
+    util.assert_close(_nchw(eng.fetch("semi")), ref["semi"].numpy(), f"{H}x{W} semi")

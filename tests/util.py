@@ -193,3 +193,12 @@ def canon_keypoints(kpts, scores, desc=None):
         d = desc.detach().cpu().numpy() if isinstance(desc, torch.Tensor) else np.asarray(desc)
         out.append(d[:, order])
     return out
+
+
+def fuzz_seeds(default):
+    """IMX_FUZZ_SEEDS="a-b" replaces a fuzz test's seed list for a soak run (tools/gpu_soak.sh); the suite runs the default."""
+    spec = os.environ.get("IMX_FUZZ_SEEDS")
+    if not spec:
+        return default
+    a, b = spec.split("-")
+    return list(range(int(a), int(b) + 1))
