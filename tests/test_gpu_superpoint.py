@@ -300,15 +300,22 @@ def test_superpoint_random_shapes_and_configs_vs_oracle(seed):
     border = int(rng.choice([0, 2, 4, 4, 8, 16]))
     thr = float(rng.choice([0.0005, 0.002, 0.005, 0.005, 0.015]))
     K = int(rng.choice([-1, 1, 30, 200, 1024, 5000]))
+    official = seed % 5 == 3              # the no-BN network of superglue/models/superpoint.py (d = 256)
+    ac = seed % 7 == 5                    # the torch < 1.10 branch of sample_descriptors (superpoint_test.py:47)
+    if official:
+        from image_matching_amd import synth
+        d = 256
+        sd = util.to_torch(synth.synth_state_dict(synth.superpoint_official_shapes(d), 77))
+    else:
+        sd = util.sp_sd(d)
     cfg = util.sp_config(d, K, nms_radius=radius, remove_borders=border, keypoint_threshold=thr)
-    eng = Engine(cfg, util.sg_config(d), "cuda")
-    sd = util.sp_sd(d)
+    eng = Engine(cfg, util.sg_config(d), "cuda", 1 if official else 0, True if ac else None)
     eng.load_state_dict(L.NET_SUPERPOINT, sd)
     eng.set_debug(True)
     x = torch.cat([util.pair(300 + 7 * seed + b, H, W)[b & 1] for b in range(B)])
-    what = f"seed {seed}: B={B} {H}x{W} r={radius} border={border} thr={thr} K={K}"
+    what = f"seed {seed}: B={B} {H}x{W} r={radius} border={border} thr={thr} K={K}{' official' if official else ''}{' align_corners' if ac else ''}"
     kpts, scores, desc, n = eng.superpoint(x.cuda())
-    ref = superpoint_ref.superpoint_forward(x, sd, cfg, return_dense=True)
+    ref = superpoint_ref.superpoint_forward(x, sd, cfg, variant="official" if official else "bn", align_corners=ac, return_dense=True)
     H8, W8 = (H // 8) * 8, (W // 8) * 8
     util.assert_close(_nchw(eng.fetch("semi")), ref["semi"].numpy(), what + " semi")
     raw = _nchw(eng.fetch("desc_raw"))
@@ -326,7 +333,7 @@ def test_superpoint_random_shapes_and_configs_vs_oracle(seed):
         if n[b] == 0:
             continue
         km, sm, dm = kpts[b, :n[b]].cpu().numpy(), scores[b, :n[b]].cpu().numpy(), desc[b, :n[b]].t().cpu().numpy()
-        d_ref = superpoint_ref.sample_descriptors(k_ref[None], torch.from_numpy(dense[b:b + 1]), 8, False)[0].numpy()
+        d_ref = superpoint_ref.sample_descriptors(k_ref[None], torch.from_numpy(dense[b:b + 1]), 8, ac)[0].numpy()
         a, r = util.canon_keypoints(km, sm, dm), util.canon_keypoints(k_ref.numpy(), s_ref.numpy(), d_ref)
         if not np.array_equal(a[0], r[0]):
             # legal only as a tie at the top-k boundary: every keypoint on one side only carries the boundary score
