@@ -86,3 +86,25 @@ def test_ingest_pipeline_feeds_matching_identically():
         ref = m.match_batch(host0, host1)
         for key in ref:
             assert torch.equal(ref[key], outs[k][key]), (k, key)
+
+
+@pytest.mark.parametrize("seed", util.fuzz_seeds([0, 1, 2, 3, 4, 5]))
+def test_resize_and_warp_random_sizes_bit_exact(seed):
+    """Random source / destination sizes (up- and down-scaling, 1-pixel edges, non-integer ratios) and random affine maps: every
+    byte equal to the scalar restatement of OpenCV's fixed-point INTER_LINEAR resize / warp (oracle/ingest_ref.py)."""
+    from oracle import ingest_ref
+    eng = _engine()
+    rng = np.random.RandomState(888 + seed)
+    B = int(rng.randint(1, 4))
+    src = (int(rng.randint(1, 90)), int(rng.randint(1, 120)))
+    dst = (int(rng.randint(1, 100)), int(rng.randint(1, 130)))
+    img = rng.randint(0, 256, (B,) + src).astype(np.uint8)
+    out = eng.ingest(torch.from_numpy(img), dst).cpu().numpy()
+    assert out.shape == (B, 1) + dst
+    for b in range(B):
+        ref = ingest_ref.unit_float(ingest_ref.resize_u8(img[b], (dst[1], dst[0])))
+        assert np.array_equal(out[b, 0], ref), f"seed {seed}: resize {src} -> {dst} image {b}"
+    th, sc = rng.uniform(-3.1, 3.1), rng.uniform(0.3, 3.0)
+    M = [[sc * np.cos(th), -sc * np.sin(th), rng.uniform(-60, 60)], [sc * np.sin(th), sc * np.cos(th), rng.uniform(-60, 60)]]
+    got = eng.warp_affine_u8(torch.from_numpy(img[0]), M).cpu().numpy()
+    assert np.array_equal(got, ingest_ref.warp_affine_u8(img[0], M, (src[1], src[0]))), f"seed {seed}: warp {src} M={M}"

@@ -120,3 +120,62 @@ def test_flann_cli_end_to_end_on_synthetic_dataset(tmp_path):
         # source = roll(template, (16(i+1) rows, 32(i+1) cols)) at full size -> template = source shifted back
         np.testing.assert_allclose(M[:, :2], np.eye(2), atol=0.02)
         np.testing.assert_allclose(M[:, 2], [-32 * (i + 1), -16 * (i + 1)], atol=1.5)
+
+
+@pytest.mark.parametrize("seed", util.fuzz_seeds([0, 1, 2, 3, 4, 5]))
+def test_ransac_random_sizes_counts_and_outliers_vs_host_restatement(seed):
+    """Random batch sizes, keypoint capacities (4..3000, K0 != K1), unmatched fractions, outlier rates, thresholds and hypothesis
+    counts: the inlier mask must equal the host restatement's (same hypothesis sequence) and the model agree to 2e-4."""
+    from image_matching_amd.engine import Engine
+    from oracle import ransac_ref
+    rng = np.random.RandomState(777 + seed)
+    B = int(rng.randint(1, 5))
+    K = int(rng.choice([4, 5, 9, 64, 65, 257, 1000, 1024, 3000]))
+    if seed % 3 == 1:
+        K = int(rng.randint(4, 700))
+    thresh = float(rng.choice([1.0, 3.0, 7.0]))
+    hyp = int(rng.choice([1, 16, 100, 256, 512]))
+    eng = Engine(util.sp_config(128, 1024), util.sg_config(128), "cuda")
+    cases = [_case(seed * 10 + b, K, float(rng.uniform(-1.5, 1.5)), float(rng.uniform(0.5, 2.0)), (float(rng.uniform(-100, 100)), float(rng.uniform(-100, 100))),
+                   frac_unmatched=int(rng.randint(2, 9)), outlier_every=int(rng.randint(2, 12))) for b in range(B)]
+    k0 = torch.from_numpy(np.stack([c[0] for c in cases])).cuda()
+    k1 = torch.from_numpy(np.stack([c[1] for c in cases])).cuda()
+    m = torch.from_numpy(np.stack([c[2] for c in cases])).cuda()
+    rs = int(rng.randint(0, 2 ** 31))
+    M, inl, ninl = eng.estimate_affine_partial(k0, k1, m, ransac_thresh=thresh, hypotheses=hyp, seed=rs)
+    M, inl, ninl = M.cpu().numpy(), inl.cpu().numpy(), ninl.cpu().numpy()
+    for b, (c0, c1, cm, _) in enumerate(cases):
+        Mr, maskr, nr = ransac_ref.estimate_affine_partial(c0, c1, cm, b=b, thresh=thresh, hypotheses=hyp, seed=rs)
+        what = f"seed {seed} pair {b}: B={B} K={K} thresh={thresh} hypotheses={hyp}"
+        assert ninl[b] == nr and np.array_equal(inl[b], maskr), what + ": inlier mask differs from the host restatement"
+        np.testing.assert_allclose(M[b], Mr, atol=2e-4, rtol=1e-5, err_msg=what)
+
+
+@pytest.mark.parametrize("seed", util.fuzz_seeds([0, 1, 2, 3, 4, 5]))
+def test_knn_ratio_random_shapes_vs_brute_force(seed):
+    """Random batch sizes, descriptor counts per side (1..900), descriptor widths and ratios, strided inputs: exact 2-NN distances
+    at 2e-4 and the ratio decision wherever it is not within 1e-3 of the boundary (float64 brute force)."""
+    from image_matching_amd.engine import Engine
+    rng = np.random.RandomState(555 + seed)
+    B, d = int(rng.randint(1, 4)), int(rng.choice([64, 128, 256]))
+    N0, N1 = int(rng.randint(1, 901)), int(rng.randint(2, 901))
+    ratio = float(rng.choice([0.6, 0.7, 0.8, 0.95]))
+    g = torch.Generator().manual_seed(seed)
+    a = torch.nn.functional.normalize(torch.randn(B, N0, d, generator=g), dim=2)
+    b = torch.nn.functional.normalize(torch.randn(B, N1, d, generator=g), dim=2)
+    if N1 >= N0:                      # plant true neighbours so the ratio test accepts some rows
+        b[:, :N0:3] = torch.nn.functional.normalize(a[:, ::3] + 0.05 * torch.randn(a[:, ::3].shape, generator=g), dim=2)
+    eng = Engine(util.sp_config(d, 64), util.sg_config(d), "cuda")
+    m, dist1, dist2 = eng.knn_ratio_match(a.cuda().transpose(1, 2), b.cuda().transpose(1, 2), ratio=ratio)      # (B,d,N) strided views
+    for i in range(B):
+        x, y = a[i].double().numpy(), b[i].double().numpy()
+        D = np.sqrt(np.maximum((x * x).sum(1)[:, None] + (y * y).sum(1)[None] - 2 * x @ y.T, 0))
+        order = np.argsort(D, axis=1)
+        nn1, nn2 = order[:, 0], order[:, 1]
+        r1, r2 = D[np.arange(N0), nn1], D[np.arange(N0), nn2]
+        what = f"seed {seed}: B={B} d={d} {N0}x{N1} ratio {ratio} pair {i}"
+        np.testing.assert_allclose(dist1[i].cpu().numpy(), r1, atol=2e-4, err_msg=what)
+        np.testing.assert_allclose(dist2[i].cpu().numpy(), r2, atol=2e-4, err_msg=what)
+        got = m[i].cpu().numpy()
+        decided = (np.abs(r1 - ratio * r2) > 1e-3) & ((r2 - r1) > 1e-3)
+        assert np.array_equal(got[decided], np.where(r1 < ratio * r2, nn1, -1)[decided]), what
