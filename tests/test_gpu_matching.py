@@ -275,3 +275,58 @@ def test_bench_default_invocation_prints_exactly_one_line():
                 "data", "config", "roofline", "latency_b1_ms", "gather_ms", "c5"):
         assert key in line, key
     assert line["gather_ms"] is not None, line.get("gather_note")
+
+
+@pytest.mark.parametrize("seed", util.fuzz_seeds([0, 1, 2, 3, 4, 5, 6, 7]))
+def test_matching_forward_random_sizes_vs_oracle_on_its_own_features(seed):
+    """Matching.forward (matching_test.py:54-82) on random image sizes -- equal shapes (the fused call) or a different shape per
+    image (the generic path; normalize_keypoints takes each image's own shape, superglue_test.py:246-247) -- and max_keypoints
+    in {-1, 40, 200}.  The SuperPoint halves must equal the SuperPoint drop-in called alone (bit for bit); the SuperGlue half is
+    held to the oracle run on the library's OWN keypoints / scores / descriptors: matching_scores at 1e-4 where the indices
+    agree, and an index may differ only where the oracle's transport matrix has a margin below 2e-3 (row or column top-1 /
+    top-2 gap, or distance to the match threshold)."""
+    from oracle import superglue_ref
+    rng = np.random.RandomState(2468 + seed)
+    d = 128
+    K = int(rng.choice([-1, 40, 200]))
+    H0, W0 = int(rng.randint(64, 260)), int(rng.randint(64, 340))
+    H1, W1 = (H0, W0) if seed % 2 == 0 else (int(rng.randint(64, 260)), int(rng.randint(64, 340)))
+    m = _matching(d, K)
+    x0 = util.pair(500 + seed, H0, W0)[0].cuda()
+    x1 = util.pair(500 + seed, H1, W1)[1].cuda()
+    what = f"seed {seed}: {H0}x{W0} / {H1}x{W1} K={K}"
+    pred = m({"image0": x0, "image1": x1})
+    assert set(pred) == {"keypoints0", "scores0", "descriptors0", "keypoints1", "scores1", "descriptors1",
+                         "matches0", "matches1", "matching_scores0", "matching_scores1"}, what
+    for side, x in ((0, x0), (1, x1)):
+        alone = m.superpoint(x)
+        assert torch.equal(alone["keypoints"][0], pred[f"keypoints{side}"][0]) and torch.equal(alone["scores"][0], pred[f"scores{side}"][0]), what
+        assert torch.equal(alone["descriptors"][0], pred[f"descriptors{side}"][0]), what
+    n0, n1 = len(pred["keypoints0"][0]), len(pred["keypoints1"][0])
+    assert pred["matches0"].shape == (1, n0) and pred["matches1"].shape == (1, n1), what
+    if n0 == 0 or n1 == 0:
+        assert pred["matches0"].dtype == torch.int32 and (pred["matches0"] == -1).all(), what       # superglue_test.py:235-242
+        return
+    assert pred["matches0"].dtype == torch.int64 and pred["matching_scores0"].dtype == torch.float32
+    data = {"keypoints0": pred["keypoints0"][0][None].cpu(), "keypoints1": pred["keypoints1"][0][None].cpu(),
+            "scores0": pred["scores0"][0][None].cpu(), "scores1": pred["scores1"][0][None].cpu(),
+            "descriptors0": pred["descriptors0"][0][None].cpu(), "descriptors1": pred["descriptors1"][0][None].cpu(),
+            "image_shape0": tuple(x0.shape), "image_shape1": tuple(x1.shape)}
+    cfg = util.sg_config(d)
+    ref = superglue_ref.superglue_forward(data, util.sg_sd(d), cfg, return_dense=True)
+    Z = ref["dense"]["Z"][0].numpy()[:-1, :-1] if "Z" in ref["dense"] else None
+    assert Z is not None, "the oracle's dense outputs carry Z"
+    r0, mine0 = ref["matches0"][0].numpy(), pred["matches0"][0].cpu().numpy()
+    thr = np.log(cfg["match_threshold"])
+    srt_r, srt_c = np.sort(Z, axis=1), np.sort(Z, axis=0)
+    gap_r = srt_r[:, -1] - srt_r[:, -2] if Z.shape[1] > 1 else np.full(Z.shape[0], np.inf)
+    gap_c = srt_c[-1] - srt_c[-2] if Z.shape[0] > 1 else np.full(Z.shape[1], np.inf)
+    for i in np.nonzero(mine0 != r0)[0]:
+        j = int(Z[i].argmax())
+        ok = gap_r[i] < 2e-3 or gap_c[j] < 2e-3 or abs(Z[i, j] - thr) < 2e-3
+        assert ok, f"{what}: matches0[{i}] = {mine0[i]}, oracle {r0[i]} (row gap {gap_r[i]:.2e}, column gap {gap_c[j]:.2e}, threshold distance {abs(Z[i, j] - thr):.2e})"
+    same = mine0 == r0
+    util.assert_close(pred["matching_scores0"][0].cpu().numpy()[same], ref["matching_scores0"][0].numpy()[same], what + " matching_scores0")
+    m1 = pred["matches1"][0].cpu().numpy()
+    i = np.nonzero(mine0 > -1)[0]
+    assert np.array_equal(m1[mine0[i]], i), what + ": matches1 inconsistent with matches0"
