@@ -50,6 +50,7 @@ struct ConvW {
 struct GemmW {
   float* w = nullptr;
   float* wx3 = nullptr;   // the same weights as three bf16 terms per value in MFMA fragment order (split_bf16x3; gemm_x3.hip)
+  float* wf = nullptr;    // the same fp32 weights in the B-fragment order of gnn_small.hip (fragment_order; K % 16 == 0 only)
   float* b = nullptr;
   int K = 0, N = 0, Npad = 0;
 };
@@ -410,9 +411,21 @@ std::vector<float> split_bf16x3(const std::vector<float>& w, int K, int Npad) {
   return out;
 }
 
+// W [K][Npad] -> [K/16][4 (kq)][Npad][4 (j)], element (t, kq, col, j) = W[16 t + 4 kq + j][col]: the four B values a lane of
+// v_mfma_f32_16x16x4_f32 feeds to the four MFMAs of a 16-k group are one 16-byte load, sixteen lanes 256 contiguous bytes
+std::vector<float> fragment_order(const std::vector<float>& w, int K, int Npad) {
+  std::vector<float> f((size_t)K * Npad);
+  for (int t = 0; t < K / 16; ++t)
+    for (int kq = 0; kq < 4; ++kq)
+      for (int col = 0; col < Npad; ++col)
+        for (int j = 0; j < 4; ++j) f[(((size_t)t * 4 + kq) * Npad + col) * 4 + j] = w[(size_t)(16 * t + 4 * kq + j) * Npad + col];
+  return f;
+}
+
 int upload_gemm(imx_handle_t h, GemmW& out, const std::vector<float>& w, const std::vector<float>& b, int K, int N, int Npad,
                 const char* what) {
   out.w = upload(h, w);
+  out.wf = (K % 16 == 0 && K <= 512 && N == Npad) ? upload(h, fragment_order(w, K, Npad)) : nullptr;
   out.wx3 = upload(h, split_bf16x3(w, K, Npad));
   out.b = upload(h, b);
   out.K = K;
@@ -533,6 +546,7 @@ int finalize_superglue(imx_handle_t h) {
       }
       L.qkv.w = upload(h, w);
       L.qkv.wx3 = upload(h, split_bf16x3(w, d, N));
+      L.qkv.wf = (d % 16 == 0) ? upload(h, fragment_order(w, d, N)) : nullptr;
       L.qkv.b = upload(h, b);
       L.qkv.K = d;
       L.qkv.N = N;
@@ -781,16 +795,31 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     tap(h, "kenc", tk, {R, d});
   }
   // attentional GNN (superglue_test.py:122-138)
+  // Latency form (one or two pairs; "latency_forms"): the three products after the attention -- mlp.0', mlp.3 + residual and the
+  // NEXT layer's q|k|v (final_proj after the last layer) -- are ONE launch per layer (gnn_small.hip; same arithmetic, bit for bit,
+  // as the three gemm_small launches it replaces).
+  const bool small_form = h->opt.latency_forms >= 0 ? h->opt.latency_forms != 0 : R <= 4096;
+  bool have_next = false, have_mdesc = false;
   for (size_t l = 0; l < h->layers.size(); ++l) {
     const GnnLayer& L = h->layers[l];
-    if (gemm(h, s, "qkv_proj", L.qkv, x, d, d, nullptr, 0, 0, nullptr, 0, qkv, 3 * d, R, false)) return -1;
+    if (!have_next && gemm(h, s, "qkv_proj", L.qkv, x, d, d, nullptr, 0, 0, nullptr, 0, qkv, 3 * d, R, false)) return -1;
+    have_next = false;
     AttnArgs a{};
     a.qkv = qkv; a.out = att; a.B = B; a.N0p = N0p; a.N1p = N1p; a.d = d; a.heads = HEADS;
     a.n0 = sd[0].n; a.n1 = sd[1].n; a.N0 = N0; a.N1 = N1; a.cross = c.gnn_layer_is_cross[l];
     a.mfma_f32 = h->opt.mfma_f32; a.latency_forms = h->opt.latency_forms;
     RUN("attention", launch_attention(a, s));
-    if (gemm(h, s, "gnn_mlp1", L.mlp1, x, d, d, att, d, d, nullptr, 0, hid, 2 * d, R, true)) return -1;   // merge folded in
-    if (gemm(h, s, "gnn_mlp2", L.mlp2, hid, 2 * d, 2 * d, nullptr, 0, 0, x, d, x, d, R, false)) return -1;
+    const bool last = l + 1 == h->layers.size();
+    const GemmW& nx = last ? h->final_proj : h->layers[l + 1].qkv;
+    GnnSmallArgs ga{x, att, L.mlp1.wf, L.mlp1.b, L.mlp2.wf, L.mlp2.b, nx.wf, nx.b, last ? mdesc : qkv, R, d, nx.N};
+    if (small_form && h->opt.latency_forms != 2 && L.mlp1.Npad == 2 * d && L.mlp2.Npad == d && nx.Npad == nx.N && gnn_layer_small_supported(ga)) {
+      RUN("gnn_layer", launch_gnn_layer_small(ga, s));
+      have_next = !last;
+      have_mdesc = last;
+    } else {
+      if (gemm(h, s, "gnn_mlp1", L.mlp1, x, d, d, att, d, d, nullptr, 0, hid, 2 * d, R, true)) return -1;   // merge folded in
+      if (gemm(h, s, "gnn_mlp2", L.mlp2, hid, 2 * d, 2 * d, nullptr, 0, 0, x, d, x, d, R, false)) return -1;
+    }
     if (h->debug) {
       std::string nm = "gnn" + std::to_string(l);
       WS(tg, float, "tap." + nm, (size_t)R * d * f);
@@ -798,7 +827,7 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
       tap(h, nm.c_str(), tg, {R, d});
     }
   }
-  if (gemm(h, s, "final_proj", h->final_proj, x, d, d, nullptr, 0, 0, nullptr, 0, mdesc, d, R, false)) return -1;
+  if (!have_mdesc && gemm(h, s, "final_proj", h->final_proj, x, d, d, nullptr, 0, 0, nullptr, 0, mdesc, d, R, false)) return -1;
   ScoreArgs sc{mdesc, mdesc + off1 * d, S, B, N0p, N1p, d, (float)(1.0 / std::sqrt((double)d))};
   RUN("score_gemm", launch_score_gemm(sc, s));
   float* part = nullptr;
@@ -821,13 +850,13 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   return 0;
 }
 
-// "mfma" = x3 | f32, "latency_forms" = auto | off | on, "conv" = wino | wx3 | direct.  Returns 0, or -1 for an unknown key / value.
+// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | wx3 | direct.  Returns 0, or -1 for an unknown key / value.
 int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
   Options& o = h->opt;
   if (key == "mfma") {
     if (v == "x3") o.mfma_f32 = 0; else if (v == "f32") o.mfma_f32 = 1; else return -1;
   } else if (key == "latency_forms") {
-    if (v == "auto") o.latency_forms = -1; else if (v == "off" || v == "0") o.latency_forms = 0; else if (v == "on" || v == "1") o.latency_forms = 1; else return -1;
+    if (v == "auto") o.latency_forms = -1; else if (v == "off" || v == "0") o.latency_forms = 0; else if (v == "on" || v == "1") o.latency_forms = 1; else if (v == "unfused") o.latency_forms = 2; else return -1;
   } else if (key == "conv") {
     if (v == "wino") { o.conv_direct = 0; o.conv_wx3 = 0; }
     else if (v == "wx3") { o.conv_direct = 0; o.conv_wx3 = 1; }
@@ -1314,7 +1343,7 @@ int imx_set_option(imx_handle_t h, const char* key, const char* value) {
   return guarded(h, "imx_set_option", [&]() -> int {
     if (!h) return -1;
     if (!key || !value) return fail(h, "imx_set_option: null argument");
-    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on, conv = wino|wx3|direct)", key, value);
+    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wx3|direct)", key, value);
     return 0;
   });
 }
@@ -1325,7 +1354,7 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     const std::string k = key;
     const Options& o = h->opt;
     if (k == "mfma") h->opt_text = o.mfma_f32 ? "f32" : "x3";
-    else if (k == "latency_forms") h->opt_text = o.latency_forms < 0 ? "auto" : o.latency_forms ? "on" : "off";
+    else if (k == "latency_forms") h->opt_text = o.latency_forms < 0 ? "auto" : o.latency_forms == 2 ? "unfused" : o.latency_forms ? "on" : "off";
     else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : o.conv_wx3 ? "wx3" : "wino";
     else h->opt_text.clear();
     return h->opt_text.c_str();

@@ -13,7 +13,8 @@ struct Options {
   int mfma_f32 = 0;        // "mfma": 0 = "x3" (fp32 products as six bf16 term products on the bf16 matrix pipe where a kernel has
                            //         that form), 1 = "f32" (fp32 MFMA everywhere: the A/B reference of the parity tests)
   int latency_forms = -1;  // "latency_forms": -1 = "auto" (gemm_small for M <= 4096 rows, key-split attention for grids of
-                           //         <= 256 workgroups), 0 = "off" (results do not depend on the batch size bit for bit), 1 = "on"
+                           //         <= 256 workgroups, one launch per GNN layer tail), 0 = "off" (results do not depend on the batch size
+                           //         bit for bit), 1 = "on", 2 = "unfused" (on, with the layer tail as three gemm_small launches: the A/B of the fusion)
   int conv_direct = 0;     // "conv": 0 = "wino" (Winograd F(2x4,3x3) on the fp32 MFMA; direct only for shapes it rejects), 1 = "direct"
   int conv_wx3 = 0;        // "conv" = "wx3": the Winograd layers after the first as six bf16 term products on the bf16 pipe (conv3x3_wx3.hip)
 };
@@ -82,6 +83,20 @@ struct GemmArgs {
 };
 // (K0, K1) % 32 == 0.
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+// The tail of one GNN layer for small row counts, fused (gnn_small.hip): hidden = relu([x | att] w1 + b1); x += hidden w2 + b2;
+// out = x w3 + b3 (the next layer's q|k|v, n3 = 3 d, or final_proj, n3 = d).  Weights unpadded, in B-fragment order
+// [K/16][4][N][4] (imx_api.cpp:fragment_order).
+struct GnnSmallArgs {
+  float* x;                             // [M][d], updated in place
+  const float* att;                     // [M][d]
+  const float* w1; const float* b1;     // [2d][2d]
+  const float* w2; const float* b2;     // [2d][d]
+  const float* w3; const float* b3;     // [d][n3]
+  float* out;                           // [M][n3]
+  int M, d, n3;
+};
+bool gnn_layer_small_supported(const GnnSmallArgs& a);
+hipError_t launch_gnn_layer_small(const GnnSmallArgs& a, hipStream_t s);
 // fp32 products as six bf16 term products on the bf16 matrix pipe (gemm_x3.hip): wx3 = the weights as three bf16 terms per value in
 // B-fragment order [Npad/32][K/16][3][64][8]; (K0, K1) % 32 == 0, Npad % 64 == 0, float4-aligned leading dimensions
 bool gemm_x3_supported(const GemmArgs& a);

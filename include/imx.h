@@ -216,8 +216,9 @@ const char* imx_timing_form(imx_handle_t h, int index);
  *                           form (every linear layer, attention at head dims 32/64); "f32" keeps every product on the fp32 MFMA
  *                           (the A/B reference the parity tests hold the default against);
  *   "latency_forms"  "auto" (default) one or two pairs take the latency forms of the linear layers (M <= 4096 rows) and of
- *                           the attention (grids of <= 256 workgroups); "off" never (results then do not depend on the batch
- *                           size bit for bit); "on" whenever the shape allows;
+ *                           the attention (grids of <= 256 workgroups) and one launch per GNN layer tail; "off" never (results
+ *                           then do not depend on the batch size bit for bit); "on" whenever the shape allows; "unfused" = "on" with the GNN layer tail as three
+ *                           launches instead of one (same bytes: the A/B reference of the fused latency kernel);
  *   "conv"           "wino" (default) Winograd F(2x4,3x3) on the fp32 MFMA; "wx3" the same arithmetic with its products as six bf16
  *                           term products on the bf16 pipe for every 3x3 layer after the first (as accurate; slower as of this build);
  *                           "direct" the direct implicit-GEMM kernel for every 3x3 layer.

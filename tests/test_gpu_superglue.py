@@ -235,3 +235,35 @@ def test_full_size_transport_marginals(name):
     np.testing.assert_allclose(P[:, :K].sum(0), 1.0, rtol=3e-4)
     np.testing.assert_allclose(P[:, K].sum(), float(K), rtol=3e-4)
     assert np.all(P[:K].sum(1) > 0.5) and np.all(P[:K].sum(1) < 1.5)
+
+
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_fused_small_layer_equals_the_three_launch_form(d):
+    """Latency form of the GNN layer tail (gnn_small.hip: mlp.0' -> ReLU -> mlp.3 + residual -> the next layer's q|k|v / final_proj
+    in one launch) against the three gemm_small launches it replaces ("latency_forms" = "unfused"): the same MFMA sequence, so
+    the score matrix, the potentials and every output must be the same BYTES -- ragged counts, two pairs, all three widths."""
+    B, N0, N1 = 2, 300, 171
+    g = torch.Generator().manual_seed(31 + d)
+    t = {"keypoints0": torch.rand(B, N0, 2, generator=g) * torch.tensor([639.0, 479.0]), "keypoints1": torch.rand(B, N1, 2, generator=g) * torch.tensor([639.0, 479.0]),
+         "scores0": torch.rand(B, N0, generator=g), "scores1": torch.rand(B, N1, generator=g),
+         "descriptors0": torch.nn.functional.normalize(torch.randn(B, d, N0, generator=g), dim=1),
+         "descriptors1": torch.nn.functional.normalize(torch.randn(B, d, N1, generator=g), dim=1)}
+    tc = {k: v.cuda() for k, v in t.items()}
+    n0 = torch.tensor([N0, 123], dtype=torch.int32).cuda()
+    n1 = torch.tensor([77, N1], dtype=torch.int32).cuda()
+    eng, L = _engine(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(d))
+    eng.set_debug(True)
+    eng.set_timing(True)
+    res = {}
+    for forms in ("on", "unfused"):
+        eng.set_option("latency_forms", forms)
+        eng.timing_reset()
+        out = eng.superglue(tc["keypoints0"], tc["scores0"], tc["descriptors0"], (1, 1, 480, 640),
+                            tc["keypoints1"], tc["scores1"], tc["descriptors1"], (1, 1, 480, 640), n0, n1)
+        torch.cuda.synchronize()
+        names = {r[0] for r in eng.timing_report(forms=True)}
+        assert ("gnn_layer" in names) == (forms == "on") and ("gnn_mlp1" in names) == (forms == "unfused"), names
+        res[forms] = [o.cpu().numpy() for o in out] + [eng.fetch("scores_in"), eng.fetch("x"), eng.fetch("u")]
+    for a, b in zip(res["on"], res["unfused"]):
+        assert np.array_equal(a, b)
