@@ -607,7 +607,7 @@ int gemm(imx_handle_t h, hipStream_t s, const char* name, const GemmW& W, const 
 
 // ----------------------------------------------------------------------------- SuperPoint
 int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, int B, int H, int W, int32_t* counts_out,
-              hipStream_t s, bool dense_only = false) {
+              hipStream_t s, bool dense_only = false, int32_t* counts_lo = nullptr, int32_t* counts_hi = nullptr) {
   if (!h->finalized[IMX_NET_SUPERPOINT]) return fail(h, "SuperPoint weights not finalized");
   if (B <= 0 || H < 8 || W < 8) return fail(h, "bad image batch shape B=%d H=%d W=%d", B, H, W);
   const imx_config_t& c = h->cfg;
@@ -685,6 +685,7 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   WS(sel_score, float, "kp.sel_score", (size_t)B * Ksel * 4);
   k.row_count = row_count; k.row_off = row_off; k.cand_count = cand_count; k.cand_idx = cand_idx; k.cand_score = cand_score;
   k.sel_count = sel_count; k.sel_idx = sel_idx; k.sel_score = sel_score;
+  k.counts_out[0] = counts_out; k.counts_out[1] = counts_lo; k.counts_out[2] = counts_hi; k.counts_split = split;   // written by kp_topk itself
   if (c.max_keypoints > 16384) {      // beyond the LDS sort of kp_topk: its sort slots live in HBM (slow, but nothing is refused)
     size_t P = 1;
     while (P < (size_t)c.max_keypoints) P <<= 1;
@@ -692,7 +693,6 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
     k.sort_scratch = slots;
   }
   RUN("keypoints", launch_keypoints(k, s));
-  if (counts_out) HIP_OK(h, hipMemcpyAsync(counts_out, sel_count, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
 
   h->det_B = B; h->det_H = H; h->det_W = W; h->det_Hc = Hc; h->det_Wc = Wc; h->det_Ksel = Ksel;
   tap(h, "a1", a1, {B, H2, W2, 64}, blocked);
@@ -752,8 +752,9 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   WS(hid, float, "sg.hid", (size_t)R * 2 * d * f);
   WS(mdesc, float, "sg.mdesc", (size_t)R * d * f);
   WS(S, float, "sg.S", (size_t)B * N0p * N1p * f);
-  WS(u, float, "sg.u", (size_t)B * (N0p + 1) * f);
-  WS(v, float, "sg.v", (size_t)B * (N1p + 1) * f);
+  WS(uv, float, "sg.uv", ((size_t)B * (N0p + 1) + (size_t)B * (N1p + 1)) * f);     // u then v, contiguous: ONE memset zeroes both
+  float* u = uv;
+  float* v = uv + (size_t)B * (N0p + 1);
   WS(max0, float, "sg.max0", (size_t)B * N0p * f);
   WS(max1, float, "sg.max1", (size_t)B * N1p * f);
   WS(idx0, int, "sg.idx0", (size_t)B * N0p * 4);
@@ -1052,13 +1053,11 @@ int imx_match_pairs(imx_handle_t h, const float* img0_dev, const float* img1_dev
     const int K = h->cfg.max_keypoints, d = h->cfg.descriptor_dim;
     if (K <= 0) return fail(h, "imx_match_pairs needs max_keypoints > 0 (fixed-size outputs); got %d", K);
     WS(counts, int32_t, "mp.counts", (size_t)2 * B * 4);
-    if (sp_detect(h, img0_dev, img1_dev, B, 2 * B, H, W, counts, s)) return -1;
+    if (sp_detect(h, img0_dev, img1_dev, B, 2 * B, H, W, counts, s, false, counts0_dev, counts1_dev)) return -1;
     if (!desc0_dev) { WS(t0, float, "mp.desc0", (size_t)B * K * d * 4); desc0_dev = t0; }
     if (!desc1_dev) { WS(t1, float, "mp.desc1", (size_t)B * K * d * 4); desc1_dev = t1; }
     if (sp_describe(h, 0, B, K, kpts0_dev, scores0_dev, desc0_dev, s)) return -1;
     if (sp_describe(h, B, B, K, kpts1_dev, scores1_dev, desc1_dev, s)) return -1;
-    if (counts0_dev) HIP_OK(h, hipMemcpyAsync(counts0_dev, counts, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
-    if (counts1_dev) HIP_OK(h, hipMemcpyAsync(counts1_dev, counts + B, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
     const int H8 = h->det_Hc * 8, W8 = h->det_Wc * 8;
     (void)H8; (void)W8;
     SgSide sd[2] = {{kpts0_dev, scores0_dev, desc0_dev, (int64_t)K * d, 1, d, counts, K, H, W},

@@ -135,6 +135,8 @@ struct KeypointArgs {
   int* cand_idx;             // (B,H*W) linear index y*W+x, row-major order
   float* cand_score;         // (B,H*W)
   int* sel_count;            // (B)   kept keypoints
+  int* counts_out[3];        // optional copies of sel_count written by the same kernel (a 4-byte device-to-device copy is a ~4 us
+  int counts_split;          //   stream operation): [0] all B; [1] images b < counts_split; [2] images b >= counts_split, rebased
   int* sel_idx;              // (B,Ksel)  Ksel = max_keypoints >=0 ? max_keypoints : H*W
   float* sel_score;          // (B,Ksel)
   int Ksel;

@@ -321,6 +321,13 @@ __device__ int block_scan_1024(int v, int* wsum /*[17]*/, int* tot) {
   return res;
 }
 
+__device__ __forceinline__ void kp_store_count(const KeypointArgs& a, int b, int n) {
+  a.sel_count[b] = n;
+  if (a.counts_out[0]) a.counts_out[0][b] = n;
+  if (b < a.counts_split) { if (a.counts_out[1]) a.counts_out[1][b] = n; }
+  else if (a.counts_out[2]) a.counts_out[2][b - a.counts_split] = n;
+}
+
 // top-k per image: radix select of the k-th largest score, ordered tie handling (lowest index
 // first), then bitonic sort of the k survivors by (score desc, index asc) = torch.topk's sorted
 // output (:33-37) with a deterministic tie rule.  If count <= k (or k < 0) the row-major
@@ -330,11 +337,14 @@ __device__ int block_scan_1024(int v, int* wsum /*[17]*/, int* tot) {
 __global__ __launch_bounds__(1024) void kp_topk(KeypointArgs a, int P /* pow2 >= k */) {
   extern __shared__ unsigned long long lds_keys[];   // P entries when P <= 16384
   unsigned long long* keys = P <= 16384 ? lds_keys : a.sort_scratch + (size_t)blockIdx.x * P;
-  __shared__ int hist[256];
+  // round 3 (single-pair latency: this kernel was 76 us of a 1.7 ms pair): one histogram per wave (the top byte of a score in
+  // (0.005, 1) takes two or three values: 7000 atomics on three LDS words), the digit picked by a 256-thread scan instead of a
+  // serial walk, survivors placed with one atomic per wave, and the sort's 45 in-wave stages (partner distance < 64) as shuffles
+  __shared__ int hist[16][256];
   __shared__ int wsum[17];
   __shared__ unsigned sh_prefix;
   __shared__ int sh_kth, sh_npos;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = a.cand_count[b];
   const int K = a.max_keypoints;
   const int* ci = a.cand_idx + (size_t)b * a.H * a.W;
@@ -343,40 +353,55 @@ __global__ __launch_bounds__(1024) void kp_topk(KeypointArgs a, int P /* pow2 >=
   float* ss = a.sel_score + (size_t)b * a.Ksel;
 
   if (K == 0) {
-    if (tid == 0) a.sel_count[b] = 0;
+    if (tid == 0) kp_store_count(a, b, 0);
     return;
   }
   if (K < 0 || n <= K) {
     for (int i = tid; i < n; i += 1024) { si[i] = ci[i]; ss[i] = cs[i]; }
-    if (tid == 0) a.sel_count[b] = n;
+    if (tid == 0) kp_store_count(a, b, n);
     return;
   }
   // ---- radix select (scores are positive floats: bit pattern is monotone)
   unsigned prefix = 0, mask = 0;
   int kth = K;
   for (int pass = 3; pass >= 0; --pass) {
-    if (tid < 256) hist[tid] = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) (&hist[0][0])[tid + 1024 * e] = 0;
     __syncthreads();
     const int sh = 8 * pass;
     for (int i = tid; i < n; i += 1024) {
       unsigned key = __float_as_uint(cs[i]);
-      if ((key & mask) == prefix) atomicAdd(&hist[(key >> sh) & 255], 1);
+      if ((key & mask) == prefix) atomicAdd(&hist[wave][(key >> sh) & 255], 1);
     }
     __syncthreads();
-    if (tid == 0) {
-      int cum = 0, d = 255;
-      for (; d > 0; --d) {
-        if (cum + hist[d] >= kth) break;
-        cum += hist[d];
+    // digit d = 255 - tid (descending): inclusive count of keys with a digit >= d; the digit of the k-th largest is the one
+    // whose count reaches kth
+    int h = 0, inc = 0;
+    if (tid < 256) {
+#pragma unroll
+      for (int w = 0; w < 16; ++w) h += hist[w][255 - tid];
+      inc = h;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
       }
-      sh_kth = kth - cum;
-      sh_prefix = prefix | ((unsigned)d << sh);
+      if (lane == 63) wsum[wave] = inc;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      int base = 0;
+      for (int w = 0; w < wave; ++w) base += wsum[w];
+      inc += base;
+      if (inc >= kth && inc - h < kth) {        // exactly one thread: the counts are non-decreasing and the last one is >= kth
+        sh_kth = kth - (inc - h);
+        sh_prefix = prefix | ((unsigned)(255 - tid) << sh);
+      }
     }
     __syncthreads();
     kth = sh_kth;
     prefix = sh_prefix;
     mask |= 0xFFu << sh;
-    __syncthreads();
   }
   const unsigned pivot = prefix;       // bit pattern of the k-th largest score
   const int take_eq = kth;             // how many scores == pivot to keep (lowest indices first)
@@ -390,17 +415,59 @@ __global__ __launch_bounds__(1024) void kp_topk(KeypointArgs a, int P /* pow2 >=
     unsigned key = i < n ? __float_as_uint(cs[i]) : 0u;
     int idx = i < n ? ci[i] : 0;
     bool gt = i < n && key > pivot, eq = i < n && key == pivot;
-    int tot;
-    int er = block_scan_1024(eq ? 1 : 0, wsum, &tot);
-    bool take = gt || (eq && (eq_base + er) < take_eq);
-    eq_base += tot;
-    if (take) {
-      int pos = atomicAdd(&sh_npos, 1);
-      keys[pos] = ((unsigned long long)key << 32) | (unsigned)(~(unsigned)idx);
+    // ties at the pivot are kept lowest index first: their rank needs a block scan only in a chunk that holds some of them and
+    // cannot take them all (scores are almost always distinct: one barrier per chunk instead of three)
+    const int ne = __syncthreads_count(eq);
+    bool take = gt;
+    if (ne > 0) {
+      if (eq_base + ne <= take_eq) {
+        take = gt || eq;
+      } else {
+        int tot;
+        const int er = block_scan_1024(eq ? 1 : 0, wsum, &tot);
+        take = gt || (eq && (eq_base + er) < take_eq);
+      }
+      eq_base += ne;
+    }
+    const unsigned long long bal = __ballot(take);
+    if (bal) {
+      int base = 0;
+      const int first = __ffsll((long long)bal) - 1;
+      if (lane == first) base = atomicAdd(&sh_npos, __popcll(bal));
+      base = __shfl(base, first);
+      if (take) keys[base + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned long long)key << 32) | (unsigned)(~(unsigned)idx);
     }
   }
   __syncthreads();
   // ---- bitonic sort, descending
+  if (P <= 1024) {
+    // one key per thread in a register; partner distances below 64 are in-wave shuffles, the others go through LDS
+    unsigned long long x = tid < P ? keys[tid] : 0ull;
+    for (int k2 = 2; k2 <= P; k2 <<= 1) {
+      const bool desc = (tid & k2) == 0;
+      for (int j = k2 >> 1; j > 0; j >>= 1) {
+        unsigned long long y;
+        if (j >= 64) {
+          __syncthreads();                       // every thread has read its partner of the previous LDS stage
+          if (tid < P) keys[tid] = x;
+          __syncthreads();
+          y = tid < P ? keys[tid ^ j] : 0ull;
+        } else {
+          const unsigned lo = __shfl_xor((unsigned)(x & 0xFFFFFFFFull), j), hi = __shfl_xor((unsigned)(x >> 32), j);
+          y = ((unsigned long long)hi << 32) | lo;
+        }
+        const bool lower = (tid & j) == 0;       // the lower index of the pair keeps the larger key in a descending run
+        const bool want_max = desc == lower;
+        x = want_max ? (x > y ? x : y) : (x < y ? x : y);
+      }
+    }
+    if (tid < K) {
+      si[tid] = (int)(~(unsigned)(x & 0xFFFFFFFFull));
+      ss[tid] = __uint_as_float((unsigned)(x >> 32));
+    }
+    if (tid == 0) kp_store_count(a, b, K);
+    return;
+  }
   for (int k2 = 2; k2 <= P; k2 <<= 1) {
     for (int j = k2 >> 1; j > 0; j >>= 1) {
       for (int i = tid; i < P; i += 1024) {
@@ -419,7 +486,7 @@ __global__ __launch_bounds__(1024) void kp_topk(KeypointArgs a, int P /* pow2 >=
     si[i] = (int)(~(unsigned)(kk & 0xFFFFFFFFull));
     ss[i] = __uint_as_float((unsigned)(kk >> 32));
   }
-  if (tid == 0) a.sel_count[b] = K;
+  if (tid == 0) kp_store_count(a, b, K);
 }
 
 // ------------------------------------------------------------------ descriptors
