@@ -330,3 +330,44 @@ def test_matching_forward_random_sizes_vs_oracle_on_its_own_features(seed):
     m1 = pred["matches1"][0].cpu().numpy()
     i = np.nonzero(mine0 > -1)[0]
     assert np.array_equal(m1[mine0[i]], i), what + ": matches1 inconsistent with matches0"
+
+
+def test_two_handles_on_two_host_threads_and_streams():
+    """include/imx.h: a handle is not thread-safe, different handles are independent -- one host thread per handle is the serving
+    model.  Two Matching objects (two handles, separate workspaces and weights) driven concurrently from two host threads, each on
+    its own HIP stream (ctypes releases the GIL for the duration of a C call), must give what each gives alone, bit for bit, every
+    time."""
+    import threading
+    d, K, H, W = 128, 512, 240, 320
+    ms = [_matching(d, K), _matching(d, K)]
+    pairs = [[util.pair(700 + 10 * t + i, H, W) for i in range(3)] for t in range(2)]
+    ins = [(torch.cat([p[0] for p in ps]).cuda(), torch.cat([p[1] for p in ps]).cuda()) for ps in pairs]
+    keys = ("keypoints0", "keypoints1", "scores0", "matches0", "matches1", "matching_scores0", "matching_scores1", "counts0", "counts1")
+    alone = []
+    for t in range(2):
+        out = ms[t].match_batch(*ins[t])
+        torch.cuda.synchronize()
+        alone.append({k: out[k].clone() for k in keys})
+    errors = []
+
+    def worker(t):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for it in range(12):
+                    out = ms[t].match_batch(*ins[t])
+                    stream.synchronize()
+                    for k in keys:
+                        if not torch.equal(out[k], alone[t][k]):
+                            errors.append(f"thread {t} iteration {it}: {k} differs from the single-threaded run")
+                            return
+        except Exception as e:            # noqa: BLE001 -- reported through the list, the assert below fails the test
+            errors.append(f"thread {t}: {type(e).__name__}: {e}")
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not any(th.is_alive() for th in threads), "a worker thread did not finish"
+    assert not errors, errors
