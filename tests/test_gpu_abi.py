@@ -126,3 +126,57 @@ def test_gather_records_through_the_c_abi_over_rccl():
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_bad_calls_return_errors_with_messages_and_leave_the_handle_usable():
+    """Every entry point returns 0 / <0 and never throws or aborts across the ABI (include/imx.h).  A sequence of wrong calls --
+    forward before the weights are loaded, a state-dict key the reference's module does not have, a tensor of the wrong shape
+    (the reference's load_state_dict messages: superpoint_test.py:87-99), a missing key at finalize, shapes that make no sense,
+    unknown options and taps, null pointers -- each fails with a message, and the same handle then loads the weights and matches
+    a pair as if nothing had happened."""
+    import ctypes
+    from image_matching_amd import _lib as L
+    from image_matching_amd.engine import Engine, ImxError
+    d, K, H, W = 128, 200, 120, 160
+    eng = Engine(util.sp_config(d, K), util.sg_config(d), "cuda")
+    lib, h = eng.lib, eng.handle
+    err = lambda: lib.imx_last_error(h).decode()
+    x = torch.cat(util.pair(3, H, W)).cuda()
+    counts = torch.zeros(2, dtype=torch.int32, device="cuda")
+    fp = lambda t: ctypes.cast(t.data_ptr(), ctypes.POINTER(ctypes.c_float))
+    # forward before load_state_dict
+    assert lib.imx_superpoint_detect(h, fp(x), 2, H, W, counts.data_ptr(), None) < 0 and "not finalized" in err()
+    # keys and shapes
+    w = torch.zeros(64, 1, 3, 3)
+    shape = (ctypes.c_int64 * 4)(64, 1, 3, 3)
+    assert lib.imx_load_weight(h, L.NET_SUPERPOINT, b"inc.conv.conv.0.weights", w.data_ptr(), 4, shape) < 0 and "unexpected key" in err().lower()
+    bad = (ctypes.c_int64 * 4)(32, 1, 3, 3)
+    assert lib.imx_load_weight(h, L.NET_SUPERPOINT, b"inc.conv.conv.0.weight", w.data_ptr(), 4, bad) < 0 and "size mismatch" in err()
+    assert lib.imx_load_weight(h, 7, b"inc.conv.conv.0.weight", w.data_ptr(), 4, shape) < 0 and "net" in err()
+    assert lib.imx_load_weight(h, L.NET_SUPERPOINT, None, w.data_ptr(), 4, shape) < 0
+    assert lib.imx_load_weight(h, L.NET_SUPERPOINT, b"inc.conv.conv.0.weight", w.data_ptr(), 4, shape) == 0
+    assert lib.imx_finalize_weights(h, L.NET_SUPERPOINT) < 0 and "Missing key" in err()
+    # options, taps
+    assert lib.imx_set_option(h, b"mfma", b"fp8") < 0 and lib.imx_set_option(h, b"nonsense", b"1") < 0 and lib.imx_set_option(h, None, b"1") < 0
+    assert lib.imx_get_option(h, b"nonsense") == b""
+    with pytest.raises(ImxError):
+        eng.fetch("no_such_tap")
+    # now the real weights; then wrong shapes on the forward calls
+    eng.load_state_dict(L.NET_SUPERPOINT, util.sp_sd(d))
+    eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(d))
+    assert lib.imx_superpoint_detect(h, fp(x), 0, H, W, counts.data_ptr(), None) < 0 and "shape" in err()
+    assert lib.imx_superpoint_detect(h, fp(x), 2, 4, W, counts.data_ptr(), None) < 0
+    kp = torch.zeros(1, 50, 2, device="cuda"); sc = torch.zeros(1, 50, device="cuda"); ds = torch.zeros(1, d, 50, device="cuda")
+    m = torch.zeros(1, 50, dtype=torch.int64, device="cuda"); ms = torch.zeros(1, 50, device="cuda")
+    args = lambda B, N0: (h, B, fp(kp), fp(sc), fp(ds), d * 50, 50, 1, None, N0, H, W, fp(kp), fp(sc), fp(ds), d * 50, 50, 1, None, 50, H, W,
+                          m.data_ptr(), m.data_ptr(), fp(ms), fp(ms), None)
+    assert lib.imx_superglue_forward(*args(0, 50)) < 0 and "shape" in err()
+    assert lib.imx_superglue_forward(*args(1, -3)) < 0
+    with pytest.raises(ImxError):                          # descriptor width that is not the configured one
+        eng.superglue(kp, sc, torch.zeros(1, 64, 50, device="cuda"), (1, 1, H, W), kp, sc, ds, (1, 1, H, W))
+    assert lib.imx_estimate_affine_partial(h, fp(kp), fp(kp), m.data_ptr(), None, 0, 50, 7.0, 16, 1, fp(ms), m.data_ptr(), counts.data_ptr(), None) < 0
+    assert lib.imx_timing_report(h, 10 ** 6, None, None, None) < 0
+    # and the handle works
+    out = eng.match_pairs(x[:1], x[1:], want_desc=True)
+    torch.cuda.synchronize()
+    assert int(out["counts0"][0]) == K and int((out["matches0"] >= 0).sum()) > 0
