@@ -205,9 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
     for (int jj = 0; jj < 6; ++jj) *reinterpret_cast<f32x2*>(vwr + (2 * jj) * QSL * 4) = T[jj];
   }
 
-  f32x4 acc[24];
-#pragma unroll
-  for (int q = 0; q < 24; ++q) acc[q] = w24_zero4();
+  f32x4 acc[24];          // never cleared: an item's first chunk starts every accumulator from a literal-zero C operand
   const f32x2 k8 = {8.f, 8.f};
   // ---- store offsets.  FASTW (the width is a whole number of tiles: every SuperPoint layer at 640x480 and
   //      1280x960): a lane's byte offsets relative to its item's first pixel never change.  The item part (tile origin,
@@ -241,8 +239,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
   // compile-time constant: every LDS address of a phase is then a per-thread base + an immediate offset (the run-time parity
   // cost 8 v_add_u32 + 3 v_lshl_add per phase, each ~4.5 cycles of matrix-pipe time).  An item has an even number of chunks
   // (Cin % 32 == 0), so the parity of a stream position is the parity of its chunk index and items end after an odd phase.
-  auto phase = [&](auto parc, int c) __attribute__((always_inline)) {
+  // FIRST (an item's chunk 0): the MFMAs' C operand is the literal 0 instead of the accumulator -- clearing 24 accumulators was 48
+  // v_mov_b64 in the epilogue, where a VALU instruction costs ~25 cycles beside the co-resident workgroup's MFMA stream (round 3:
+  // the epilogue's store phase 3.0 k -> cycles per item in the cycle trace)
+  const f32x4 zero4c = {0.f, 0.f, 0.f, 0.f};
+  auto phase = [&](auto parc, auto firstc, int c) __attribute__((always_inline)) {
     constexpr int par = decltype(parc)::value ? 1 : 0;
+    constexpr bool FIRST = decltype(firstc)::value;
     __syncthreads();               // V[par] and raw[par ^ 1] (position s+1) complete; the buffers written below are free
     IMX_TS(0)
     {
@@ -263,8 +266,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
       for (int g = 0; g < NQ; ++g) {
         const int cu = g & 1, nx = cu ^ 1;
         if (g + 1 < NQ) af[nx] = *reinterpret_cast<const f32x4*>(vr + (g + 1) * QSL * 4);
-        acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][0], af[cu][0], acc[2 * g], 0, 0, 0);
-        acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][2], af[cu][2], acc[2 * g + 1], 0, 0, 0);
+        acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][0], af[cu][0], FIRST ? zero4c : acc[2 * g], 0, 0, 0);
+        acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][2], af[cu][2], FIRST ? zero4c : acc[2 * g + 1], 0, 0, 0);
         acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][1], af[cu][1], acc[2 * g], 0, 0, 0);
         acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][3], af[cu][3], acc[2 * g + 1], 0, 0, 0);
         bf[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, voff, uoff + g * 4096, 0));
@@ -298,10 +301,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
   };
 #pragma unroll 1
   for (;;) {
-    phase(BoolC<false>{}, chunk);
-    phase(BoolC<true>{}, chunk + 1);
-    chunk += 2;
-    if (chunk < nchunk) continue;
+    phase(BoolC<false>{}, BoolC<true>{}, 0);
+    phase(BoolC<true>{}, BoolC<false>{}, 1);
+#pragma unroll 1
+    for (chunk = 2; chunk < nchunk; chunk += 2) {
+      phase(BoolC<false>{}, BoolC<false>{}, chunk);
+      phase(BoolC<true>{}, BoolC<false>{}, chunk + 1);
+    }
 
     // ---- item done: output transform Y = A2^T M A4, bias, ReLU, (2x2 max-pool), stores straight from registers.
     //      The MFMAs take U as their A operand and V as B, so D is [channel][wtile]: acc[j*4 + i][r] belongs to wtile
@@ -354,8 +360,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24(ConvArgs p, int tiles_x
           }
       }
     }
-#pragma unroll
-    for (int q = 0; q < 24; ++q) acc[q] = w24_zero4();
     IMX_TS(3)
     ++nitem_done;
     item_c += grid;
