@@ -88,8 +88,7 @@ def algorithmic_work(B, H, W, d, K, kenc, iters, n_layers=18):
         "nms": ("hbm", 4.0 * I * 2 * H * W),
         "keypoints": ("hbm", 4.0 * I * H * W),
         "describe": ("hbm", 4.0 * I * K * (4 * d + d + 3)),
-        "gather_desc": ("hbm", 4.0 * 2 * R * d / 2),
-        "kenc0": ("hbm", 4.0 * R * (3 + kenc[0])),
+        "sg_prologue": ("hbm", 4.0 * 2 * R * d / 2 + 4.0 * R * (3 + kenc[0])),     # descriptor gather + kenc layer 0, both sides
         "qkv_proj": ("mfma", 2.0 * R * d * 3 * d),
         "attention": ("mfma", 2.0 * 2 * B * 2 * K * K * d),
         # attn.merge (d->d) is folded into mlp.0's weights at load; its reference FLOPs stay in the count

@@ -706,7 +706,8 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   return 0;
 }
 
-int sp_describe(imx_handle_t h, int b0, int B, int Kcap, float* kpts, float* scores, float* desc, hipStream_t s) {
+int sp_describe(imx_handle_t h, int b0, int B, int Kcap, float* kpts, float* scores, float* desc, hipStream_t s,
+                int split = -1, float* kpts2 = nullptr, float* scores2 = nullptr, float* desc2 = nullptr) {
   if (h->det_B <= 0 || b0 + B > h->det_B) return fail(h, "describe: no matching imx_superpoint_detect (B=%d, detect B=%d)", B, h->det_B);
   DescribeArgs a{};
   a.dense = static_cast<const float*>(h->bufs["sp.dense"].p);
@@ -715,6 +716,7 @@ int sp_describe(imx_handle_t h, int b0, int B, int Kcap, float* kpts, float* sco
   a.sel_idx = static_cast<const int*>(h->bufs["kp.sel_idx"].p);
   a.sel_score = static_cast<const float*>(h->bufs["kp.sel_score"].p);
   a.Ksel = h->det_Ksel; a.b0 = b0; a.B = B; a.Kcap = Kcap; a.kpts = kpts; a.scores = scores; a.desc = desc;
+  a.split = split >= 0 ? split : B; a.kpts2 = kpts2; a.scores2 = scores2; a.desc2 = desc2;
   a.align_corners = h->cfg.align_corners; a.dense_eps = h->cfg.sp_variant == IMX_SP_VARIANT_OFFICIAL ? 1 : 0;
   RUN("describe", launch_describe(a, s));
   return 0;
@@ -760,19 +762,23 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   WS(idx0, int, "sg.idx0", (size_t)B * N0p * 4);
   WS(idx1, int, "sg.idx1", (size_t)B * N1p * 4);
 
-  // descriptors -> rows; keypoint encoder (superglue_test.py:245-250)
-  for (int sidx = 0; sidx < 2; ++sidx) {
-    const SgSide& q = sd[sidx];
-    const int Np = sidx ? N1p : N0p;
-    float* xr = x + (sidx ? off1 : 0) * d;
-    RUN("gather_desc", launch_gather_desc(q.desc, q.sb, q.sc, q.sn, B, q.N, Np, d, xr, s));
-    Kenc0Args k{};
-    k.kpts = q.kpts; k.scores = q.scores; k.B = B; k.N = q.N; k.Np = Np;
-    k.cx = (float)q.W / 2.0f; k.cy = (float)q.H / 2.0f;
-    k.scaling = (float)std::max(q.W, q.H) * 0.7f;
-    k.w = h->kenc0_w; k.bias = h->kenc0_b; k.C1 = h->kenc_c1;
-    k.out = ta + (sidx ? off1 : 0) * h->kenc_c1;
-    RUN("kenc0", launch_kenc0(k, s));
+  // descriptors -> rows; first keypoint-encoder layer (superglue_test.py:245-250): both sides, one launch
+  {
+    SgPrologueArgs pa{};
+    pa.d = d;
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const SgSide& q = sd[sidx];
+      const int Np = sidx ? N1p : N0p;
+      pa.desc[sidx] = q.desc; pa.sb[sidx] = (long)q.sb; pa.sc[sidx] = (long)q.sc; pa.sn[sidx] = (long)q.sn;
+      pa.xrow[sidx] = x + (sidx ? off1 : 0) * d;
+      Kenc0Args& k = pa.k[sidx];
+      k.kpts = q.kpts; k.scores = q.scores; k.B = B; k.N = q.N; k.Np = Np;
+      k.cx = (float)q.W / 2.0f; k.cy = (float)q.H / 2.0f;
+      k.scaling = (float)std::max(q.W, q.H) * 0.7f;
+      k.w = h->kenc0_w; k.bias = h->kenc0_b; k.C1 = h->kenc_c1;
+      k.out = ta + (sidx ? off1 : 0) * h->kenc_c1;
+    }
+    RUN("sg_prologue", launch_sg_prologue(pa, s));
   }
   {
     float* cur = ta;
@@ -1056,8 +1062,7 @@ int imx_match_pairs(imx_handle_t h, const float* img0_dev, const float* img1_dev
     if (sp_detect(h, img0_dev, img1_dev, B, 2 * B, H, W, counts, s, false, counts0_dev, counts1_dev)) return -1;
     if (!desc0_dev) { WS(t0, float, "mp.desc0", (size_t)B * K * d * 4); desc0_dev = t0; }
     if (!desc1_dev) { WS(t1, float, "mp.desc1", (size_t)B * K * d * 4); desc1_dev = t1; }
-    if (sp_describe(h, 0, B, K, kpts0_dev, scores0_dev, desc0_dev, s)) return -1;
-    if (sp_describe(h, B, B, K, kpts1_dev, scores1_dev, desc1_dev, s)) return -1;
+    if (sp_describe(h, 0, 2 * B, K, kpts0_dev, scores0_dev, desc0_dev, s, B, kpts1_dev, scores1_dev, desc1_dev)) return -1;   // both sides, one launch
     const int H8 = h->det_Hc * 8, W8 = h->det_Wc * 8;
     (void)H8; (void)W8;
     SgSide sd[2] = {{kpts0_dev, scores0_dev, desc0_dev, (int64_t)K * d, 1, d, counts, K, H, W},

@@ -151,6 +151,8 @@ struct DescribeArgs {
   int b0;                                    // first image (index into dense / sel_*) of this call
   int B, Kcap;
   float* kpts; float* scores; float* desc;   // (B,Kcap,2) (B,Kcap) (B,Kcap,d); rows >= count zeroed
+  float* kpts2; float* scores2; float* desc2; int split;   // images >= split (rebased) go to this second set: both sides of
+                                             // imx_match_pairs in one launch; split = B and nulls otherwise
   int align_corners; int dense_eps;          // dense_eps: 1 = F.normalize(eps 1e-12), 0 = plain division
 };
 hipError_t launch_describe(const DescribeArgs& a, hipStream_t s);
@@ -165,7 +167,15 @@ struct Kenc0Args {
   int C1;
   float* out;                              // rows (b*Np + i), ld = C1; rows >= N zeroed
 };
-hipError_t launch_kenc0(const Kenc0Args& a, hipStream_t s);
+// SuperGlue's prologue for BOTH sides in one launch: the descriptor gather and the first keypoint-encoder layer (four launches of
+// ~4.5 us each on the single-pair path).  Same per-element arithmetic as launch_gather_desc / launch_kenc0.
+struct SgPrologueArgs {
+  const float* desc[2]; long sb[2], sc[2], sn[2];   // descriptors (arbitrary strides) per side
+  float* xrow[2];                                    // rows (b*Np + i), ld = d
+  Kenc0Args k[2];                                    // B, N, Np per side in here
+  int d;
+};
+hipError_t launch_sg_prologue(const SgPrologueArgs& a, hipStream_t s);
 // copy descriptors (arbitrary strides) into rows (b*Np+i), ld=d; rows >= N zero.
 hipError_t launch_gather_desc(const float* src, int64_t sb, int64_t sc, int64_t sn, int B, int N, int Np, int d,
                               float* out, hipStream_t s);

@@ -48,28 +48,6 @@ __device__ __forceinline__ float lse_value(const LSE& a) { return a.m + logf(a.s
 __device__ __forceinline__ float lse_unbias(float sum, float mx, float ml) { return fmaf(sum, -0.69314718f * fmaf(mx, LOG2E, ml), sum); }
 
 // ------------------------------------------------------------------ kenc layer 0
-__global__ __launch_bounds__(256) void kenc0_kernel(Kenc0Args a, float scaling) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  const long total = (long)a.B * a.Np * a.C1;
-  if (e >= total) return;
-  const int c = (int)(e % a.C1);
-  const long row = e / a.C1;
-  const int i = (int)(row % a.Np), b = (int)(row / a.Np);
-  float v = 0.f;
-  if (i < a.N) {
-    const float* kp = a.kpts + ((size_t)b * a.N + i) * 2;
-    const float xn = (kp[0] - a.cx) / scaling;          // normalize_keypoints (:63-70)
-    const float yn = (kp[1] - a.cy) / scaling;
-    const float sc = a.scores[(size_t)b * a.N + i];
-    v = a.bias[c];
-    v = fmaf(a.w[c], xn, v);
-    v = fmaf(a.w[a.C1 + c], yn, v);
-    v = fmaf(a.w[2 * a.C1 + c], sc, v);
-    v = fmaxf(v, 0.f);
-  }
-  a.out[e] = v;
-}
-
 __global__ __launch_bounds__(256) void gather_desc_kernel(const float* __restrict__ src, long sb, long sc, long sn,
                                                           int B, int N, int Np, int d, float* __restrict__ out) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -79,6 +57,46 @@ __global__ __launch_bounds__(256) void gather_desc_kernel(const float* __restric
   const long row = e / d;
   const int i = (int)(row % Np), b = (int)(row / Np);
   out[e] = i < N ? src[b * sb + c * sc + i * sn] : 0.f;
+}
+
+// both sides' gather + kenc layer 0 in one grid: blocks [0, g0) gather side 0, [g0, k0) kenc0 side 0, [k0, g1) gather side 1,
+// [g1, ...) kenc0 side 1 -- the element functions above, unchanged
+__device__ __forceinline__ void kenc0_element(const Kenc0Args& a, long e) {
+  const long total = (long)a.B * a.Np * a.C1;
+  if (e >= total) return;
+  const int c = (int)(e % a.C1);
+  const long row = e / a.C1;
+  const int i = (int)(row % a.Np), b = (int)(row / a.Np);
+  float v = 0.f;
+  if (i < a.N) {
+    const float* kp = a.kpts + ((size_t)b * a.N + i) * 2;
+    const float xn = (kp[0] - a.cx) / a.scaling;          // normalize_keypoints (:63-70)
+    const float yn = (kp[1] - a.cy) / a.scaling;
+    const float sc = a.scores[(size_t)b * a.N + i];
+    v = a.bias[c];
+    v = fmaf(a.w[c], xn, v);
+    v = fmaf(a.w[a.C1 + c], yn, v);
+    v = fmaf(a.w[2 * a.C1 + c], sc, v);
+    v = fmaxf(v, 0.f);
+  }
+  a.out[e] = v;
+}
+__global__ __launch_bounds__(256) void sg_prologue_kernel(SgPrologueArgs a, unsigned g0, unsigned k0, unsigned g1) {
+  const unsigned blk = blockIdx.x;
+  const int side = blk >= k0 ? 1 : 0;
+  const unsigned base = side ? k0 : 0u, gend = side ? g1 : g0;
+  const Kenc0Args& k = a.k[side];
+  if (blk < gend) {
+    const long e = (long)(blk - base) * 256 + threadIdx.x;
+    const long total = (long)k.B * k.Np * a.d;
+    if (e >= total) return;
+    const int c = (int)(e % a.d);
+    const long row = e / a.d;
+    const int i = (int)(row % k.Np), b = (int)(row / k.Np);
+    a.xrow[side][e] = i < k.N ? a.desc[side][b * a.sb[side] + c * a.sc[side] + i * a.sn[side]] : 0.f;
+  } else {
+    kenc0_element(k, (long)(blk - gend) * 256 + threadIdx.x);
+  }
 }
 
 // ------------------------------------------------------------------ Sinkhorn
@@ -494,9 +512,12 @@ __global__ __launch_bounds__(256) void match_finalize(MatchArgs a) {
 // rows per LDS slab (R * N1p floats <= 64 KB); 0 = use the two-pass kernels
 int sinkhorn_slab_rows(int N1p) { return N1p <= 2048 ? 8 : N1p <= 4096 ? 4 : 0; }   // 16-row slabs measured slower (3.19 vs 2.36 ms at N = 1024)   // 8 rows even when 16 fit: 4 workgroups per CU (36 KB) hide the load latency better
 
-hipError_t launch_kenc0(const Kenc0Args& a, hipStream_t s) {
-  long total = (long)a.B * a.Np * a.C1;
-  hipLaunchKernelGGL(kenc0_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, a.scaling);
+
+hipError_t launch_sg_prologue(const SgPrologueArgs& a, hipStream_t s) {
+  auto blocks = [](long n) { return (unsigned)((n + 255) / 256); };
+  const unsigned g0 = blocks((long)a.k[0].B * a.k[0].Np * a.d), k0 = g0 + blocks((long)a.k[0].B * a.k[0].Np * a.k[0].C1);
+  const unsigned g1 = k0 + blocks((long)a.k[1].B * a.k[1].Np * a.d), k1 = g1 + blocks((long)a.k[1].B * a.k[1].Np * a.k[1].C1);
+  hipLaunchKernelGGL(sg_prologue_kernel, dim3(k1), dim3(256), 0, s, a, g0, k0, g1);
   return hipGetLastError();
 }
 

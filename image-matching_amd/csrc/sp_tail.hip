@@ -499,18 +499,21 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
   const int bl = (int)(slot / a.Kcap), i = (int)(slot % a.Kcap);
   const int b = a.b0 + bl;                     // image index into dense / sel_* arrays
   const int cnt = a.sel_count[b];
-  float* kp = a.kpts + slot * 2;
-  float* dsc = a.desc + slot * a.d;
+  const bool second = bl >= a.split;
+  const long oslot = second ? slot - (long)a.split * a.Kcap : slot;
+  float* kp = (second ? a.kpts2 : a.kpts) + oslot * 2;
+  float* dsc = (second ? a.desc2 : a.desc) + oslot * a.d;
+  float* scp = (second ? a.scores2 : a.scores) + oslot;
   if (i >= cnt) {
     if (lane < 2) kp[lane] = 0.f;
-    if (lane == 0) a.scores[slot] = 0.f;
+    if (lane == 0) *scp = 0.f;
     for (int c = lane; c < a.d; c += 64) dsc[c] = 0.f;
     return;
   }
   const int idx = a.sel_idx[(size_t)b * a.Ksel + i];
   const int py = idx / a.W8, px = idx - py * a.W8;
   const float kx = (float)px, ky = (float)py;                                   // flip (y,x)->(x,y) (:151)
-  if (lane == 0) { kp[0] = kx; kp[1] = ky; a.scores[slot] = a.sel_score[(size_t)b * a.Ksel + i]; }
+  if (lane == 0) { kp[0] = kx; kp[1] = ky; *scp = a.sel_score[(size_t)b * a.Ksel + i]; }
 
   const int w = a.Wc, h = a.Hc;
   // sample_descriptors (:43-46), s = 8
