@@ -371,3 +371,29 @@ def test_two_handles_on_two_host_threads_and_streams():
         th.join(timeout=300)
     assert not any(th.is_alive() for th in threads), "a worker thread did not finish"
     assert not errors, errors
+
+
+def test_batch_whose_images_yield_different_keypoint_counts():
+    """max_keypoints above what the images yield (every image keeps ALL its keypoints: counts differ from slot to slot and sit
+    below the buffers' capacity): the fused batch call must give, pair by pair, what Matching.forward gives for that pair alone
+    -- identical keypoints and match indices, -1 / 0 past each count -- and nothing leaks between batch slots."""
+    d, K, H, W = 128, 2500, 200, 264
+    m = _matching(d, K)
+    m._shared.get_engine([0, 1]).set_option("latency_forms", "off")       # same kernel forms for the batch and the single pairs
+    base = [util.pair(40 + i, H, W) for i in range(3)]
+    im0 = torch.cat([p[0] for p in base]).cuda()
+    im1 = torch.cat([p[1] for p in base]).cuda()
+    out = m.match_batch(im0, im1, want_desc=True)
+    torch.cuda.synchronize()
+    c0, c1 = out["counts0"].tolist(), out["counts1"].tolist()
+    assert all(0 < c < K for c in c0 + c1) and len(set(c0 + c1)) > 2, (c0, c1)
+    for b in range(3):
+        pred = m({"image0": im0[b:b + 1], "image1": im1[b:b + 1]})
+        n0, n1 = c0[b], c1[b]
+        assert len(pred["keypoints0"][0]) == n0 and len(pred["keypoints1"][0]) == n1
+        assert (out["matches0"][b, n0:] == -1).all() and (out["matches1"][b, n1:] == -1).all()
+        assert (out["matching_scores0"][b, n0:] == 0).all() and (out["keypoints0"][b, n0:] == 0).all() and (out["descriptors1"][b, n1:] == 0).all()
+        assert torch.equal(out["keypoints0"][b, :n0], pred["keypoints0"][0]) and torch.equal(out["keypoints1"][b, :n1], pred["keypoints1"][0])
+        assert torch.equal(out["descriptors0"][b, :n0].t(), pred["descriptors0"][0])
+        assert torch.equal(out["matches0"][b, :n0], pred["matches0"][0]) and torch.equal(out["matches1"][b, :n1], pred["matches1"][0])
+        torch.testing.assert_close(out["matching_scores0"][b, :n0], pred["matching_scores0"][0], rtol=0, atol=2e-5)
