@@ -321,6 +321,11 @@ def test_superpoint_random_shapes_and_configs_vs_oracle(seed):
     raw = _nchw(eng.fetch("desc_raw"))
     dense = raw / np.linalg.norm(raw, axis=1, keepdims=True)
     util.assert_close(dense, ref["desc"].numpy(), what + " dense descriptors")
+    # the dense export of the training / label-export forward (superpoint_train.py:31-57): the reference's channel-major layout
+    semi_d, desc_d = eng.superpoint_dense(x.cuda())
+    util.assert_close(semi_d.cpu().numpy(), ref["semi"].numpy(), what + " dense-export semi")
+    util.assert_close(desc_d.cpu().numpy(), ref["desc"].numpy(), what + " dense-export descriptors")
+    kpts, scores, desc, n = eng.superpoint(x.cuda())          # (the dense call overwrote the detection state: run it again)
     own_map = eng.fetch("score_map")
     assert own_map.shape == (B, H8, W8), what
     util.assert_close(own_map, ref["score_map"].numpy(), what + " score map", atol=1e-5)
