@@ -217,17 +217,28 @@ SG_CONFIGS = {      # descriptor_dim -> (keypoint_encoder, sinkhorn_iterations, 
     128: ([32, 64, 128], 30, 0.1),            # superpoint_glue_test.py:23,33-35 defaults (C3)
     256: ([32, 64, 128, 256], 100, 0.2),      # SuperGlue.default_config (C5)
 }
-_STATS = None
+# Second SuperGlue weight set, "t" (round 4, VERDICT r3 task 1): the SAME seeded values with gains chosen for trained-model-like
+# score statistics -- scores_in std = 5.0 on the calibration pair, bin_score = mean + 2 sigma (SURVEY 8c's recipe) -- and a tamer
+# GNN (residual branch x0.1, q/k projections x0.5: attention logits a quarter as large).  The selection criterion was a property of
+# the REFERENCE alone: on this set its own fp32 forward stays inside 1e-4 + 1e-4|x| of a float64 evaluation of itself on gnn17,
+# scores_in and Z (worst element of three probe seeds: 5e-6 / 9e-5 / 1.1e-4 at |x| > 100), so the north_star bar is one a correct
+# fp32 implementation can be held to element-wise, with no envelope clause.  The default set (SG_GAINS) is where it cannot: there
+# the reference itself is 2e-4..2.6e-3 from its float64 self.  final_proj gains per descriptor_dim were solved for std = 5.0.
+SGT_GAINS = {
+    64: {".mlp.3.weight": 0.1, "attn.proj.0.weight": 0.5, "attn.proj.1.weight": 0.5, "final_proj.weight": 0.881},
+    128: {".mlp.3.weight": 0.1, "attn.proj.0.weight": 0.5, "attn.proj.1.weight": 0.5, "final_proj.weight": 0.787},
+    256: {".mlp.3.weight": 0.1, "attn.proj.0.weight": 0.5, "attn.proj.1.weight": 0.5, "final_proj.weight": 0.745},
+}
+_STATS = {}
 
 
-def _stats():
-    global _STATS
-    if _STATS is None:
+def _stats(fname="synth_bn_stats.npz"):
+    if fname not in _STATS:
         import os
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "synth_bn_stats.npz")
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", fname)
         with np.load(path) as z:
-            _STATS = {k: z[k] for k in z.files}
-    return _STATS
+            _STATS[fname] = {k: z[k] for k in z.files}
+    return _STATS[fname]
 
 
 def calibrated_stats(prefix):
@@ -241,8 +252,18 @@ def make_superpoint_state_dict(descriptor_dim=128):
     return apply_bn_stats(sd, calibrated_stats(f"sp{descriptor_dim}"))
 
 
-def make_superglue_state_dict(descriptor_dim=128, keypoint_encoder=None, n_layers=18):
+def make_superglue_state_dict(descriptor_dim=128, keypoint_encoder=None, n_layers=18, variant="default"):
+    """variant "default": SG_GAINS (heavy-tailed scores, |S| up to several hundred); "t": SGT_GAINS (trained-model-like score
+    statistics, see above).  Both carry BatchNorm running statistics calibrated with the reference's own modules."""
     kenc = list(keypoint_encoder) if keypoint_encoder is not None else SG_CONFIGS[descriptor_dim][0]
+    if variant == "t":
+        sd = synth_state_dict(superglue_shapes(descriptor_dim, kenc, n_layers), SG_SEED, gains=SGT_GAINS[descriptor_dim])
+        st = _stats("synth_bn_stats_t.npz")
+        pre = f"sgt{descriptor_dim}/"
+        apply_bn_stats(sd, {k[len(pre):]: v for k, v in st.items() if k.startswith(pre) and not k.endswith("bin_score") and k[len(pre):] in sd})
+        sd["bin_score"] = np.float32(st[pre + "bin_score"]).reshape(())
+        return sd
+    assert variant == "default", variant
     sd = synth_state_dict(superglue_shapes(descriptor_dim, kenc, n_layers), SG_SEED, gains=SG_GAINS)
     apply_bn_stats(sd, {k: v for k, v in calibrated_stats(f"sg{descriptor_dim}").items() if k in sd})
     sd["bin_score"] = np.float32(_stats()[f"sg{descriptor_dim}/bin_score"]).reshape(())

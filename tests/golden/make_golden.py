@@ -67,14 +67,14 @@ def build_sp(d, max_kp, stats=None, **kw):
     return sp.eval(), sd
 
 
-def build_sg(d, kenc, iters, thr, stats=None, bin_score=None, layers=None):
+def build_sg(d, kenc, iters, thr, stats=None, bin_score=None, layers=None, gains=None):
     cfg = {"weights": None, "descriptor_dim": d, "keypoint_encoder": list(kenc),
            "sinkhorn_iterations": iters, "match_threshold": thr}
     if layers is not None:
         cfg["GNN_layers"] = layers
     sg = SuperGlue(cfg)
     nl = len(sg.config["GNN_layers"])
-    sd = synth.synth_state_dict(synth.superglue_shapes(d, kenc, nl), SG_SEED, gains=SG_GAINS)
+    sd = synth.synth_state_dict(synth.superglue_shapes(d, kenc, nl), SG_SEED, gains=SG_GAINS if gains is None else gains)
     if stats is not None:
         synth.apply_bn_stats(sd, stats)
     if bin_score is not None:
@@ -507,8 +507,109 @@ def sweep_envelopes():
         npz(name + ".npz", **g)
 
 
+def strict_set():
+    """Round 4 (VERDICT r3 task 1): the second synthetic SuperGlue weight set ("t", synth.SGT_GAINS: trained-model-like score
+    statistics) -- BatchNorm calibration with the reference's modules on the calibration pair (seed 0, 480x640), bin_score =
+    mean + 2 sigma of scores_in there -- and the reference's outputs on the SAME unselected seeds as the round-2 sweeps (C3 1000-1031,
+    C5 2000-2007; NO seed is rejected or searched), written as strict_c3.npz / strict_c5.npz: keypoints, scores, matches, matching
+    scores, both argmaxes and their margins, strided samples of gnn17 / scores_in / Z in fp32, the float64 evaluation of the same
+    module on the same samples (stored as float32 differences f64 - fp32), and per seed the reference's own fp32-vs-float64
+    envelope (max, rms, fraction outside 1e-4 + 1e-4|f64|) over the FULL tensors."""
+    def outside(a32, a64):
+        return float(((a32.double() - a64).abs() > 1e-4 + 1e-4 * a64.abs()).double().mean())
+    x0, x1 = pair_tensor(0, 480, 640)
+    stats_t = {}
+    sg_t = {}
+    for d in (128, 256):
+        kenc, iters, thr = synth.SG_CONFIGS[d]
+        sp, _ = build_sp(d, 1024, synth.calibrated_stats(f"sp{d}"))
+        data = sg_data(x0, x1, sp(x0), sp(x1))
+        sg, _ = build_sg(d, kenc, iters, thr, gains=synth.SGT_GAINS[d])
+        st = calibrate(sg, lambda: sg(data))
+        sc = sg_dense(sg, data)["scores_in"]
+        b = float(sc.mean() + 2.0 * sc.std())
+        for k, v in st.items():
+            stats_t[f"sgt{d}/{k}"] = v
+        stats_t[f"sgt{d}/bin_score"] = np.float32(b)
+        sg_t[d] = (st, b)
+        print(f"t set d={d}: calibration pair scores_in mean {sc.mean():.3f} std {sc.std():.3f} max |S| {sc.abs().max():.1f} -> bin_score {b:.4f}", flush=True)
+    np.savez_compressed(os.path.join(DATA, "synth_bn_stats_t.npz"), **stats_t)
+    print("  wrote synth_bn_stats_t.npz", os.path.getsize(os.path.join(DATA, "synth_bn_stats_t.npz")) // 1024, "KB")
+    synth._STATS.pop("synth_bn_stats_t.npz", None)
+
+    for name, H, W, d, K, seeds, st_s, st_g in (("strict_c3", 480, 640, 128, 1024, range(1000, 1032), 16, 32),
+                                                ("strict_c5", 960, 1280, 256, 2048, range(2000, 2008), 32, 64)):
+        kenc, iters, thr = synth.SG_CONFIGS[d]
+        cfg = {"superpoint": {"weights": None, "descriptor_dim": d, "nms_radius": 4, "keypoint_threshold": 0.005, "max_keypoints": K},
+               "superglue": {"weights": None, "descriptor_dim": d, "keypoint_encoder": kenc, "sinkhorn_iterations": iters,
+                             "match_threshold": thr}}
+        m = Matching(cfg).eval()
+        m.superpoint.load_state_dict(to_torch(synth.make_superpoint_state_dict(d)))
+        sd_t = synth.make_superglue_state_dict(d, variant="t")
+        m.superglue.load_state_dict(to_torch(sd_t))
+        rows = {k: [] for k in ("kpts0", "kpts1", "scores0", "scores1", "matches0", "matches1", "mscores0", "mscores1", "idx0", "idx1",
+                                "gap0", "gap1", "thr_gap0", "topk_gap", "n_matches", "gnn_sub", "scores_in_sub", "Z_sub",
+                                "scores_in_sub_d64", "Z_sub_d64", "env_gnn", "env_scores_in", "env_Z", "out_gnn", "out_scores_in", "out_Z",
+                                "stat_scores_in", "decision_gap")}
+        for seed in seeds:
+            xa, xb_ = pair_tensor(seed, H, W)
+            pred = m({"image0": xa, "image1": xb_})
+            assert len(pred["scores0"][0]) == K and len(pred["scores1"][0]) == K
+            data = {"image0": xa, "image1": xb_, **{k: torch.stack(list(v)) for k, v in pred.items() if isinstance(v, (list, tuple))}}
+            a32, a64 = sg_dense(m.superglue, data), sg_dense_f64(m.superglue, data)
+            Zf = a32["Z"]
+            Z = Zf[0, :-1, :-1]
+            t0, t1 = Z.topk(2, dim=1), Z.topk(2, dim=0)
+            i0, i1 = Z.max(1).indices, Z.max(0).indices
+            mutual = i1[i0] == torch.arange(K)
+            tg = torch.where(mutual, (t0.values[:, 0] - float(np.log(thr))).abs(), torch.full((K,), float("inf")))
+            gaps = []
+            for x_ in (xa, xb_):
+                nm = sp_dense(m.superpoint, x_)["nms"][0]
+                sel = nm > 0.005
+                cs = ref_sp_mod.remove_borders(torch.nonzero(sel), nm[sel], 4, nm.shape[0], nm.shape[1])[1].numpy()
+                gaps.append(topk_margin(cs, K)[0])
+            mgn = match_margins(Zf, pred, thr)
+            g32, g64 = torch.cat([a32["gnn0"], a32["gnn1"]]), torch.cat([a64["gnn0"], a64["gnn1"]])
+            for key, x32, x64 in (("gnn", g32, g64), ("scores_in", a32["scores_in"], a64["scores_in"]), ("Z", a32["Z"], a64["Z"])):
+                rows["env_" + key].append(envelope(x32, x64))
+                rows["out_" + key].append(outside(x32, x64))
+            S = a32["scores_in"]
+            nmatch = int((pred["matches0"] > -1).sum())
+            print(f"{name} seed {seed}: matches {nmatch}; scores_in mean {S.mean():.2f} std {S.std():.2f} max|S| {S.abs().max():.1f} max|Z| {Zf.abs().max():.1f}; "
+                  f"reference fp32 vs float64: gnn max {rows['env_gnn'][-1][0]:.1e} S max {rows['env_scores_in'][-1][0]:.1e} Z max {rows['env_Z'][-1][0]:.1e} "
+                  f"outside {rows['out_gnn'][-1]:.1e}/{rows['out_scores_in'][-1]:.1e}/{rows['out_Z'][-1]:.1e}; decision gap {mgn['decision_gap']:.1e} "
+                  f"thr gap {mgn['thr_gap']:.1e} top-k gaps {gaps[0]:.1e} {gaps[1]:.1e}", flush=True)
+            rows["kpts0"].append(pred["keypoints0"][0].numpy().astype(np.int16))
+            rows["kpts1"].append(pred["keypoints1"][0].numpy().astype(np.int16))
+            rows["scores0"].append(pred["scores0"][0].numpy())
+            rows["scores1"].append(pred["scores1"][0].numpy())
+            rows["matches0"].append(pred["matches0"][0].numpy().astype(np.int16))
+            rows["matches1"].append(pred["matches1"][0].numpy().astype(np.int16))
+            rows["mscores0"].append(pred["matching_scores0"][0].numpy())
+            rows["mscores1"].append(pred["matching_scores1"][0].numpy())
+            rows["idx0"].append(i0.numpy().astype(np.int16))
+            rows["idx1"].append(i1.numpy().astype(np.int16))
+            rows["gap0"].append((t0.values[:, 0] - t0.values[:, 1]).numpy())
+            rows["gap1"].append((t1.values[0] - t1.values[1]).numpy())
+            rows["thr_gap0"].append(tg.numpy())
+            rows["topk_gap"].append(np.array(gaps, np.float32))
+            rows["n_matches"].append(nmatch)
+            rows["decision_gap"].append(mgn["decision_gap"])
+            rows["gnn_sub"].append(torch.stack([a32["gnn0"][0, :, ::st_g], a32["gnn1"][0, :, ::st_g]]).numpy())
+            rows["scores_in_sub"].append(S[0, ::st_s, ::st_s].numpy())
+            rows["Z_sub"].append(Zf[0, ::st_s, ::st_s].numpy())
+            rows["scores_in_sub_d64"].append((a64["scores_in"][0, ::st_s, ::st_s] - S[0, ::st_s, ::st_s].double()).float().numpy())
+            rows["Z_sub_d64"].append((a64["Z"][0, ::st_s, ::st_s] - Zf[0, ::st_s, ::st_s].double()).float().numpy())
+            rows["stat_scores_in"].append(np.array([float(S.mean()), float(S.std()), float(S.abs().max()), float(Zf.abs().max())]))
+        npz(name + ".npz", H=H, W=W, d=d, K=K, seeds=np.array(list(seeds)), stride_s=st_s, stride_g=st_g,
+            bin_score=np.float32(sd_t["bin_score"]), **{k: np.stack(v) for k, v in rows.items()})
+
+
 if __name__ == "__main__":
     if "--sweep-envelopes" in sys.argv:
         sweep_envelopes()
+    elif "--strict-set" in sys.argv:
+        strict_set()
     else:
         main()

@@ -106,3 +106,30 @@ def test_official_superpoint_variant():
     assert np.array_equal(out["keypoints"][0].numpy(), g["keypoints0"])
     util.assert_close(out["scores"][0], g["scores0"], "scores", atol=1e-6, rtol=1e-6)
     util.assert_close(out["descriptors"][0], g["descriptors0"], "descriptors", atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name,idx", [("strict_c3.npz", 0), ("strict_c3.npz", 22)])
+def test_oracle_on_the_strict_weight_set(name, idx):
+    """Round 4: the "t" SuperGlue weight set (synth.SGT_GAINS: trained-model-like score statistics).  The oracle from images to
+    matches against the reference's outputs on unselected seeds (strict_c3.npz; index 22 = seed 1022, the one whose closest
+    matching score is 1.1e-6 from the threshold), and its dense gnn17 / scores_in / Z on the fixture's strided samples."""
+    g = util.golden(name)
+    H, W, d, K = (int(g[k]) for k in ("H", "W", "d", "K"))
+    seed = int(g["seeds"][idx])
+    x0, x1 = util.pair(seed, H, W)
+    cfg = {"superpoint": util.sp_config(d, K), "superglue": util.sg_config(d)}
+    sd_sg = util.sg_sd(d, variant="t")
+    assert abs(float(sd_sg["bin_score"]) - float(g["bin_score"])) == 0.0
+    pred = matching_ref.matching_forward({"image0": x0, "image1": x1}, util.sp_sd(d), sd_sg, cfg)
+    assert np.array_equal(pred["keypoints0"][0].numpy().astype(np.int16), g["kpts0"][idx])
+    assert np.array_equal(pred["keypoints1"][0].numpy().astype(np.int16), g["kpts1"][idx])
+    assert np.array_equal(pred["matches0"][0].numpy(), g["matches0"][idx].astype(np.int64))
+    assert np.array_equal(pred["matches1"][0].numpy(), g["matches1"][idx].astype(np.int64))
+    util.assert_close(pred["matching_scores0"][0], g["mscores0"][idx], "mscores0", atol=1e-5, rtol=1e-4)
+    data = {k: torch.stack(list(pred[k])) for k in ("keypoints0", "keypoints1", "scores0", "scores1", "descriptors0", "descriptors1")}
+    data["image_shape0"] = data["image_shape1"] = (1, 1, H, W)
+    dn = superglue_ref.superglue_forward(data, sd_sg, cfg["superglue"], return_dense=True)["dense"]
+    for key, (mine, ref) in util.strict_samples(g, idx, dn["gnn0"][0], dn["gnn1"][0], dn["scores_in"][0], dn["Z"][0]).items():
+        util.assert_close(mine, ref, f"{name} seed {seed}: {key}", atol=1e-5, rtol=1e-5)
+    # the statistics the set was built for (SURVEY 8c: scores_in std ~ 5, bin_score = mean + 2 sigma on the calibration pair)
+    assert 4.0 < float(g["stat_scores_in"][:, 1].mean()) < 6.5 and float(g["out_Z"].max()) == 0.0 and float(g["out_gnn"].max()) == 0.0

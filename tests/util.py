@@ -23,8 +23,8 @@ def sp_sd(d=128):
     return to_torch(synth.make_superpoint_state_dict(d))
 
 
-def sg_sd(d=128, kenc=None, n_layers=18):
-    return to_torch(synth.make_superglue_state_dict(d, kenc, n_layers))
+def sg_sd(d=128, kenc=None, n_layers=18, variant="default"):
+    return to_torch(synth.make_superglue_state_dict(d, kenc, n_layers, variant=variant))
 
 
 def pair(seed, H, W):
@@ -202,3 +202,79 @@ def fuzz_seeds(default):
         return default
     a, b = spec.split("-")
     return list(range(int(a), int(b) + 1))
+
+
+# ---------------------------------------------------------------------------------------------- strict fixtures (round 4)
+def strict_f64(g, key):
+    """The float64 evaluation of the reference module on a strict fixture's sample (stored as float32 differences)."""
+    return g[key].astype(np.float64) + g[key + "_d64"].astype(np.float64)
+
+
+def strict_samples(g, s, gnn0, gnn1, S, Z):
+    """The strided samples a strict fixture holds for seed index `s`, cut from full tensors laid out like the reference's:
+    gnn0/gnn1 (d, N), S (N0, N1), Z (N0+1, N1+1).  Returns {fixture key: (mine, reference)}."""
+    ss, sg = int(g["stride_s"]), int(g["stride_g"])
+    return {"gnn17": (np.stack([np.asarray(gnn0)[:, ::sg], np.asarray(gnn1)[:, ::sg]]), g["gnn_sub"][s]),
+            "scores_in": (np.asarray(S)[::ss, ::ss], g["scores_in_sub"][s]),
+            "Z": (np.asarray(Z)[::ss, ::ss], g["Z_sub"][s])}
+
+
+def tolerance_used(a, b):
+    """Worst |a-b| / (1e-4 + 1e-4|b|): the fraction of the north_star tolerance used (< 1 passes)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) / (ATOL + RTOL * np.abs(b))).max())
+
+
+def strict_compare_batch(g, out, eng, B, alpha, dense=True):
+    """One imx_match_pairs output of B pairs (pair b = fixture seed b mod n) against a strict fixture: identical keypoint sets,
+    every match identical (as coordinate pairs, and as indices where the keypoint order agrees), matching scores at 1e-4; with
+    `dense`, the fixture's samples of gnn17 / scores_in / Z against the library's taps (rows mapped to the reference's keypoint
+    order).  Returns a summary dict; raises on any violation.  Used by the test below and by bench.py's parity_in_run_strict."""
+    K, n = int(g["K"]), len(g["seeds"])
+    k0a, k1a = out["keypoints0"].cpu().numpy().astype(int), out["keypoints1"].cpu().numpy().astype(int)
+    m0a, ms0a = out["matches0"].cpu().numpy(), out["matching_scores0"].cpu().numpy()
+    m1a = out["matches1"].cpu().numpy()
+    assert (out["counts0"].cpu().numpy() == K).all() and (out["counts1"].cpu().numpy() == K).all()
+    summary = {"pairs": B, "reference_matches": 0, "index_mismatches": 0, "keypoint_set_mismatches": 0, "order_differs_images": 0,
+               "worst_tolerance_used": {"mscores": 0.0}}
+    Sall = eng.fetch("scores_in") if dense else None
+    U, V, X = (eng.fetch("u"), eng.fetch("v"), eng.fetch("x")) if dense else (None, None, None)
+    Kp = (K + 31) // 32 * 32
+    for b in range(B):
+        s = b % n
+        seed = int(g["seeds"][s])
+        r_k0, r_k1 = g["kpts0"][s].astype(int), g["kpts1"][s].astype(int)
+        pos0 = {tuple(p): i for i, p in enumerate(r_k0)}
+        pos1 = {tuple(p): i for i, p in enumerate(r_k1)}
+        same0 = set(map(tuple, k0a[b])) == set(pos0)
+        same1 = set(map(tuple, k1a[b])) == set(pos1)
+        summary["keypoint_set_mismatches"] += (not same0) + (not same1)
+        assert same0 and same1, f"pair {b} (seed {seed}): keypoint SET differs from the reference's"
+        p0 = np.array([pos0[tuple(p)] for p in k0a[b]])         # my row i is the reference's row p0[i]
+        p1 = np.array([pos1[tuple(p)] for p in k1a[b]])
+        summary["order_differs_images"] += int((p0 != np.arange(K)).any()) + int((p1 != np.arange(K)).any())
+        mine0 = np.full(K, -1, np.int64)
+        mine0[p0] = np.where(m0a[b] >= 0, p1[np.clip(m0a[b], 0, K - 1)], -1)
+        mine1 = np.full(K, -1, np.int64)
+        mine1[p1] = np.where(m1a[b] >= 0, p0[np.clip(m1a[b], 0, K - 1)], -1)
+        r0, r1 = g["matches0"][s].astype(np.int64), g["matches1"][s].astype(np.int64)
+        nd = int((mine0 != r0).sum()) + int((mine1 != r1).sum())
+        summary["reference_matches"] += int((r0 >= 0).sum())
+        summary["index_mismatches"] += nd
+        assert nd == 0, f"pair {b} (seed {seed}): {nd} match indices differ from the reference's (rows {np.nonzero(mine0 != r0)[0][:6]})"
+        sc = np.zeros(K, np.float32)
+        sc[p0] = ms0a[b]
+        assert_close(sc, g["mscores0"][s], f"pair {b} (seed {seed}): matching_scores0")
+        summary["worst_tolerance_used"]["mscores"] = max(summary["worst_tolerance_used"]["mscores"], tolerance_used(sc, g["mscores0"][s]))
+        if dense:
+            i0, i1 = np.argsort(p0), np.argsort(p1)              # reference row r is my row i0[r]
+            g0 = X[b * Kp:b * Kp + K][i0].T
+            g1 = X[B * Kp + b * Kp:B * Kp + b * Kp + K][i1].T
+            S = Sall[b, :K, :K][i0][:, i1]
+            Z = transport_Z(Sall[b], U[b], V[b], K, K, alpha)
+            Z = Z[np.append(i0, K)][:, np.append(i1, K)]
+            for key, (mine, fx) in strict_samples(g, s, g0, g1, S, Z).items():
+                assert_close(mine, fx, f"pair {b} (seed {seed}), images in: {key} vs the reference's sample")
+                w = summary["worst_tolerance_used"]
+                w[key] = max(w.get(key, 0.0), tolerance_used(mine, fx))
+    return summary
