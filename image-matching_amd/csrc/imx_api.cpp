@@ -18,6 +18,7 @@
 #include <map>
 #include <memory>
 #include <new>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -906,7 +907,7 @@ extern "C" {
 #ifndef IMX_BUILD_ID
 #define IMX_BUILD_ID "dev"
 #endif
-const char* imx_version(void) { return "imx 0.3 gfx950 hip-7.2 fp32 build " IMX_BUILD_ID; }
+const char* imx_version(void) { return "imx 0.4 gfx950 hip-7.2 fp32 build " IMX_BUILD_ID; }
 
 int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
   return guarded(nullptr, "imx_create", [&]() -> int {
@@ -917,6 +918,8 @@ int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
     // dims) are checked when ITS weights are finalized
     if (cfg->descriptor_dim <= 0 || cfg->descriptor_dim % 4 || cfg->descriptor_dim > 512) return fail(nullptr, "imx_create: descriptor_dim must be a multiple of 4 in [4,512] (got %d)", cfg->descriptor_dim);
     if (cfg->nms_radius < 0) return fail(nullptr, "imx_create: nms_radius must be >= 0 (got %d)", cfg->nms_radius);
+    // the top-k stage rounds max_keypoints up to a power of two in 32-bit arithmetic (sp_tail.hip: launch_keypoints)
+    if (cfg->max_keypoints > (1 << 30)) return fail(nullptr, "imx_create: max_keypoints must be <= 2^30 (got %d); use -1 for 'all'", cfg->max_keypoints);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "imx_create: no HIP device available (this library has no CPU path)");
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, "imx_create: device %d out of range (%d devices)", device_id, ndev);
@@ -931,6 +934,14 @@ int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
       if (const char* e = getenv(env.c_str()))
         if (apply_option(h.get(), key, e)) return fail(nullptr, "imx_create: bad value '%s' in the environment variable %s", e, env.c_str());
     }
+    // switches of earlier rounds that no longer exist: say so once instead of silently measuring the default path
+    static std::atomic<bool> warned{false};
+    for (const char* old : {"IMX_GEMM", "IMX_GEMM_SMALL", "IMX_ATTN", "IMX_ATTN_SPLIT", "IMX_NMS", "IMX_CONV_BLOCKED", "IMX_WINO_EXP", "IMX_WINO_WGS",
+                            "IMX_X3_WGS", "IMX_SINKHORN_WAVES"})
+      if (getenv(old) && !warned.exchange(true))
+        fprintf(stderr, "libimx: the environment variable %s (and the other per-kernel switches of rounds 1-2) was removed; it is ignored. "
+                        "Kernel forms are handle options now: imx_set_option(h, \"mfma\" | \"latency_forms\" | \"conv\", ...), seeded from IMX_MFMA / "
+                        "IMX_LATENCY_FORMS / IMX_CONV at imx_create (an unknown VALUE of those three makes imx_create fail).\n", old);
     build_expected(h.get());
     *out = h.release();
     return 0;
@@ -1110,8 +1121,11 @@ const Rccl& rccl() {
     auto sym = [&](const char* name) -> void* {
       if (void* p = dlsym(RTLD_DEFAULT, name)) return p;
       if (!lib) {
+        // the host names the RCCL build that created its communicators with IMX_RCCL_LIBRARY (a path) when that library is not
+        // visible to dlsym(RTLD_DEFAULT) -- e.g. loaded RTLD_LOCAL under another soname; otherwise the usual names are tried
+        if (const char* path = getenv("IMX_RCCL_LIBRARY")) lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
         for (const char* so : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"})
-          if ((lib = dlopen(so, RTLD_NOW | RTLD_GLOBAL))) break;
+          if (!lib && (lib = dlopen(so, RTLD_NOW | RTLD_GLOBAL))) break;
       }
       return lib ? dlsym(lib, name) : nullptr;
     };

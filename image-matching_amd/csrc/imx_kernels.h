@@ -27,13 +27,16 @@ extern thread_local const char* last_form;
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: `done_mask` (one static per kernel
 // instantiation at the call site) remembers the devices it has been raised on, so a process holding handles on two devices
 // raises it on both.
+// Two host threads driving handles on different devices may arrive here together: the mask is read and updated atomically, and
+// the bit is set only AFTER the attribute call, so a racing thread at worst repeats the (idempotent) call; devices past 63 have no
+// bit and set the attribute on every launch.
 inline void raise_lds_limit(const void* kern, int bytes, unsigned long long& done_mask) {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (done_mask & bit) return;
+  const unsigned long long bit = dev < 64 ? 1ull << dev : 0ull;
+  if (bit && (__atomic_load_n(&done_mask, __ATOMIC_ACQUIRE) & bit)) return;
   (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  done_mask |= bit;
+  if (bit) __atomic_fetch_or(&done_mask, bit, __ATOMIC_RELEASE);
 }
 
 // ---------------------------------------------------------------- conv3x3 (MFMA fp32, implicit GEMM)

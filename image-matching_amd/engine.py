@@ -223,6 +223,17 @@ class Engine:
         if not isinstance(pair_ids, torch.Tensor):
             pair_ids = torch.as_tensor(list(pair_ids), dtype=torch.int32)
         pair_ids = pair_ids.to(self.device, torch.int32).contiguous()
+        # the kernel reads pair_ids[row] for every row < B and reinterprets raw pointers: refuse anything that is not what
+        # match_pairs returns instead of reading out of bounds or through the wrong dtype
+        if pair_ids.numel() != B:
+            raise ImxError(f"pack_records: {pair_ids.numel()} pair ids for a batch of {B} pairs")
+        want = {"keypoints0": (torch.float32, (B, K, 2)), "keypoints1": (torch.float32, (B, K, 2)), "counts0": (torch.int32, (B,)), "counts1": (torch.int32, (B,)),
+                "matches0": (torch.int64, (B, K)), "matches1": (torch.int64, (B, K)), "matching_scores0": (torch.float32, (B, K)), "matching_scores1": (torch.float32, (B, K))}
+        for key, (dt, shp) in want.items():
+            t = out[key]
+            if not (isinstance(t, torch.Tensor) and t.dtype == dt and tuple(t.shape) == shp and t.device == self.device and t.is_contiguous()):
+                raise ImxError(f"pack_records: out[{key!r}] must be a contiguous {dt} tensor of shape {shp} on {self.device} "
+                               f"(got {getattr(t, 'dtype', type(t))}, {tuple(getattr(t, 'shape', ()))}, {getattr(t, 'device', None)})")
         rec = torch.empty(rows, 3 + 8 * K, dtype=torch.int32, device=self.device)
         self._check(self.lib.imx_pack_records(
             self.handle, _ptr(pair_ids), B, K, _ptr(out["keypoints0"]), _ptr(out["keypoints1"]), _ptr(out["counts0"]), _ptr(out["counts1"]),

@@ -227,7 +227,7 @@ const char* imx_timing_form(imx_handle_t h, int index);
 int imx_set_option(imx_handle_t h, const char* key, const char* value);
 const char* imx_get_option(imx_handle_t h, const char* key);
 
-/* Library build string, e.g. "imx 0.3 gfx950 hip-7.2 fp32 build 3f2a91c07d1e" (the id is a digest of the library
+/* Library build string, e.g. "imx 0.4 gfx950 hip-7.2 fp32 build 3f2a91c07d1e" (the id is a digest of the library
  * sources: measurements taken on one build are only quoted for that build). */
 const char* imx_version(void);
 

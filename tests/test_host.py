@@ -260,3 +260,33 @@ def test_traditional_plumbing_flags_and_skip_line(capsys):
     if registration.cv2 is None:
         assert traditional.main([]) == []
         assert "skipped" in capsys.readouterr().out
+
+
+def test_bench_plans_the_c4_job_without_a_gpu():
+    """VERDICT r3 task 5: bench.py's own argument / environment handling for an 8-rank launch, far enough to see who gets which
+    pairs: `--plan-only` under WORLD_SIZE=8, RANK=r prints this rank's pair ids and the padded record rows.  The eight shards must
+    partition the 512 pairs of BASELINE configs[3] (pair i -> rank i mod 8, 64 per rank), and a --gpus / WORLD_SIZE disagreement
+    must be refused."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    seen = []
+    for r in range(8):
+        env = dict(os.environ, WORLD_SIZE="8", RANK=str(r), LOCAL_RANK=str(r))
+        out = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "20", "--warmup", "2", "--plan-only"], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        pl = json.loads(out.stdout.strip().splitlines()[-1])
+        assert pl["world"] == 8 and pl["rank"] == r and pl["global_pairs"] == 512 and pl["rows_per_rank"] == 64
+        assert pl["pair_ids"] == list(range(r, 512, 8))
+        seen += pl["pair_ids"]
+    assert sorted(seen) == list(range(512))
+    bad = subprocess.run([sys.executable, bench, "--gpus", "4", "--plan-only"], env=dict(os.environ, WORLD_SIZE="8", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=8" in (bad.stderr + bad.stdout)
+
+
+def test_package_and_library_versions_agree():
+    import image_matching_amd
+    from image_matching_amd import _lib
+    major_minor = ".".join(image_matching_amd.__version__.split(".")[:2])
+    assert f"imx {major_minor} ".encode() in _lib.load_library().imx_version()
