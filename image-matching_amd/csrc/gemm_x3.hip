@@ -22,6 +22,7 @@
 //   B operand for one step and plane is one coalesced 1 KB load straight into registers (no LDS, no barrier), requested a chunk
 //   ahead; every workgroup of a column reads the same fragments (L2 / L1 resident: 3 x K x Npad x 2 bytes per layer).
 #include "imx_kernels.h"
+#include "split3.h"
 #include <cstdlib>
 
 namespace imx {
@@ -78,12 +79,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x3(GemmArgs p, const __bf16* __re
     for (int it = 0; it < 4; ++it) {
       bf16x4 h, m, l;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float x = areg[it][t];
-        h[t] = (__bf16)x;
-        const float r1 = x - (float)h[t];
-        m[t] = (__bf16)r1;
-        l[t] = (__bf16)(r1 - (float)m[t]);
+      for (int t = 0; t < 4; t += 2) {
+        split_bf16x2 h2, m2, l2;
+        split3_pair(areg[it][t], areg[it][t + 1], h2, m2, l2);
+        h[t] = h2[0]; h[t + 1] = h2[1]; m[t] = m2[0]; m[t + 1] = m2[1]; l[t] = l2[0]; l[t + 1] = l2[1];
       }
       const int o = ((tid >> 3) + 32 * it) * RS + (tid & 7) * 4;
       *reinterpret_cast<bf16x4*>(&Ad[0][o]) = h;

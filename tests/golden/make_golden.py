@@ -421,14 +421,22 @@ def main():
     # ---------------------------------------------------------------- unselected seed sweeps (no rejection)
     for name, H, W, d, K, seeds in (("sweep_c3", 480, 640, 128, 1024, range(1000, 1032)),
                                     ("sweep_c5", 960, 1280, 256, 2048, range(2000, 2008))):
-        kenc, iters, thr = sg_cfgs[d]
+        rows = sweep_rows(name, H, W, d, K, seeds, sg_cfgs[d], sp_stats[d], sg_stats[d], sg_bin[d])
+        npz(name + ".npz", H=H, W=W, d=d, K=K, seeds=np.array(list(seeds)), **{k: np.stack(v) for k, v in rows.items()})
+
+
+def sweep_rows(name, H, W, d, K, seeds, sg_cfg, sp_stat, sg_stat, sg_b):
+    """The reference on consecutive seeds with NO rejection: per seed its keypoints, scores, matches, both argmaxes of Z and their
+    margins (top-1 minus top-2 per row / column, distance to the match threshold, SuperPoint's top-k boundary gap)."""
+    if True:
+        kenc, iters, thr = sg_cfg
         cfg = {"superpoint": {"weights": None, "descriptor_dim": d, "nms_radius": 4,
                               "keypoint_threshold": 0.005, "max_keypoints": K},
                "superglue": {"weights": None, "descriptor_dim": d, "keypoint_encoder": kenc,
                              "sinkhorn_iterations": iters, "match_threshold": thr}}
         m = Matching(cfg).eval()
-        _, sd_sp = build_sp(d, K, sp_stats[d])
-        _, sd_sg = build_sg(d, kenc, iters, thr, sg_stats[d], sg_bin[d])
+        _, sd_sp = build_sp(d, K, sp_stat)
+        _, sd_sg = build_sg(d, kenc, iters, thr, sg_stat, sg_b)
         m.superpoint.load_state_dict(to_torch(sd_sp))
         m.superglue.load_state_dict(to_torch(sd_sg))
         rows = {k: [] for k in ("kpts0", "kpts1", "scores0", "scores1", "matches0", "matches1", "idx0", "idx1", "gap0", "gap1", "thr_gap0",
@@ -468,17 +476,17 @@ def main():
             rows["thr_gap0"].append(tg.numpy())
             rows["topk_gap"].append(np.array(gaps, np.float32))
             rows["n_matches"].append(nmatch)
-        npz(name + ".npz", H=H, W=W, d=d, K=K, seeds=np.array(list(seeds)), **{k: np.stack(v) for k, v in rows.items()})
+        return rows
 
 
-def sweep_envelopes():
+def sweep_envelopes(only=("sweep_c3", "sweep_c5")):
     """Round 3 (VERDICT r2 #1c, #2): per unselected seed, the reference's OWN fp32 rounding envelope -- its fp32 result against the
     float64 evaluation of the same module on the same inputs -- for gnn17, scores_in and Z: (max, rms) and the fraction of elements
     outside 1e-4 + 1e-4*|f64|.  Added to the committed sweep fixtures as `env_*` / `out_*` arrays (the other arrays are re-checked
     against the reference, not rewritten).  The GPU sweep tests bound their acceptance threshold with these."""
     def outside(a32, a64):
         return float(((a32.double() - a64).abs() > 1e-4 + 1e-4 * a64.abs()).double().mean())
-    for name in ("sweep_c3", "sweep_c5"):
+    for name in only:
         path = os.path.join(OUT, name + ".npz")
         with np.load(path) as z:
             g = {k: z[k] for k in z.files}
@@ -505,6 +513,29 @@ def sweep_envelopes():
                   f"outside-1e-4 {env['out_Z'][-1]:.3f} | scores_in max {env['env_scores_in'][-1][0]:.2e} outside {env['out_scores_in'][-1]:.3f}", flush=True)
         g.update({k: np.array(v, np.float64) for k, v in env.items()})
         npz(name + ".npz", **g)
+
+
+def extend_sweep_c5(new_seeds=range(2008, 2016)):
+    """Round 4 (VERDICT r3 task 8): the C5 sweep goes from 8 to 16 unselected seeds.  The committed rows are kept byte for byte; the new
+    seeds are appended with the same code path (sweep_rows) and their envelopes by sweep_envelopes() afterwards."""
+    path = os.path.join(OUT, "sweep_c5.npz")
+    with np.load(path) as z:
+        g = {k: z[k] for k in z.files}
+    have = [int(x) for x in g["seeds"]]
+    todo = [sd_ for sd_ in new_seeds if sd_ not in have]
+    if not todo:
+        print("sweep_c5 already holds", have)
+        return
+    d, K = 256, 2048
+    sg_stat = {k: v for k, v in synth.calibrated_stats("sg256").items()}
+    rows = sweep_rows("sweep_c5", 960, 1280, d, K, todo, synth.SG_CONFIGS[d], synth.calibrated_stats("sp256"), sg_stat,
+                      float(synth._stats()["sg256/bin_score"]))
+    for k, v in rows.items():
+        g[k] = np.concatenate([g[k], np.stack(v).astype(g[k].dtype)])
+    g["seeds"] = np.array(have + todo)
+    for k in [k for k in g if k.startswith("env_") or k.startswith("out_")]:
+        del g[k]                      # recomputed for all seeds by sweep_envelopes() (deterministic: the old rows come back identical)
+    npz("sweep_c5.npz", **g)
 
 
 def strict_set():
@@ -538,7 +569,7 @@ def strict_set():
     synth._STATS.pop("synth_bn_stats_t.npz", None)
 
     for name, H, W, d, K, seeds, st_s, st_g in (("strict_c3", 480, 640, 128, 1024, range(1000, 1032), 16, 32),
-                                                ("strict_c5", 960, 1280, 256, 2048, range(2000, 2008), 32, 64)):
+                                                ("strict_c5", 960, 1280, 256, 2048, range(2000, 2016), 32, 64)):
         kenc, iters, thr = synth.SG_CONFIGS[d]
         cfg = {"superpoint": {"weights": None, "descriptor_dim": d, "nms_radius": 4, "keypoint_threshold": 0.005, "max_keypoints": K},
                "superglue": {"weights": None, "descriptor_dim": d, "keypoint_encoder": kenc, "sinkhorn_iterations": iters,
@@ -611,5 +642,14 @@ if __name__ == "__main__":
         sweep_envelopes()
     elif "--strict-set" in sys.argv:
         strict_set()
+    elif "--extend-c5" in sys.argv:
+        old = dict(np.load(os.path.join(OUT, "sweep_c5.npz")))
+        extend_sweep_c5()
+        sweep_envelopes(only=("sweep_c5",))
+        new = dict(np.load(os.path.join(OUT, "sweep_c5.npz")))
+        n = len(old["seeds"])
+        for k, v in old.items():      # the committed rows are unchanged
+            if v.ndim and v.shape[0] == n:
+                assert np.array_equal(new[k][:n], v, equal_nan=True), k
     else:
         main()

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <vector>
 using namespace imx;
+namespace imx { thread_local const char* last_form = nullptr; }   // defined by imx_api.cpp in the library
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 64, N = 1024, d = 128, heads = 4, hd = d / heads, ld = 3 * d;
   const size_t rows = (size_t)2 * B * N;
@@ -23,11 +24,12 @@ int main(int argc, char** argv) {
   AttnArgs a{dq, dout, B, N, N, d, heads, nullptr, nullptr, N - 5, N - 37, 1};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int form = 0; form < 2; ++form) {
-    if (form) setenv("IMX_MFMA", "f32", 1);
+    a.mfma_f32 = form;          // the form switch is a field of the arguments since round 3 (handle options)
+    a.latency_forms = (!form && getenv("DEPHASE")) ? atoi(getenv("DEPHASE")) : 0;      // experiment hook (IMX_ATTN_DEPHASE_EXP builds)
     auto run = [&]() { return form ? launch_attention(a, 0) : launch_attention_x3(a, 0); };
-    for (int i = 0; i < 2; ++i) run();
+    for (int i = 0; i < 20; ++i) run();      // clocks settle
     hipEventRecord(e0, 0);
-    for (int i = 0; i < 10; ++i) run();
+    for (int i = 0; i < 40; ++i) run();
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     // float64 reference for pair 1, side 0 (cross: keys from side 1), head 2, queries 100..107
@@ -51,7 +53,12 @@ int main(int argc, char** argv) {
       }
       for (int t = 0; t < hd; ++t) { const double e = out[(size_t)qi * d + head * hd + t] - o[t] / l; se += e * e; if (fabs(e) > mx) mx = fabs(e); }
     }
-    const double us = ms * 1000 / 10, fl = 4.0 * 2 * B * heads * (double)N * N * hd;
+    if (!form && getenv("ATTN_DUMP")) {          // raw output of the first rows, to diff two builds of the kernel
+      std::vector<float> full((size_t)4096 * d);
+      hipMemcpy(full.data(), dout, full.size() * 4, hipMemcpyDeviceToHost);
+      FILE* f = fopen(getenv("ATTN_DUMP"), "wb"); fwrite(full.data(), 4, full.size(), f); fclose(f);
+    }
+    const double us = ms * 1000 / 40, fl = 4.0 * 2 * B * heads * (double)N * N * hd;
     printf("%-22s %8.1f us   %6.1f TFLOP/s fp32-equivalent   rms err vs float64 %.2e  max %.2e\n", form ? "attention (fp32 MFMA)" : "attention_x3", us,
            fl / us * 1e-6, sqrt(se / (8.0 * hd)), mx);
   }

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <vector>
 using namespace imx;
+namespace imx { thread_local const char* last_form = nullptr; }   // defined by imx_api.cpp in the library
 static uint16_t bf16_rne(float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 static float bf16_f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; }
 int main() {
