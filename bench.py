@@ -19,7 +19,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) including
                   reported next to it under `algorithmic`.  `executed_pair_frac` is the whole-pair view.
                   Which matrix pipe a kernel is priced against comes from the LIBRARY (imx_timing_form: the kernel form
                   that actually ran), not from a copy of its dispatch rule.  `traffic` comes from rocprofv3 PMC passes
-                  (profiles/r03_pmc_traffic.json, taken at this run's 64 pairs per step) and is dropped when that file was
+                  (profiles/r*_pmc_traffic.json, taken at this run's 64 pairs per step) and is dropped when that file was
                   measured on a different library build than the one being timed;
   "parity_in_run": the first 32 pairs of the timed batch are the UNSELECTED sweep seeds 1000..1031 whose reference outputs
                   are committed in tests/golden/sweep_c3.npz; after the timed region the keypoints and match indices of the
@@ -463,8 +463,16 @@ def roofline_block(rows, wl, B, steps, dt, lib_build, workload):
         achieved = algorithmic
     traffic, traffic_note, pmc = None, None, None   # HBM bytes per launch from rocprofv3 PMC passes (tools/pmc_traffic.py -> profiles/)
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as fh:
-            pmc = json.load(fh)
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True)      # newest round first
+        pmc = None
+        for path in cands:
+            with open(path) as fh:
+                pmc = json.load(fh)
+            if pmc.get("build") == lib_build:
+                break
+        if pmc is None:
+            raise OSError("no traffic file")
         if pmc.get("build") != lib_build:
             traffic_note = f"dropped: PMC passes were taken on build {pmc.get('build')!r}, this run is {lib_build!r}"
             pmc = None

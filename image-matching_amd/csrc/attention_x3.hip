@@ -116,16 +116,6 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnArgs p, float 
     }
   }
 
-#ifdef IMX_ATTN_DEPHASE_EXP
-  // EXPERIMENT (round 4): are the two workgroups of a CU phase-locked (both in their MFMA chains, then both in their VALU work)?
-  // The first generation's workgroups in the odd wave slot start `dephase` x 64 cycles late; all workgroups take the same time, so
-  // later generations inherit the offset.
-  if (p.latency_forms > 0) {
-    const int linear = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const unsigned hwid = __builtin_amdgcn_s_getreg(63492);       // HW_REG_HW_ID: wave slot in bits 3:0
-    if ((hwid & 1) && linear < 512) for (int i = 0; i < p.latency_forms; ++i) __builtin_amdgcn_s_sleep(1);
-  }
-#endif
   f32x16 O[OB], T[OB];      // running output, and the current 64-key group's partial product (two-level accumulation)
 #pragma unroll
   for (int o = 0; o < OB; ++o)
@@ -272,28 +262,22 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnArgs p, float 
 
   // tile kt+2 is requested while tile kt is multiplied and tile kt+1 (requested one iteration earlier) is split and stored:
   // two static register sets, two static LDS buffers, loop unrolled by two
-#ifdef IMX_ATTN_SCHED_EXP
-  const int expm = p.latency_forms >= 200 ? p.latency_forms - 200 : 0;     // ubench: drop one ingredient (results are garbage)
-#else
-  constexpr int expm = 0;
-#endif
   gload(kreg0, vreg0, 0);
   gload(kreg1, vreg1, nt > 1 ? 1 : 0);
   lstore(Kt0, Vt0, kreg0, vreg0);
-  if (expm & 2) lstore(Kt1, Vt1, kreg1, vreg1);
   __syncthreads();
   for (int kt = 0; kt < nt; kt += 2) {
-    if (!(expm & 1)) gload(kreg0, vreg0, kt + 2 < nt ? kt + 2 : kt);
+    gload(kreg0, vreg0, kt + 2 < nt ? kt + 2 : kt);
     if (kt * 32 + 32 <= nk) tile(kt, Kt0, Vt0, BoolC<true>{}, BoolC<true>{});          // block-uniform
     else tile(kt, Kt0, Vt0, BoolC<true>{}, BoolC<false>{});
-    if (!(expm & 2)) lstore(Kt1, Vt1, kreg1, vreg1);                // tile kt+1
-    if (!(expm & 4)) __syncthreads();
+    lstore(Kt1, Vt1, kreg1, vreg1);                // tile kt+1
+    __syncthreads();
     if (kt + 1 < nt) {                             // block-uniform
-      if (!(expm & 1)) gload(kreg1, vreg1, kt + 3 < nt ? kt + 3 : kt);
+      gload(kreg1, vreg1, kt + 3 < nt ? kt + 3 : kt);
       if (kt * 32 + 64 <= nk) tile(kt + 1, Kt1, Vt1, BoolC<EVERY>{}, BoolC<true>{});
       else tile(kt + 1, Kt1, Vt1, BoolC<EVERY>{}, BoolC<false>{});
-      if (!(expm & 2)) lstore(Kt0, Vt0, kreg0, vreg0);              // tile kt+2
-      if (!(expm & 4)) __syncthreads();
+      lstore(Kt0, Vt0, kreg0, vreg0);              // tile kt+2
+      __syncthreads();
     }
   }
 
@@ -312,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnArgs p, float 
   }
 }
 // The pipelined form (used for HD = 64: the straight form above needs 2 x the V / P / O registers there and spills).
-template <int HD, bool SCHED = false, int VPM = 7>
+template <int HD>
 __global__ __launch_bounds__(256, 2) void attention_x3p_kernel(AttnArgs p, float scale) {
   constexpr int TK = 32;
   constexpr int KSB = HD + 8;         // K plane row stride (bf16): 80 / 144 bytes = 5 / 9 sixteen-byte slots (odd)
@@ -437,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void attention_x3p_kernel(AttnArgs p, float
   //          element), softmax + split of tile k's scores, split + store of tile k+2 (requested one iteration earlier)
   // one barrier per tile, no branch in the body except the key mask of the last tile.
   auto body = [&](int k, const __bf16 (&Kn)[3][TK * KSB], const __bf16 (&Vp)[3][TK * HD], __bf16 (&Kd)[3][TK * KSB],
-                  __bf16 (&Vd)[3][TK * HD], auto masked) __attribute__((always_inline)) {
+                  __bf16 (&Vd)[3][TK * HD]) __attribute__((always_inline)) {
     // ---- operands of this iteration's MFMAs: K of tile k+1 (A), Q (B, registers); V^T of tile k-1 (A), P^T of tile k-1 (B)
     bf16x8 kf[NS][3], vf[OB][2][3];
 #pragma unroll
@@ -477,7 +461,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3p_kernel(AttnArgs p, float
 #pragma unroll
       for (int r = 0; r < 16; ++r) O[o][r] = fmaf(O[o][r], a2, Tq[o][r]);
     // ---- online softmax over tile k's 32 keys (16 here, 16 in lane^32), log2 domain
-    if constexpr (decltype(masked)::value) {      // the last tile when the key count is not a multiple of 32 (the draining iteration's scores are not used: `live`)
+    // This branch also keeps the body in TWO scheduling regions -- the MFMAs clustered in the first, the softmax / split VALU work
+    // in the second.  Round 4 measured the alternative (branch outside the body, one region: hipcc then interleaves one MFMA with
+    // 7-8 VALU instructions, also when pinned with sched_group_barrier): 3-9 % SLOWER at HD = 32 and HD = 64.
+    if (k * 32 + 32 > nk) {               // block-uniform: the last tile (or the draining iteration, whose scores are not used)
 #pragma unroll
       for (int r = 0; r < 16; ++r) S[r] = (k * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi < nk) ? S[r] : -INFINITY;
     }
@@ -520,24 +507,6 @@ __global__ __launch_bounds__(256, 2) void attention_x3p_kernel(AttnArgs p, float
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) pf[t][pl] = pn[t][pl];
-    // ---- issue order (round 4).  tools/ubench/pingpong.hip: a wave that streams its MFMAs back to back keeps the SIMD's issue port --
-    // another wave's VALU work gets ~1 slot per MFMA, so two co-resident waves running [12 MFMAs][VALU][12 MFMAs][VALU] take the SUM
-    // of their MFMA and VALU times (1199 cycles per tile against 1253 for one wave alone); VALU instructions of the SAME wave placed
-    // between its MFMAs issue beneath them (tools/ubench/valu_rate.hip: 8 simple VALU per 32-cycle MFMA at full MFMA rate with two
-    // waves).  Everything in this body is independent of the body's own MFMAs, so the 12 * (NS / 2 + OB) MFMAs are spread evenly
-    // over the VALU work: the operand reads and the part of the VALU work that does not wait for them first, then one MFMA per group.
-    if constexpr (SCHED) {
-      constexpr int NM = 6 * NS + 12 * OB;
-      __builtin_amdgcn_sched_group_barrier(0x100, 6 * NS + 12 * OB, 0);     // the LDS reads of the operands
-      __builtin_amdgcn_sched_group_barrier(0x002, 16 * OB + 10, 0);         // the fold of tile k-2, the row maximum
-#pragma unroll
-      for (int g = 0; g < NM; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);                // VPM VALU instructions beneath it
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                  // at most one LDS store (tile k+2's planes)
-        if (g == 2) __builtin_amdgcn_sched_group_barrier(0x020, 2 * ITER, 0);   // the global loads of tile k+3
-      }
-    }
     __syncthreads();
   };
 
@@ -560,17 +529,11 @@ __global__ __launch_bounds__(256, 2) void attention_x3p_kernel(AttnArgs p, float
     }
   }
   // iteration k reads K buffer (k+1) % 4 and V buffer (k-1) % 4 (zeros x anything at k = 0: P is zero) and writes buffer (k+2) % 4
-  // the branch on the key mask sits OUTSIDE the body: one scheduling region per body, so that the issue order can be pinned
-  auto step = [&](int k, const __bf16 (&Kn)[3][TK * KSB], const __bf16 (&Vp)[3][TK * HD], __bf16 (&Kd)[3][TK * KSB],
-                  __bf16 (&Vd)[3][TK * HD]) __attribute__((always_inline)) {
-    if (k < nt && k * 32 + 32 > nk) body(k, Kn, Vp, Kd, Vd, BoolC<true>{});       // block-uniform
-    else body(k, Kn, Vp, Kd, Vd, BoolC<false>{});
-  };
   for (int k = 0; k <= nt; k += 4) {
-    step(k, Kt1, Vt3, Kt2, Vt2);
-    if (k + 1 <= nt) step(k + 1, Kt2, Vt0, Kt3, Vt3);       // block-uniform
-    if (k + 2 <= nt) step(k + 2, Kt3, Vt1, Kt0, Vt0);
-    if (k + 3 <= nt) step(k + 3, Kt0, Vt2, Kt1, Vt1);
+    body(k, Kt1, Vt3, Kt2, Vt2);
+    if (k + 1 <= nt) body(k + 1, Kt2, Vt0, Kt3, Vt3);       // block-uniform
+    if (k + 2 <= nt) body(k + 2, Kt3, Vt1, Kt0, Vt0);
+    if (k + 3 <= nt) body(k + 3, Kt0, Vt2, Kt1, Vt1);
   }
 
   if (wave_active) {
@@ -600,18 +563,6 @@ hipError_t launch_attention_x3(const AttnArgs& a, hipStream_t s) {
   dim3 grid((unsigned)((nmax + 127) / 128), (unsigned)a.heads, (unsigned)(2 * a.B));
   const float scale = (float)(1.4426950408889634 / sqrt((double)hd));   // log2(e)/sqrt(HD)
   last_form = "attention_x3:bf16x3";
-#ifdef IMX_ATTN_SCHED_EXP
-  if (hd == 32 && a.latency_forms >= 100) {        // ubench hook: the pipelined form at HD = 32, plain / with the issue order pinned
-    const int v = a.latency_forms - 100;
-    if (v == 0) hipLaunchKernelGGL((attention_x3p_kernel<32, false>), grid, dim3(256), 0, s, a, scale);
-    else if (v == 6) hipLaunchKernelGGL((attention_x3p_kernel<32, true, 6>), grid, dim3(256), 0, s, a, scale);
-    else if (v == 7) hipLaunchKernelGGL((attention_x3p_kernel<32, true, 7>), grid, dim3(256), 0, s, a, scale);
-    else if (v == 8) hipLaunchKernelGGL((attention_x3p_kernel<32, true, 8>), grid, dim3(256), 0, s, a, scale);
-    else if (v == 9) hipLaunchKernelGGL((attention_x3p_kernel<32, true, 9>), grid, dim3(256), 0, s, a, scale);
-    else hipLaunchKernelGGL((attention_x3p_kernel<32, true, 10>), grid, dim3(256), 0, s, a, scale);
-    return hipGetLastError();
-  }
-#endif
   if (hd == 32) hipLaunchKernelGGL((attention_x3_kernel<32>), grid, dim3(256), 0, s, a, scale);
   else hipLaunchKernelGGL((attention_x3p_kernel<64>), grid, dim3(256), 0, s, a, scale);
   return hipGetLastError();

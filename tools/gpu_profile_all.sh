@@ -2,7 +2,7 @@
 # Full measurement set for profiles/: bench JSON lines (c3 default, c2, c5), rocprofv3 kernel stats of the bench command,
 # and PMC passes (MFMA busy, FETCH_SIZE, WRITE_SIZE -- separate runs, kernel trace only) of the 64-pair step (the bench's own step).
 # usage: tools/gpu_profile_all.sh <tag>      -> gpurun_out/<tag>_*
-tag=${1:-r03_final}
+tag=${1:-r04}
 R=$(pwd); export TMPDIR=/tmp
 out=$R/gpurun_out; mkdir -p $out
 python bench.py > $out/${tag}_bench_c3.json 2> $out/${tag}_bench_c3.log
@@ -23,7 +23,7 @@ python tools/rocpd_pmc.py $db > $out/${tag}_pmc_fetch.txt
 db=$(prof write --kernel-trace --pmc WRITE_SIZE -d $out/prof_tmp -- python $R/tools/run_pairs.py --pairs 64 --iters 2)
 python tools/rocpd_pmc.py $db > $out/${tag}_pmc_write.txt
 rm -rf $out/prof_tmp
-python tools/pmc_traffic.py $out/${tag}_pmc_fetch.txt $out/${tag}_pmc_write.txt 64 $out/r03_pmc_traffic.json > /dev/null
+python tools/pmc_traffic.py $out/${tag}_pmc_fetch.txt $out/${tag}_pmc_write.txt 64 $out/r04_pmc_traffic.json > /dev/null
 tail -1 $out/${tag}_bench_c3.json | cut -c1-400
 head -12 $out/${tag}_kernel_stats.txt
 head -8 $out/${tag}_pmc_sq.txt; head -4 $out/${tag}_pmc_fetch.txt; head -4 $out/${tag}_pmc_write.txt

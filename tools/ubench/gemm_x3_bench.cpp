@@ -1,6 +1,6 @@
 // gemm_x3_bench.cpp -- times imx::launch_gemm_x3 (and the fp32-MFMA gemm_ws it replaces) on the GNN's three products at 64 pairs.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -x hip tools/ubench/gemm_x3_bench.cpp image-matching_amd/csrc/gemm_x3.hip \
-//         image-matching_amd/csrc/gemm_ws.hip -o tools/ubench/gemm_x3_bench
+//         -o tools/ubench/gemm_x3_bench      (-DIMX_SPLIT_DOT2=0 for the shift/subtract split: A/B of csrc/split3.h)
 #include "../../image-matching_amd/csrc/imx_kernels.h"
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -41,10 +41,9 @@ int main() {
     hipMemcpy(dwx, pl.data(), pl.size() * 2, hipMemcpyHostToDevice); hipMemset(dres, 0, (size_t)M * N * 4);
     GemmArgs g{da0, sh.K1 ? sh.K0 : K, sh.K0, sh.K1 ? da1 : nullptr, sh.K1, sh.K1, dw, db, sh.res ? dres : nullptr, N, dout, N, M, N, N, sh.relu ? 1 : 0};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int form = 0; form < 2; ++form) {
-      auto run = [&]() { return form ? launch_gemm_ws(g, 0) : launch_gemm_x3(g, dwx, 0); };
-      if (form && !gemm_ws_supported(g)) continue;
-      for (int i = 0; i < 3; ++i) run();
+    for (int form = 0; form < 1; ++form) {          // (the fp32-MFMA gemm_ws this was compared with was removed in round 3)
+      auto run = [&]() { return launch_gemm_x3(g, dwx, 0); };
+      for (int i = 0; i < 10; ++i) run();
       hipEventRecord(e0, 0);
       for (int i = 0; i < 20; ++i) run();
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
