@@ -105,6 +105,9 @@ def algorithmic_work(B, H, W, d, K, kenc, iters, n_layers=18):
         "gnn_mlp1": ("mfma", 2.0 * R * (2 * d * 2 * d + d * d)),
         "gnn_mlp2": ("mfma", 2.0 * R * 2 * d * d),
         "final_proj": ("mfma", 2.0 * R * d * d),
+        # the fused layer tail (gnn_tail_x3: mlp.0' -> mlp.3 -> the next layer's q|k|v, or final_proj after the last layer), averaged over
+        # the n_layers launches of a step: n_layers x (mlp1 + mlp2) + (n_layers - 1) x q|k|v + final_proj
+        "gnn_tail": ("mfma", (n_layers * (2.0 * R * (2 * d * 2 * d + d * d) + 2.0 * R * 2 * d * d) + (n_layers - 1) * 2.0 * R * d * 3 * d + 2.0 * R * d * d) / n_layers),
         "score_gemm": ("mfma", 2.0 * B * K * K * d),
         "sinkhorn": ("hbm", 4.0 * B * K * K * iters),           # one launch group = all iterations; the slab form reads S ONCE per iteration
         "matches": ("hbm", 4.0 * B * K * K * 2),
@@ -138,6 +141,7 @@ def executed_work(B, H, W, d, K, kenc, iters, n_layers=18):
         "qkv_proj": 2.0 * R * d * 3 * d, "attention": 2.0 * 2 * B * 2 * K * K * d,
         "gnn_mlp1": 2.0 * R * 2 * d * 2 * d, "gnn_mlp2": 2.0 * R * 2 * d * d,
         "final_proj": 2.0 * R * d * d, "score_gemm": 2.0 * B * K * K * d,
+        "gnn_tail": (n_layers * (2.0 * R * 2 * d * 2 * d + 2.0 * R * 2 * d * d) + (n_layers - 1) * 2.0 * R * d * 3 * d + 2.0 * R * d * d) / n_layers,
     }
     ch = list(kenc) + [d]
     ex["kenc"] = 2.0 * R * sum(ch[i] * ch[i + 1] for i in range(len(ch) - 1)) / (len(ch) - 1)

@@ -4,6 +4,7 @@
 // imx_kernels.h; this file only moves weights once and enqueues kernels on the caller's stream.
 #include "../../include/imx.h"
 #include "imx_kernels.h"
+#include "gnn_tail_pack.h"
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -57,6 +58,7 @@ struct GemmW {
 };
 struct GnnLayer {
   GemmW qkv, merge, mlp1, mlp2;
+  float* tail_stream = nullptr;    // gnn_tail_pack() of (mlp.0', mlp.3, the NEXT layer's q|k|v or final_proj): gnn_tail_x3.hip, d = 128 only
 };
 struct Tap {
   const void* p;
@@ -530,6 +532,8 @@ int finalize_superglue(imx_handle_t h) {
   std::vector<int> perm(d);
   for (int cidx = 0; cidx < d; ++cidx) perm[cidx] = (cidx % HEADS) * HD + cidx / HEADS;
   h->layers.clear();
+  std::vector<std::vector<float>> host_qkv, host_w1, host_w2;      // host copies for the fused layer tail's weight stream (d = 128)
+  std::vector<int> host_ld1, host_ld2;
   for (int l = 0; l < c.num_gnn_layers; ++l) {
     std::string p = "gnn.layers." + std::to_string(l);
     GnnLayer L;
@@ -545,6 +549,7 @@ int finalize_superglue(imx_handle_t h) {
           b[which * d + perm[n]] = bs[n];
         }
       }
+      host_qkv.push_back(w);
       L.qkv.w = upload(h, w);
       L.qkv.wx3 = upload(h, split_bf16x3(w, d, N));
       L.qkv.wf = (d % 16 == 0) ? upload(h, fragment_order(w, d, N)) : nullptr;
@@ -578,11 +583,35 @@ int finalize_superglue(imx_handle_t h) {
           wf[(size_t)(d + kk) * np1 + n] = (float)acc;
         }
       if (upload_gemm(h, L.mlp1, wf, bf, 2 * d, 2 * d, np1, (p + ".mlp.0 (+merge)").c_str())) return -1;
+      host_w1.push_back(wf);
+      host_ld1.push_back(np1);
     }
-    if (make_gemm(h, L.mlp2, raw, p + ".mlp.3", "", 2 * d, d)) return -1;
+    {
+      std::vector<float> w2, b2;
+      int np2 = 0;
+      build_gemm_host(raw, p + ".mlp.3", "", 2 * d, d, nullptr, w2, b2, np2);
+      if (upload_gemm(h, L.mlp2, w2, b2, 2 * d, d, np2, (p + ".mlp.3").c_str())) return -1;
+      host_w2.push_back(w2);
+      host_ld2.push_back(np2);
+    }
     h->layers.push_back(L);
   }
-  if (make_gemm(h, h->final_proj, raw, "final_proj", "", d, d)) return -1;
+  std::vector<float> wfin, bfin;
+  int npf = 0;
+  build_gemm_host(raw, "final_proj", "", d, d, nullptr, wfin, bfin, npf);
+  if (upload_gemm(h, h->final_proj, wfin, bfin, d, d, npf, "final_proj")) return -1;
+  // the fused layer tail of the throughput path (gnn_tail_x3.hip): one weight stream per layer, in consumption order
+  if (d == 128) {
+    for (int l = 0; l < c.num_gnn_layers; ++l) {
+      const bool last = l + 1 == c.num_gnn_layers;
+      const std::vector<uint16_t> st = gnn_tail_pack(host_w1[l].data(), host_ld1[l], host_w2[l].data(), host_ld2[l],
+                                                     last ? wfin.data() : host_qkv[l + 1].data(), last ? npf : 3 * d, d, last ? d : 3 * d);
+      std::vector<float> bits((st.size() + 1) / 2);
+      memcpy(bits.data(), st.data(), st.size() * sizeof(uint16_t));
+      h->layers[l].tail_stream = upload(h, bits);
+      if (!h->layers[l].tail_stream) return fail(h, "weight upload failed (layer %d tail stream)", l);
+    }
+  }
   return 0;
 }
 
@@ -820,8 +849,18 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     const bool last = l + 1 == h->layers.size();
     const GemmW& nx = last ? h->final_proj : h->layers[l + 1].qkv;
     GnnSmallArgs ga{x, att, L.mlp1.wf, L.mlp1.b, L.mlp2.wf, L.mlp2.b, nx.wf, nx.b, last ? mdesc : qkv, R, d, nx.N};
+    // Throughput form: the same three products in one launch on the bf16 pipe (gnn_tail_x3.hip).  "gnn_tail" = auto takes it from
+    // 32768 rows (16 pairs of 1024 keypoints: below that a workgroup's 256 rows leave CUs idle and three gemm_x3 launches are faster)
+    // and ALWAYS under "latency_forms" = off, whose contract is that results do not depend on the batch size.
+    GnnTailArgs ta{x, att, L.tail_stream, L.mlp1.b, L.mlp2.b, nx.b, last ? mdesc : qkv, R, d, nx.N};
+    const bool tail_ok = !small_form && !h->opt.mfma_f32 && L.tail_stream && nx.Npad == nx.N && gnn_tail_x3_supported(ta);
+    const bool tail = tail_ok && (h->opt.gnn_tail == 1 || (h->opt.gnn_tail < 0 && (h->opt.latency_forms == 0 || R >= 32768)));
     if (small_form && h->opt.latency_forms != 2 && L.mlp1.Npad == 2 * d && L.mlp2.Npad == d && nx.Npad == nx.N && gnn_layer_small_supported(ga)) {
       RUN("gnn_layer", launch_gnn_layer_small(ga, s));
+      have_next = !last;
+      have_mdesc = last;
+    } else if (tail) {
+      RUN("gnn_tail", launch_gnn_tail_x3(ta, s));
       have_next = !last;
       have_mdesc = last;
     } else {
@@ -858,13 +897,15 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   return 0;
 }
 
-// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | wx3 | direct.  Returns 0, or -1 for an unknown key / value.
+// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | wx3 | direct, "gnn_tail" = auto | fused | unfused.  Returns 0, or -1 for an unknown key / value.
 int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
   Options& o = h->opt;
   if (key == "mfma") {
     if (v == "x3") o.mfma_f32 = 0; else if (v == "f32") o.mfma_f32 = 1; else return -1;
   } else if (key == "latency_forms") {
     if (v == "auto") o.latency_forms = -1; else if (v == "off" || v == "0") o.latency_forms = 0; else if (v == "on" || v == "1") o.latency_forms = 1; else if (v == "unfused") o.latency_forms = 2; else return -1;
+  } else if (key == "gnn_tail") {
+    if (v == "auto") o.gnn_tail = -1; else if (v == "unfused" || v == "0") o.gnn_tail = 0; else if (v == "fused" || v == "1") o.gnn_tail = 1; else return -1;
   } else if (key == "conv") {
     if (v == "wino") { o.conv_direct = 0; o.conv_wx3 = 0; }
     else if (v == "wx3") { o.conv_direct = 0; o.conv_wx3 = 1; }
@@ -928,7 +969,7 @@ int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
     h->device = device_id;
     h->cfg = *cfg;
     // the environment seeds the options once, here; afterwards only imx_set_option changes them
-    for (const char* key : {"mfma", "latency_forms", "conv"}) {
+    for (const char* key : {"mfma", "latency_forms", "conv", "gnn_tail"}) {
       std::string env = std::string("IMX_") + key;
       for (char& ch : env) ch = (char)toupper((unsigned char)ch);
       if (const char* e = getenv(env.c_str()))
@@ -1361,7 +1402,7 @@ int imx_set_option(imx_handle_t h, const char* key, const char* value) {
   return guarded(h, "imx_set_option", [&]() -> int {
     if (!h) return -1;
     if (!key || !value) return fail(h, "imx_set_option: null argument");
-    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wx3|direct)", key, value);
+    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wx3|direct, gnn_tail = auto|fused|unfused)", key, value);
     return 0;
   });
 }
@@ -1374,6 +1415,7 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     if (k == "mfma") h->opt_text = o.mfma_f32 ? "f32" : "x3";
     else if (k == "latency_forms") h->opt_text = o.latency_forms < 0 ? "auto" : o.latency_forms == 2 ? "unfused" : o.latency_forms ? "on" : "off";
     else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : o.conv_wx3 ? "wx3" : "wino";
+    else if (k == "gnn_tail") h->opt_text = o.gnn_tail < 0 ? "auto" : o.gnn_tail ? "fused" : "unfused";
     else h->opt_text.clear();
     return h->opt_text.c_str();
   } catch (...) {

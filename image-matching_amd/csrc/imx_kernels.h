@@ -15,6 +15,8 @@ struct Options {
   int latency_forms = -1;  // "latency_forms": -1 = "auto" (gemm_small for M <= 4096 rows, key-split attention for grids of
                            //         <= 256 workgroups, one launch per GNN layer tail), 0 = "off" (results do not depend on the batch size
                            //         bit for bit), 1 = "on", 2 = "unfused" (on, with the layer tail as three gemm_small launches: the A/B of the fusion)
+  int gnn_tail = -1;       // "gnn_tail": -1 = "auto" (the fused layer tail gnn_tail_x3 from 32768 rows, and always under latency_forms = off),
+                           //         0 = "unfused" (three gemm_x3 launches: the A/B of the fusion), 1 = "fused" (whenever the shape allows)
   int conv_direct = 0;     // "conv": 0 = "wino" (Winograd F(2x4,3x3) on the fp32 MFMA; direct only for shapes it rejects), 1 = "direct"
   int conv_wx3 = 0;        // "conv" = "wx3": the Winograd layers after the first as six bf16 term products on the bf16 pipe (conv3x3_wx3.hip)
 };
@@ -195,6 +197,20 @@ struct AttnArgs {
   int latency_forms;             // Options::latency_forms
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+// The tail of one GNN layer of the throughput path in one launch (gnn_tail_x3.hip): hidden = relu([x | att] W1' + b1); x += hidden W2 + b2;
+// out = x W3 + b3 (the next layer's q|k|v, n3 = 3 d, or final_proj, n3 = d) -- six bf16 term products per fp32 product; d = 128.
+// `stream` = gnn_tail_pack() of the three weight matrices (gnn_tail_pack.h).
+struct GnnTailArgs {
+  float* x;                  // [M][d], updated in place
+  const float* att;          // [M][d]
+  const void* stream;        // weight images, consumption order
+  const float* b1; const float* b2; const float* b3;     // [2d], [d], [n3]
+  float* out;                // [M][n3]
+  int M, d, n3;
+};
+bool gnn_tail_x3_supported(const GnnTailArgs& a);
+hipError_t launch_gnn_tail_x3(const GnnTailArgs& a, hipStream_t s);
+
 // both products as six bf16 term products on the bf16 matrix pipe (attention_x3.hip): head dim 32 or 64
 bool attention_x3_supported(const AttnArgs& a);
 hipError_t launch_attention_x3(const AttnArgs& a, hipStream_t s);

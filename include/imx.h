@@ -211,7 +211,7 @@ int imx_timing_reset(imx_handle_t h);
 const char* imx_timing_form(imx_handle_t h, int index);
 
 /* Kernel-form options of a handle.  Defaults come from the environment ONCE, at imx_create (IMX_MFMA, IMX_LATENCY_FORMS,
- * IMX_CONV); afterwards only this call changes them -- nothing reads the environment on the launch path.
+ * IMX_CONV, IMX_GNN_TAIL); afterwards only this call changes them -- nothing reads the environment on the launch path.
  *   "mfma"           "x3"   (default) fp32 products as six bf16 term products on the bf16 matrix pipe where a kernel has that
  *                           form (every linear layer, attention at head dims 32/64); "f32" keeps every product on the fp32 MFMA
  *                           (the A/B reference the parity tests hold the default against);
@@ -222,6 +222,10 @@ const char* imx_timing_form(imx_handle_t h, int index);
  *   "conv"           "wino" (default) Winograd F(2x4,3x3) on the fp32 MFMA; "wx3" the same arithmetic with its products as six bf16
  *                           term products on the bf16 pipe for every 3x3 layer after the first (as accurate; slower as of this build);
  *                           "direct" the direct implicit-GEMM kernel for every 3x3 layer.
+ *   "gnn_tail"       "auto" (default) from 32768 feature rows (16 pairs of 1024 keypoints) the tail of a GNN layer (mlp.0 -> mlp.3 +
+ *                           residual -> the next layer's q|k|v or final_proj) is ONE launch on the bf16 pipe (descriptor_dim 128), and
+ *                           always under "latency_forms" = "off" (batch-size independent results); "unfused" three launches (the A/B
+ *                           reference); "fused" whenever the shape allows.
  * Unknown keys / values are an error.  imx_get_option returns the current value ("" for an unknown key); the pointer is valid
  * until the next call on the handle. */
 int imx_set_option(imx_handle_t h, const char* key, const char* value);

@@ -1,0 +1,113 @@
+// gnn_tail_bench.cpp -- times imx::launch_gnn_tail_x3 (the fused GNN layer tail) against the three gemm_x3 launches it replaces, at the
+// C3 step's row count (64 pairs: 131072 rows, d = 128), and checks both against a float64 evaluation of a few rows.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -Iinclude -x hip tools/ubench/gnn_tail_bench.cpp \
+//         image-matching_amd/csrc/gnn_tail_x3.hip image-matching_amd/csrc/gemm_x3.hip -o tools/ubench/gnn_tail_bench
+#include "../../image-matching_amd/csrc/imx_kernels.h"
+#include "../../image-matching_amd/csrc/gnn_tail_pack.h"
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace imx;
+#ifdef GT_TRACE
+namespace imx { void gnn_tail_trace_dump(); }
+#endif
+namespace imx { thread_local const char* last_form = nullptr; }
+static std::vector<uint16_t> x3_planes(const std::vector<float>& w, int K, int N) {      // gemm_x3's B-fragment order (imx_api.cpp: split_bf16x3)
+  const int nst = K / 16;
+  std::vector<uint16_t> pl((size_t)3 * N * K);
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < N; ++n) {
+      uint16_t t[3];
+      gt_split(w[(size_t)k * N + n], t);
+      const int nb = n >> 5, st = k >> 4, lane = (n & 31) + 32 * ((k >> 3) & 1), j = k & 7;
+      for (int q = 0; q < 3; ++q) pl[((((size_t)nb * nst + st) * 3 + q) * 64 + lane) * 8 + j] = t[q];
+    }
+  return pl;
+}
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 131072, d = 128, n3 = argc > 2 ? atoi(argv[2]) : 384;
+  std::vector<float> x((size_t)M * d), att((size_t)M * d), w1((size_t)2 * d * 2 * d), w2((size_t)2 * d * d), w3((size_t)d * n3), b1(2 * d), b2(d), b3(n3);
+  srand(11);
+  auto rnd = [](float s) { return (rand() / (float)RAND_MAX - 0.5f) * s; };
+  for (auto& v : x) v = rnd(2.f);
+  for (auto& v : att) v = rnd(2.f);
+  for (auto& v : w1) v = rnd(0.25f);
+  for (auto& v : w2) v = rnd(0.25f);
+  for (auto& v : w3) v = rnd(0.3f);
+  for (auto& v : b1) v = rnd(1.f);
+  for (auto& v : b2) v = rnd(1.f);
+  for (auto& v : b3) v = rnd(1.f);
+  const std::vector<uint16_t> stream = gnn_tail_pack(w1.data(), 2 * d, w2.data(), d, w3.data(), n3, d, n3);
+  const auto p1 = x3_planes(w1, 2 * d, 2 * d), p2 = x3_planes(w2, 2 * d, d), p3 = x3_planes(w3, d, n3);
+  float *dx, *dx0, *datt, *dhid, *dout, *db1, *db2, *db3, *dw1, *dw2, *dw3; void *dstream, *dp1, *dp2, *dp3;
+  hipMalloc(&dx, x.size() * 4); hipMalloc(&dx0, x.size() * 4); hipMalloc(&datt, x.size() * 4); hipMalloc(&dhid, (size_t)M * 2 * d * 4); hipMalloc(&dout, (size_t)M * n3 * 4);
+  hipMalloc(&db1, 2 * d * 4); hipMalloc(&db2, d * 4); hipMalloc(&db3, n3 * 4); hipMalloc(&dstream, stream.size() * 2);
+  hipMalloc(&dw1, w1.size() * 4); hipMalloc(&dw2, w2.size() * 4); hipMalloc(&dw3, w3.size() * 4);
+  hipMalloc(&dp1, p1.size() * 2); hipMalloc(&dp2, p2.size() * 2); hipMalloc(&dp3, p3.size() * 2);
+  hipMemcpy(dx0, x.data(), x.size() * 4, hipMemcpyHostToDevice); hipMemcpy(datt, att.data(), x.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(db1, b1.data(), 2 * d * 4, hipMemcpyHostToDevice); hipMemcpy(db2, b2.data(), d * 4, hipMemcpyHostToDevice); hipMemcpy(db3, b3.data(), n3 * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dstream, stream.data(), stream.size() * 2, hipMemcpyHostToDevice);
+  hipMemcpy(dw1, w1.data(), w1.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dw2, w2.data(), w2.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dw3, w3.data(), w3.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dp1, p1.data(), p1.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dp2, p2.data(), p2.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dp3, p3.data(), p3.size() * 2, hipMemcpyHostToDevice);
+  // float64 reference of rows r0 .. r0 + 63 (two waves' worth, second half of a workgroup) and the last 32 rows
+  const int nref = 96;
+  std::vector<int> rows;
+  for (int i = 0; i < 64; ++i) rows.push_back(1000 + 160 + i);
+  for (int i = 0; i < 32; ++i) rows.push_back(M - 32 + i);
+  std::vector<double> rx((size_t)nref * d), rout((size_t)nref * n3);
+  for (int ri = 0; ri < nref; ++ri) {
+    const int r = rows[ri];
+    std::vector<double> hid(2 * d);
+    for (int n = 0; n < 2 * d; ++n) {
+      double a = b1[n];
+      for (int k = 0; k < d; ++k) a += (double)x[(size_t)r * d + k] * w1[(size_t)k * 2 * d + n];
+      for (int k = 0; k < d; ++k) a += (double)att[(size_t)r * d + k] * w1[(size_t)(d + k) * 2 * d + n];
+      hid[n] = a > 0 ? a : 0;
+    }
+    for (int n = 0; n < d; ++n) {
+      double a = b2[n] + x[(size_t)r * d + n];
+      for (int k = 0; k < 2 * d; ++k) a += hid[k] * w2[(size_t)k * d + n];
+      rx[(size_t)ri * d + n] = a;
+    }
+    for (int n = 0; n < n3; ++n) {
+      double a = b3[n];
+      for (int k = 0; k < d; ++k) a += rx[(size_t)ri * d + k] * w3[(size_t)k * n3 + n];
+      rout[(size_t)ri * n3 + n] = a;
+    }
+  }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int form = 0; form < 2; ++form) {
+    GnnTailArgs t{dx, datt, dstream, db1, db2, db3, dout, M, d, n3};
+    GemmArgs g1{dx, d, d, datt, d, d, dw1, db1, nullptr, 0, dhid, 2 * d, M, 2 * d, 2 * d, 1};
+    GemmArgs g2{dhid, 2 * d, 2 * d, nullptr, 0, 0, dw2, db2, dx, d, dx, d, M, d, d, 0};
+    GemmArgs g3{dx, d, d, nullptr, 0, 0, dw3, db3, nullptr, 0, dout, n3, M, n3, n3, 0};
+    auto run = [&]() {
+      if (form == 0) return launch_gnn_tail_x3(t, 0);
+      launch_gemm_x3(g1, dp1, 0); launch_gemm_x3(g2, dp2, 0); return launch_gemm_x3(g3, dp3, 0);
+    };
+    hipMemcpy(dx, dx0, x.size() * 4, hipMemcpyDeviceToDevice);
+    hipError_t err = run();
+    hipDeviceSynchronize();
+    if (err != hipSuccess || hipGetLastError() != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(err)); return 1; }
+    std::vector<float> gx((size_t)M * d), go((size_t)M * n3);
+    hipMemcpy(gx.data(), dx, gx.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(go.data(), dout, go.size() * 4, hipMemcpyDeviceToHost);
+    double sx = 0, mx = 0, so = 0, mo = 0;
+    for (int ri = 0; ri < nref; ++ri) {
+      for (int n = 0; n < d; ++n) { const double e = gx[(size_t)rows[ri] * d + n] - rx[(size_t)ri * d + n]; sx += e * e; if (fabs(e) > mx) mx = fabs(e); }
+      for (int n = 0; n < n3; ++n) { const double e = go[(size_t)rows[ri] * n3 + n] - rout[(size_t)ri * n3 + n]; so += e * e; if (fabs(e) > mo) mo = fabs(e); }
+    }
+    for (int i = 0; i < 10; ++i) { run(); }
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 20; ++i) run();
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+#ifdef GT_TRACE
+    if (form == 0) gnn_tail_trace_dump();
+#endif
+    printf("%-34s %7.1f us per layer tail   x' rms err vs float64 %.2e max %.2e | out rms %.2e max %.2e\n", form ? "3 x gemm_x3 (mlp1, mlp2, next)" : "gnn_tail_x3 (one launch)",
+           ms * 1000 / 20, sqrt(sx / (nref * d)), mx, sqrt(so / (nref * (double)n3)), mo);
+  }
+  return 0;
+}
