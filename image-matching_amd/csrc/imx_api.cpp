@@ -45,7 +45,6 @@ struct DevBuf {
 struct ConvW {
   float* w = nullptr;    // direct form  [9][Cin][Cout] (conv3x3.hip: IMX_CONV=direct, and the fallback for shapes wino24 rejects)
   float* wu24 = nullptr; // Winograd F(2x4,3x3) form (conv1ab_wino24.hip / conv3x3_wino24.hip layout)
-  float* wux3 = nullptr; // the same Winograd weights as three bf16 planes per value, MFMA A-fragment order (conv3x3_wx3.hip)
   float* b = nullptr;
   int cin = 0, cout = 0;
 };
@@ -326,39 +325,6 @@ float bf16_to_f32(uint16_t b) {
   return x;
 }
 // U = G2 g G4^T as in wino24_transform, every value split exactly into three bf16 terms (x = h + m + l) and laid out as
-// conv3x3_wx3.hip's MFMA A fragments: [Cout/64][Cin/16][row i (4)][column j (6)][co block (2)][plane (3)][lane (64)][8], lane =
-// (co & 31) + 32 * ((ci >> 3) & 1), element = ci & 7.  Returned packed two bf16 per float slot (bit patterns only).
-std::vector<float> wino24x3_transform(const std::vector<float>& w, int cin, int cout) {
-  static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-  static const double G4[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                  {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-  const int nchunk = cin / 16;
-  std::vector<uint16_t> u((size_t)cout * cin * 24 * 3, 0);
-  for (int co = 0; co < cout; ++co)
-    for (int ci = 0; ci < cin; ++ci) {
-      double g[3][3];
-      for (int ky = 0; ky < 3; ++ky)
-        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((size_t)(ky * 3 + kx) * cin + ci) * cout + co];
-      const int cog = co / 64, cob = (co >> 5) & 1, chunk = ci / 16, lane = (co & 31) + 32 * ((ci >> 3) & 1), e = ci & 7;
-      for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 6; ++j) {
-          double acc = 0.0;
-          for (int ky = 0; ky < 3; ++ky)
-            for (int kx = 0; kx < 3; ++kx) acc += G2[i][ky] * g[ky][kx] * G4[j][kx];
-          const float x = (float)acc;          // the fp32 weight the fp32-MFMA form multiplies with: the SAME value, split exactly
-          uint16_t t[3];
-          t[0] = bf16_rne(x);
-          const float r1 = x - bf16_to_f32(t[0]);
-          t[1] = bf16_rne(r1);
-          t[2] = bf16_rne(r1 - bf16_to_f32(t[1]));
-          const size_t base = ((((size_t)(cog * nchunk + chunk) * 4 + i) * 6 + j) * 2 + cob) * 3;
-          for (int pl = 0; pl < 3; ++pl) u[((base + pl) * 64 + lane) * 8 + e] = t[pl];
-        }
-    }
-  std::vector<float> out((u.size() + 1) / 2);
-  memcpy(out.data(), u.data(), u.size() * sizeof(uint16_t));
-  return out;
-}
 
 int make_conv(imx_handle_t h, ConvW& out, const std::map<std::string, HostTensor>& raw, const std::string& conv,
               const std::string& bn, int cin, int cout) {
@@ -366,11 +332,10 @@ int make_conv(imx_handle_t h, ConvW& out, const std::map<std::string, HostTensor
   put_conv3(raw, conv, bn, cin, cout, cout, 0, w, b);
   out.w = upload(h, w);
   out.wu24 = upload(h, wino24_transform(w, cin, cout));
-  out.wux3 = upload(h, wino24x3_transform(w, cin, cout));
   out.b = upload(h, b);
   out.cin = cin;
   out.cout = cout;
-  return (out.w && out.wu24 && out.wux3 && out.b) ? 0 : fail(h, "weight upload failed (%s)", conv.c_str());
+  return (out.w && out.wu24 && out.b) ? 0 : fail(h, "weight upload failed (%s)", conv.c_str());
 }
 
 // linear weight (N,K[,1[,1]]) -> W[k_perm(k)][n_perm(n)] padded to Npad columns, folded BN
@@ -478,11 +443,10 @@ int finalize_superpoint(imx_handle_t h) {
     put_conv3(raw, "convDa", bn ? "bnDa" : "", 128, 256, 512, 256, w, b);
     h->conv[7].w = upload(h, w);
     h->conv[7].wu24 = upload(h, wino24_transform(w, 128, 512));
-    h->conv[7].wux3 = upload(h, wino24x3_transform(w, 128, 512));
     h->conv[7].b = upload(h, b);
     h->conv[7].cin = 128;
     h->conv[7].cout = 512;
-    if (!h->conv[7].w || !h->conv[7].wu24 || !h->conv[7].wux3 || !h->conv[7].b) return fail(h, "weight upload failed (heads)");
+    if (!h->conv[7].w || !h->conv[7].wu24 || !h->conv[7].b) return fail(h, "weight upload failed (heads)");
   }
   if (make_gemm(h, h->pb, raw, "convPb", bn ? "bnPb" : "", 256, 65)) return -1;
   if (make_gemm(h, h->db, raw, "convDb", bn ? "bnDb" : "", 256, d)) return -1;
@@ -674,14 +638,11 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
     a.in_blocked = (blocked && !first) ? 1 : 0;
     a.out_blocked = (blocked && !last) ? 1 : 0;
     a.in = in; a.in2 = first ? img1 : nullptr; a.split = first ? split : 0;
-    a.w = w.w; a.wu24 = w.wu24; a.wux3 = w.wux3; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
+    a.w = w.w; a.wu24 = w.wu24; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
     a.B = B; a.H = hh; a.W = ww; a.Cin = w.cin; a.Cout = w.cout; a.relu = 1; a.pool = pool ? 1 : 0; a.first = first ? 1 : 0;
     const bool fused1 = a.first && a.pool && !h->opt.conv_direct;
     const bool wino = !a.first && !h->opt.conv_direct && conv3x3_wino24_supported(a);
-    // "conv" = "wx3": the same Winograd arithmetic with its fp32 products as six bf16 term products on the bf16 matrix pipe
-    // (conv3x3_wx3.hip: correct, as accurate, and slower than the fp32-MFMA form as of round 3 -- DESIGN 5d -- hence opt-in)
-    const bool wx3 = wino && h->opt.conv_wx3 && conv3x3_wx3_supported(a);
-    RUN(name, fused1 ? launch_conv1ab_wino24(a, s) : wx3 ? launch_conv3x3_wx3(a, s) : wino ? launch_conv3x3_wino24(a, s) : launch_conv3x3(a, s));
+    RUN(name, fused1 ? launch_conv1ab_wino24(a, s) : wino ? launch_conv3x3_wino24(a, s) : launch_conv3x3(a, s));
     return 0;
   };
   if (conv("conv1ab_pool", h->conv[0], img0, a1, H, W, true, true)) return -1;
@@ -897,7 +858,7 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   return 0;
 }
 
-// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | wx3 | direct, "gnn_tail" = auto | fused | unfused.  Returns 0, or -1 for an unknown key / value.
+// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | direct, "gnn_tail" = auto | fused | unfused.  Returns 0, or -1 for an unknown key / value.
 int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
   Options& o = h->opt;
   if (key == "mfma") {
@@ -907,9 +868,8 @@ int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
   } else if (key == "gnn_tail") {
     if (v == "auto") o.gnn_tail = -1; else if (v == "unfused" || v == "0") o.gnn_tail = 0; else if (v == "fused" || v == "1") o.gnn_tail = 1; else return -1;
   } else if (key == "conv") {
-    if (v == "wino") { o.conv_direct = 0; o.conv_wx3 = 0; }
-    else if (v == "wx3") { o.conv_direct = 0; o.conv_wx3 = 1; }
-    else if (v == "direct") { o.conv_direct = 1; o.conv_wx3 = 0; }
+    if (v == "wino") o.conv_direct = 0;
+    else if (v == "direct") o.conv_direct = 1;
     else return -1;
   } else {
     return -1;
@@ -1402,7 +1362,7 @@ int imx_set_option(imx_handle_t h, const char* key, const char* value) {
   return guarded(h, "imx_set_option", [&]() -> int {
     if (!h) return -1;
     if (!key || !value) return fail(h, "imx_set_option: null argument");
-    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wx3|direct, gnn_tail = auto|fused|unfused)", key, value);
+    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|direct, gnn_tail = auto|fused|unfused)", key, value);
     return 0;
   });
 }
@@ -1414,7 +1374,7 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     const Options& o = h->opt;
     if (k == "mfma") h->opt_text = o.mfma_f32 ? "f32" : "x3";
     else if (k == "latency_forms") h->opt_text = o.latency_forms < 0 ? "auto" : o.latency_forms == 2 ? "unfused" : o.latency_forms ? "on" : "off";
-    else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : o.conv_wx3 ? "wx3" : "wino";
+    else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : "wino";
     else if (k == "gnn_tail") h->opt_text = o.gnn_tail < 0 ? "auto" : o.gnn_tail ? "fused" : "unfused";
     else h->opt_text.clear();
     return h->opt_text.c_str();

@@ -18,7 +18,6 @@ struct Options {
   int gnn_tail = -1;       // "gnn_tail": -1 = "auto" (the fused layer tail gnn_tail_x3 from 32768 rows, and always under latency_forms = off),
                            //         0 = "unfused" (three gemm_x3 launches: the A/B of the fusion), 1 = "fused" (whenever the shape allows)
   int conv_direct = 0;     // "conv": 0 = "wino" (Winograd F(2x4,3x3) on the fp32 MFMA; direct only for shapes it rejects), 1 = "direct"
-  int conv_wx3 = 0;        // "conv" = "wx3": the Winograd layers after the first as six bf16 term products on the bf16 pipe (conv3x3_wx3.hip)
 };
 
 // The form a launcher picked ("gemm_x3:bf16x3", "conv3x3_wino24:f32", ...: kernel family, then the matrix pipe it runs on or
@@ -48,8 +47,6 @@ struct ConvArgs {
   int split;
   const float* w;     // [9][Cin][Cout]  (BN folded)
   const float* wu24;  // Winograd F(2x4,3x3) weights G2 g G4^T: [Cout/64][Cin/8][12 quads][4 co-blocks][64 lanes][4] (conv1ab_wino24.hip, conv3x3_wino24.hip)
-  const void* wux3;   // the same Winograd weights as three bf16 planes per value in MFMA A-fragment order (conv3x3_wx3.hip):
-                      // [Cout/64][Cin/16][4 rows i][6 columns j][2 co blocks][3 planes][64 lanes][8]
   const float* bias;  // [Cout]
   const float* w1;    // FIRST mode: conv1a weights [9][64] and bias [64] (BN folded), Cin == 64
   const float* b1;
@@ -69,10 +66,6 @@ hipError_t launch_conv1ab_wino24(const ConvArgs& a, hipStream_t s); // fused con
 bool conv3x3_wino24_supported(const ConvArgs& a);                   // false (e.g. an image of >= 2 GB per layer): callers fall back to the direct form
 hipError_t launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s); // Winograd F(2x4,3x3), persistent, in-stream transform
 
-// Winograd F(2x4,3x3) with every fp32 product as six bf16 term products on the bf16 matrix pipe; channel-blocked input,
-// Cin % 16 == 0, Cout % 64 == 0, not first
-bool conv3x3_wx3_supported(const ConvArgs& a);
-hipError_t launch_conv3x3_wx3(const ConvArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- GEMM (MFMA fp32): 1x1 conv / linear
 // out[r][n] = act( sum_k A[r][k] * W[k][n] + bias[n] ) (+ res[r][n]);  A = [a0 | a1] column concat.

@@ -1,5 +1,5 @@
 // split3.h -- x = h + m + l, an fp32 value as three bf16 terms (8 significant bits each, round-to-nearest residuals): the operand
-// split of every "six bf16 term products per fp32 product" kernel (gemm_x3.hip, attention_x3.hip, conv3x3_wx3.hip).
+// split of every "six bf16 term products per fp32 product" kernel (gemm_x3.hip, gnn_tail_x3.hip, attention_x3.hip).
 //
 // Round 4: the residuals r = x - float(h) and r - float(m) are ONE instruction per value, v_dot2c_f32_bf16 (D += a.lo * b.lo +
 // a.hi * b.hi with the packed pair (h0, h1) as `a` and the constant (-1, 0) / (0, -1) as `b`): the products of a bf16 value with

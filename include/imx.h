@@ -219,9 +219,8 @@ const char* imx_timing_form(imx_handle_t h, int index);
  *                           the attention (grids of <= 256 workgroups) and one launch per GNN layer tail; "off" never (results
  *                           then do not depend on the batch size bit for bit); "on" whenever the shape allows; "unfused" = "on" with the GNN layer tail as three
  *                           launches instead of one (same bytes: the A/B reference of the fused latency kernel);
- *   "conv"           "wino" (default) Winograd F(2x4,3x3) on the fp32 MFMA; "wx3" the same arithmetic with its products as six bf16
- *                           term products on the bf16 pipe for every 3x3 layer after the first (as accurate; slower as of this build);
- *                           "direct" the direct implicit-GEMM kernel for every 3x3 layer.
+ *   "conv"           "wino" (default) Winograd F(2x4,3x3) on the fp32 MFMA; "direct" the direct implicit-GEMM kernel for every 3x3
+ *                           layer (the fallback for shapes Winograd rejects, and the A/B reference);
  *   "gnn_tail"       "auto" (default) from 32768 feature rows (16 pairs of 1024 keypoints) the tail of a GNN layer (mlp.0 -> mlp.3 +
  *                           residual -> the next layer's q|k|v or final_proj) is ONE launch on the bf16 pipe (descriptor_dim 128), and
  *                           always under "latency_forms" = "off" (batch-size independent results); "unfused" three launches (the A/B

@@ -198,28 +198,6 @@ def test_direct_conv_fallback_vs_reference_golden(monkeypatch):
         util.assert_close(_nchw(eng.fetch("semi")), g["semi"], "semi (direct)")
 
 
-@pytest.mark.parametrize("name", ["sp_ragged.npz", "sp_small.npz"])
-def test_winograd_on_the_bf16_pipe_vs_reference_golden(name):
-    """"conv" = "wx3": every 3x3 layer after the first as Winograd F(2x4,3x3) with its fp32 products carried as six bf16 term
-    products (conv3x3_wx3.hip; opt-in).  Same bar as the default kernels: the reference's dense stages at 1e-4, the score map at
-    1e-5, the reference's keypoints -- on the ragged fixture (123x165: partial tiles on both axes, odd pooled maps) and the
-    120x160 one -- and the form the library reports."""
-    g = util.golden(name)
-    H, W, seed, K = int(g["H"]), int(g["W"]), int(g["seed"]), int(g["max_keypoints"])
-    eng, L = _engine(128, K)
-    eng.set_option("conv", "wx3")
-    eng.load_state_dict(L.NET_SUPERPOINT, util.sp_sd(128))
-    x = torch.cat(util.pair(seed, H, W))
-    eng.set_timing(True)
-    _check_against(eng, x, [g["keypoints0"], g["keypoints1"]], [g["scores0"], g["scores1"]], [g["descriptors0"], g["descriptors1"]])
-    forms = {r[0]: r[3] for r in eng.timing_report(forms=True)}
-    eng.set_timing(False)
-    assert forms["conv2a"] == "conv3x3_wx3:bf16x3" and forms["convPaDa"] == "conv3x3_wx3:bf16x3" and forms["conv1ab_pool"] == "conv1ab_wino24:f32", forms
-    util.assert_close(_nchw(eng.fetch("x4")), g["x4"], "x4 (wx3)")
-    util.assert_close(_nchw(eng.fetch("semi")), g["semi"], "semi (wx3)")
-    util.assert_close(eng.fetch("score_map"), g["score_map"], "score map (wx3)", atol=1e-5)
-
-
 @pytest.mark.parametrize("radius", [1, 2, 3, 4, 5, 6, 9, 13])
 def test_nms_every_radius_bit_exact_vs_oracle(radius):
     """simple_nms is compare-only, so both forms (radius <= 4: the staged three-kernel form with bit-row masks; any other radius:

@@ -31,7 +31,7 @@ for name in ("sp_small.npz", "sp_ragged.npz"):
         out.append("%%s %%.3f" %% (k, r))
     print(name, " ".join(out))
 ''' % ROOT
-for label, env in (("default (F(2x4,3x3) on the fp32 MFMA)", {}), ("IMX_CONV=wx3 (F(2x4,3x3), fp32 products as six bf16 term products)", {"IMX_CONV": "wx3"}),
+for label, env in (("default (F(2x4,3x3) on the fp32 MFMA)", {}),
                    ("IMX_CONV=direct", {"IMX_CONV": "direct"})):
     r = subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, **env), capture_output=True, text=True)
     print(label)
