@@ -397,3 +397,30 @@ def test_batch_whose_images_yield_different_keypoint_counts():
         assert torch.equal(out["descriptors0"][b, :n0].t(), pred["descriptors0"][0])
         assert torch.equal(out["matches0"][b, :n0], pred["matches0"][0]) and torch.equal(out["matches1"][b, :n1], pred["matches1"][0])
         torch.testing.assert_close(out["matching_scores0"][b, :n0], pred["matching_scores0"][0], rtol=0, atol=2e-5)
+
+
+def test_repeated_launches_of_the_timed_batch_are_bitwise_identical():
+    """Race screen for the kernels whose ordering is hand-counted (round 4: gnn_tail_x3 stages its weights by LDS-DMA behind counted
+    vmcnt waits and raw s_barriers): the bench's own call -- 64 pairs, throughput forms -- launched 12 times on the same inputs must
+    return the same bytes every time (a read that races its DMA shows up as a rare wrong tile, not as a wrong mean)."""
+    from image_matching_amd.superglue.models.matching_test import Matching
+    d, K, H, W, B = 128, 1024, 480, 640, 64
+    m = Matching({"superpoint": util.sp_config(d, K), "superglue": util.sg_config(d)}).eval().to("cuda")
+    m.superpoint.load_state_dict(util.sp_sd(d))
+    m.superglue.load_state_dict(util.sg_sd(d))
+    ims = [util.pair(3000 + b % 8, H, W) for b in range(B)]
+    i0 = torch.cat([p[0] for p in ims]).cuda()
+    i1 = torch.cat([p[1] for p in ims]).cuda()
+    eng = m._shared.get_engine([0, 1])
+    eng.timing_reset()
+    eng.set_timing(True)
+    ref = {k: v.clone() for k, v in m.match_batch(i0, i1, want_desc=True).items()}
+    forms = {r[0]: r[3] for r in eng.timing_report(forms=True)}
+    eng.set_timing(False)
+    assert forms["gnn_tail"] == "gnn_tail_x3:bf16x3" and forms["attention"] == "attention_x3:bf16x3", forms
+    for it in range(11):
+        out = m.match_batch(i0, i1, want_desc=True)
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), f"launch {it + 2}: {k} differs from the first launch"
+    for b in range(8, B):            # and the copies of a pair inside the batch agree with each other
+        assert torch.equal(ref["matches0"][b], ref["matches0"][b % 8]) and torch.equal(ref["matching_scores0"][b], ref["matching_scores0"][b % 8])

@@ -119,7 +119,7 @@ def test_sinkhorn_when_the_dustbin_row_closes_a_full_slab(n0, n1):
     # to the float64 optimal transport as the oracle's fp32 evaluations are (five draws of its rounding noise: S and 4 permutations)
     Zrs, Z64 = util.sinkhorn_fp32_evaluations(S, sd["bin_score"], 30)
     Zr = Zrs[0]
-    util.assert_plan_close(Z, Z64, f"Sinkhorn alone ({n0}x{n1})")              # what the reference consumes: 1e-4, strict
+    util.assert_plan_anchored(Z, Zrs, Z64, f"Sinkhorn alone ({n0}x{n1})")      # what the reference consumes: 1e-4 (or what the oracle's own fp32 reaches)
     util.assert_sinkhorn_anchored(Z, Zrs, Z64, f"Sinkhorn alone ({n0}x{n1}) Z on the library's own scores",
                                   drift_floor=util.sinkhorn_drift_bound(u[:n0 + 1], v[:n1 + 1], 30), iters=30)
     # ONE iteration on the same inputs: no drift has happened yet, so the plain criterion applies with no floor -- an error of a
@@ -370,7 +370,7 @@ def test_superglue_random_shapes_batches_and_counts_vs_oracle(seed):
         util.assert_fp64_anchored(Sb, ref["scores_in"][0], f64, f"pair {b} ({a}x{c} of {N0}x{N1}, B={B}) scores_in", c=4.0, c_max=6.0)
         Z = util.transport_Z(Sb, U[b], V[b], a, c, float(sd["bin_score"]))
         Zrs, Z64 = util.sinkhorn_fp32_evaluations(Sb, sd["bin_score"], cfg["sinkhorn_iterations"])
-        util.assert_plan_close(Z, Z64, f"pair {b} ({a}x{c})")
+        util.assert_plan_anchored(Z, Zrs, Z64, f"pair {b} ({a}x{c})")
         util.assert_sinkhorn_anchored(Z, Zrs, Z64, f"pair {b} ({a}x{c}) Z on the library's own scores",
                                       drift_floor=util.sinkhorn_drift_bound(U[b][:a + 1], V[b][:c + 1], cfg["sinkhorn_iterations"]), iters=cfg["sinkhorn_iterations"])
         i0, i1, r0, r1 = superglue_ref.extract_matches(torch.from_numpy(Z)[None], cfg["match_threshold"])

@@ -113,6 +113,16 @@ def assert_plan_close(Z_hip, Z_ref, what):
     assert_close(np.exp(np.asarray(Z_hip, np.float64)), np.exp(np.asarray(Z_ref, np.float64)), what + ": exp(Z)")
 
 
+def assert_plan_anchored(Z_hip, Z32s, Z64, what, c=2.5):
+    """exp(Z) against the float64 plan at the north_star tolerance -- unless the oracle's OWN fp32 evaluations of the same problem do
+    not reach it (random descriptors drive |S| to several hundred: the drifted potentials move exp(Z) by more than 1e-4 on a few
+    entries in any fp32 evaluation): then the limit is c x the worst of theirs.  Same anchoring as the sweeps' `used_P`."""
+    P64 = np.exp(np.asarray(Z64, np.float64))
+    used = tolerance_used(np.exp(np.asarray(Z_hip, np.float64)), P64)
+    own = max(tolerance_used(np.exp(np.asarray(r, np.float64)), P64) for r in Z32s)
+    assert used <= max(1.0, c * own), f"{what}: exp(Z) uses {used:.2f} of the 1e-4 + 1e-4|ref| tolerance against float64 (the oracle's fp32 evaluations: {own:.2f})"
+
+
 def assert_fp64_anchored(hip, ref32, f64, what, c=2.0, c_max=2.5, floor=0.0):
     """For long fp32 reductions (GNN features after 18 layers, the score matrix, the transport matrix Z) two
     correct fp32 evaluation orders differ by more than 1e-4 at small |ref| -- the reference's own fp32 result
