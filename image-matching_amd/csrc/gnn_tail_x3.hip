@@ -54,7 +54,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&pl)[3]) {
 // next image have to be complete before the others may read them: lgkmcnt(0).
 // The weight images arrive by LDS-DMA (global_load_lds: no staging registers, no ds_write pass); such data is ordered for the readers
 // only by the ISSUING wave's counted vmcnt followed by a barrier.  VMEM operations retire in order, so vmcnt(N) with N = the loads
-// this wave issued AFTER the image's six DMA pieces and has not consumed yet (the activation prefetch of the next chunk: 4) retires
+// this wave issued AFTER the image's six DMA pieces and has not consumed yet (the activation prefetch: two chunks = 8 loads) retires
 // the image without draining that prefetch; lgkmcnt(0) retires this wave's LDS reads of the slot that is about to be refilled.
 #ifdef GT_TRACE
 __device__ long long gt_trace[64];
@@ -64,7 +64,7 @@ __device__ long long gt_trace[64];
 #endif
 template <int N>
 __device__ __forceinline__ void image_barrier() {
-  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -158,21 +158,22 @@ __global__ __launch_bounds__(512, 1) void gnn_tail_x3_kernel(GnnTailArgs p) {
     // ---- mlp.0', hidden channels 128 half .. +127: 4 images = 16 k-steps = 8 chunks of 32 k
     f32x16 acc1[4];
     bias_init(acc1, D * half);
-    f32x4 actA[4], actB[4];
-    act_load(0, actA);
+    f32x4 act[3][4];                                       // ring of three chunks: loaded TWO chunks (four k-steps) ahead
+    act_load(0, act[0]);
+    act_load(1, act[1]);
 #pragma unroll
     for (int i = 0; i < 4; ++i, ++img) {
       GT_STAMP(2 * img);
-      if (img > 0) { if (i == 0) image_barrier<0>(); else image_barrier<4>(); }      // image `img` is in its slot (its DMA was issued an image ago); the other slot is free
+      // image `img` is in its slot (its DMA was issued an image ago); the other slot is free.  Younger than that DMA and possibly still
+      // in flight: the two chunks prefetched since (8 loads) -- none after the last image of a half
+      if (img > 0) image_barrier<8>();
       GT_STAMP(2 * img + 1);
       if (img + 1 < NIMG) fetch(img + 1);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int s = 4 * i + t, c = s >> 1;
-        if ((s & 1) == 0 && c + 1 < 8) {                  // the next chunk, one chunk ahead
-          if (c & 1) act_load(c + 1, actA); else act_load(c + 1, actB);
-        }
-        const f32x4 (&cur)[4] = (c & 1) ? actB : actA;
+        if ((s & 1) == 0 && c + 2 < 8) act_load(c + 2, act[(c + 2) % 3]);
+        const f32x4 (&cur)[4] = act[c % 3];
         const f32x4 lo = cur[2 * (s & 1)], hi4 = cur[2 * (s & 1) + 1];
         const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
         bf16x8 bp[3];
@@ -223,6 +224,16 @@ __global__ __launch_bounds__(512, 1) void gnn_tail_x3_kernel(GnnTailArgs p) {
       acc2[blk][4 * g] = v[0]; acc2[blk][4 * g + 1] = v[1]; acc2[blk][4 * g + 2] = v[2]; acc2[blk][4 * g + 3] = v[3];
     }
   }
+  bf16x8 xp[8][3];                     // x' as the B operands of the next product's k-steps (ob, h2): split once, used by every pass
+#pragma unroll
+  for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = acc2[ob][8 * h2 + j];
+      split8(v, xp[2 * ob + h2]);
+    }
   // ---- the next product: NPASS passes of 128 output channels, 2 images each
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
@@ -239,14 +250,7 @@ __global__ __launch_bounds__(512, 1) void gnn_tail_x3_kernel(GnnTailArgs p) {
       if (img + 1 < NIMG) fetch(img + 1);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        // k-step (ob, h2) of x': split again in every pass (keeping the 8 x 3 planes would be 96 registers: spills; +450 VALU per wave)
-        const int ob = 2 * i + t / 2, h2 = t & 1;
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = acc2[ob][8 * h2 + j];
-        bf16x8 bp[3];
-        split8(v, bp);
-        step24(img, t, bp, acc3);
+        step24(img, t, xp[4 * i + t], acc3);
       }
     }
     if (pass == NPASS - 1) GT_STAMP(36);
