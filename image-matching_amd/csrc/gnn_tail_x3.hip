@@ -58,51 +58,73 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&pl)[3]) {
 // the image without draining that prefetch; lgkmcnt(0) retires this wave's LDS reads of the slot that is about to be refilled.
 #ifdef GT_TRACE
 __device__ long long gt_trace[64];
-#define GT_STAMP(k) do { if (blockIdx.x == 300 && threadIdx.x == 64) gt_trace[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GT_STAMP(k) do { if (blockIdx.x == 300 && threadIdx.x == 64 && (k) < 64) gt_trace[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define GT_STAMP(k) do { } while (0)
 #endif
-template <int N>
-__device__ __forceinline__ void image_barrier() {
-  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+// n = 0, 4, 8 or 16 (compile-time constants after unrolling); exactly one s_barrier is executed whatever n is
+__device__ __forceinline__ void image_barrier(int n) {
+  if (n >= 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else if (n >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else if (n >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int NPASS>
-__global__ __launch_bounds__(512, 1) void gnn_tail_x3_kernel(GnnTailArgs p) {
+// NW waves per workgroup: 8 = one workgroup of 256 rows per CU and 48-KB weight images (4 k-steps); 4 = TWO workgroups of 128 rows per CU
+// and 24-KB images (2 k-steps).  Two waves share a SIMD either way.  Measured (tools/ubench/gnn_tail_bench.cpp, -DGT_NW8): the same at
+// 131072 rows (255 vs 256 us: a SIMD's time is the sum of its waves' MFMA and VALU issue whichever way they are grouped),
+// NW = 4 ahead where workgroups are scarce (8224 rows: 40 vs 60 us; three gemm_x3 launches: 50) -- the library launches NW = 4.
+template <int NPASS, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void gnn_tail_x3_kernel(GnnTailArgs p) {
   constexpr int D = 128;
-  constexpr int NIMG = 12 + 2 * NPASS;
-  extern __shared__ __attribute__((aligned(16))) u32x4 ring[];       // [2][GT_SLOT] weight images, then the biases (2 D + D + NPASS D floats)
-  float* lbias = reinterpret_cast<float*>(ring + 2 * GT_SLOT);
+  constexpr int SPI = NW / 2;                              // k-steps per weight image (12 KB each: 4 blocks x 3 planes x 1 KB)
+  constexpr int SLOT = SPI * 768;                          // 16-byte elements per image
+  constexpr int NT = 64 * NW;
+  constexpr int NSTEP = 2 * (16 + 8) + 8 * NPASS;          // k-steps of the whole tail
+  constexpr int NIMG = NSTEP / SPI;
+  extern __shared__ __attribute__((aligned(16))) u32x4 ring[];       // [2][SLOT] weight images, the biases (2 D + D + NPASS D floats), the transpose tiles
+  float* lbias = reinterpret_cast<float*>(ring + 2 * SLOT);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-  const int row0 = blockIdx.x * 256 + 32 * wave;
+  const int row0 = blockIdx.x * (32 * NW) + 32 * wave;
   float* stage = lbias + (3 + NPASS) * D + wave * (32 * GT_STAGE_RS);      // this wave's 32 x 32 transpose tile (row stride 36 floats: conflict-free 16-byte accesses)
   const bool active = row0 < p.M;                                    // waves past M (a multiple of 32) compute on a clamped row and store nothing
   const int row = min(row0 + l31, p.M - 1);
   const u32x4* stream = reinterpret_cast<const u32x4*>(p.stream);
 
-  // ---- the weight stream: image i -> ring slot i & 1 by LDS-DMA, one image ahead (wave w copies 16-byte elements j * 512 + 64 w + lane)
+  // ---- the weight stream: image i -> ring slot i & 1 by LDS-DMA, one image ahead (six pieces per thread: 16-byte elements j * NT + tid)
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
+  int pend = 0;      // VMEM operations issued after the newest image's DMA pieces that may still be in flight at the next barrier
   auto fetch = [&](int i) __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);            // the order of VMEM operations around the DMA pieces is what image_barrier counts on
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
-      __builtin_amdgcn_global_load_lds((glb_void*)(stream + (size_t)i * GT_SLOT + j * 512 + tid),
-                                       (lds_void*)(ring + (i & 1) * GT_SLOT + j * 512 + 64 * wave), 16, 0, 0);
+    for (int j = 0; j < SLOT / NT; ++j)
+      __builtin_amdgcn_global_load_lds((glb_void*)(stream + (size_t)i * SLOT + j * NT + tid),
+                                       (lds_void*)(ring + (i & 1) * SLOT + j * NT + 64 * wave), 16, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    pend = 0;
+  };
+  // global k-step gs: at the first step of an image the workgroup meets (image gs / SPI is in its slot: its DMA was issued an image ago;
+  // the other slot is free) and the next image is requested
+  auto enter_step = [&](int gs) __attribute__((always_inline)) {
+    if (gs % SPI) return;
+    const int img = gs / SPI;
+    GT_STAMP(2 * img);
+    if (img > 0) image_barrier(active ? pend : 0);
+    GT_STAMP(2 * img + 1);
+    if (img + 1 < NIMG) fetch(img + 1);
   };
   // one k-step: 24 MFMAs.  The A operands (four output blocks x three planes from the image) are read two blocks at a time -- 24
   // registers instead of 48 -- and the two blocks' MFMAs alternate, so consecutive MFMAs never share an accumulator.
-  auto step24 = [&](int i, int t, const bf16x8 (&b)[3], f32x16 (&acc)[4]) __attribute__((always_inline)) {
+  auto step24 = [&](int gs, const bf16x8 (&b)[3], f32x16 (&acc)[4]) __attribute__((always_inline)) {
+    const int i = gs / SPI, t = gs % SPI;
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
       bf16x8 a[2][3];
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) a[e][q] = __builtin_bit_cast(bf16x8, ring[(i & 1) * GT_SLOT + ((t * 4 + 2 * pr + e) * 3 + q) * 64 + lane]);
+        for (int q = 0; q < 3; ++q) a[e][q] = __builtin_bit_cast(bf16x8, ring[(i & 1) * SLOT + ((t * 4 + 2 * pr + e) * 3 + q) * 64 + lane]);
 #pragma unroll
       for (int q = 0; q < 6; ++q)
 #pragma unroll
@@ -128,6 +150,7 @@ __global__ __launch_bounds__(512, 1) void gnn_tail_x3_kernel(GnnTailArgs p) {
     const float* src = (c < 4 ? xrow : arow) + 32 * (c & 3) + 16 * hi;
 #pragma unroll
     for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(src + 4 * q);
+    pend += 4;
   };
 
   // A 32-channel block of a transposed result -> 32 rows x 128 bytes of a row-major tensor, through this wave's LDS tile: a lane's
@@ -148,56 +171,42 @@ __global__ __launch_bounds__(512, 1) void gnn_tail_x3_kernel(GnnTailArgs p) {
   };
 
   fetch(0);
-  for (int e = tid; e < (3 + NPASS) * D; e += 512) lbias[e] = e < 2 * D ? p.b1[e] : e < 3 * D ? p.b2[e - 2 * D] : p.b3[e - 3 * D];
+  for (int e = tid; e < (3 + NPASS) * D; e += NT) lbias[e] = e < 2 * D ? p.b1[e] : e < 3 * D ? p.b2[e - 2 * D] : p.b3[e - 3 * D];
   __syncthreads();                     // (a full fence: the biases, and image 0)
   f32x16 acc2[4];                      // x' (mlp.3's output, transposed)
   bias_init(acc2, 2 * D);
-  int img = 0;
+  int gs = 0;                          // global k-step (a compile-time constant at every use: all loops are unrolled)
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    // ---- mlp.0', hidden channels 128 half .. +127: 4 images = 16 k-steps = 8 chunks of 32 k
+    // ---- mlp.0', hidden channels 128 half .. +127: 16 k-steps = 8 chunks of 32 k
     f32x16 acc1[4];
     bias_init(acc1, D * half);
     f32x4 act[3][4];                                       // ring of three chunks: loaded TWO chunks (four k-steps) ahead
     act_load(0, act[0]);
     act_load(1, act[1]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i, ++img) {
-      GT_STAMP(2 * img);
-      // image `img` is in its slot (its DMA was issued an image ago); the other slot is free.  Younger than that DMA and possibly still
-      // in flight: the two chunks prefetched since (8 loads) -- none after the last image of a half
-      if (img > 0) image_barrier<8>();
-      GT_STAMP(2 * img + 1);
-      if (img + 1 < NIMG) fetch(img + 1);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int s = 4 * i + t, c = s >> 1;
-        if ((s & 1) == 0 && c + 2 < 8) act_load(c + 2, act[(c + 2) % 3]);
-        const f32x4 (&cur)[4] = act[c % 3];
-        const f32x4 lo = cur[2 * (s & 1)], hi4 = cur[2 * (s & 1) + 1];
-        const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-        bf16x8 bp[3];
-        split8(v, bp);
-        step24(img, t, bp, acc1);
-      }
+    for (int s = 0; s < 16; ++s, ++gs) {
+      enter_step(gs);
+      const int c = s >> 1;
+      if ((s & 1) == 0 && c + 2 < 8) act_load(c + 2, act[(c + 2) % 3]);
+      const f32x4 (&cur)[4] = act[c % 3];
+      const f32x4 lo = cur[2 * (s & 1)], hi4 = cur[2 * (s & 1) + 1];
+      const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+      bf16x8 bp[3];
+      split8(v, bp);
+      step24(gs, bp, acc1);
     }
-    // ---- mlp.3 over this half's hidden channels: 2 images, k-steps (b, h2) with the B operand straight from acc1 (ReLU here)
+    // ---- mlp.3 over this half's hidden channels: k-steps (b, h2) with the B operand straight from acc1 (ReLU here)
 #pragma unroll
-    for (int i = 0; i < 2; ++i, ++img) {
-      GT_STAMP(2 * img);
-      image_barrier<0>();
-      GT_STAMP(2 * img + 1);
-      if (img + 1 < NIMG) fetch(img + 1);
+    for (int s = 0; s < 8; ++s, ++gs) {
+      enter_step(gs);
+      const int b = s / 2, h2 = s & 1;
+      float v[8];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int b = 2 * i + t / 2, h2 = t & 1;
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc1[b][8 * h2 + j], 0.f);
-        bf16x8 bp[3];
-        split8(v, bp);
-        step24(img, t, bp, acc2);
-      }
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc1[b][8 * h2 + j], 0.f);
+      bf16x8 bp[3];
+      split8(v, bp);
+      step24(gs, bp, acc2);
     }
   }
   // ---- x' = x + (hidden W2 + b2): through the transpose tile, where a lane sees 16 contiguous bytes of a row -- the residual is read
@@ -224,6 +233,7 @@ __global__ __launch_bounds__(512, 1) void gnn_tail_x3_kernel(GnnTailArgs p) {
       acc2[blk][4 * g] = v[0]; acc2[blk][4 * g + 1] = v[1]; acc2[blk][4 * g + 2] = v[2]; acc2[blk][4 * g + 3] = v[3];
     }
   }
+  pend = 16;                           // the sixteen stores of x' (their loads are older and were consumed)
   bf16x8 xp[8][3];                     // x' as the B operands of the next product's k-steps (ob, h2): split once, used by every pass
 #pragma unroll
   for (int ob = 0; ob < 4; ++ob)
@@ -234,30 +244,23 @@ __global__ __launch_bounds__(512, 1) void gnn_tail_x3_kernel(GnnTailArgs p) {
       for (int j = 0; j < 8; ++j) v[j] = acc2[ob][8 * h2 + j];
       split8(v, xp[2 * ob + h2]);
     }
-  // ---- the next product: NPASS passes of 128 output channels, 2 images each
+  // ---- the next product: NPASS passes of 128 output channels, 8 k-steps each
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
     __builtin_amdgcn_sched_barrier(0);           // (keeps the next pass's accumulators from being initialised before this pass's are stored: registers)
     f32x16 acc3[4];
     bias_init(acc3, 3 * D + D * pass);
 #pragma unroll
-    for (int i = 0; i < 2; ++i, ++img) {
-      GT_STAMP(2 * img);
-      // the first image of a pass follows a burst of 16 stores (x', or the previous pass's output) issued AFTER its DMA pieces: they may
-      // stay in flight (a wave without rows issued none)
-      if (i == 0 && active) image_barrier<16>(); else image_barrier<0>();
-      GT_STAMP(2 * img + 1);
-      if (img + 1 < NIMG) fetch(img + 1);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        step24(img, t, xp[4 * i + t], acc3);
-      }
+    for (int s = 0; s < 8; ++s, ++gs) {
+      enter_step(gs);
+      step24(gs, xp[s], acc3);
     }
-    if (pass == NPASS - 1) GT_STAMP(36);
+    if (pass == NPASS - 1) GT_STAMP(2 * NIMG);
     if (active) {
 #pragma unroll
       for (int blk = 0; blk < 4; ++blk) store_block(acc3[blk], p.out, p.n3, D * pass + 32 * blk);
     }
+    pend = 16;
   }
 }
 
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(512, 1) void gnn_tail_x3_kernel(GnnTailArgs p) {
 void gnn_tail_trace_dump() {
   long long t[64];
   hipMemcpyFromSymbol(t, HIP_SYMBOL(gt_trace), sizeof(t));
-  for (int i = 0; i < 18; ++i) printf("image %2d: barrier wait %6lld   body %6lld\n", i, t[2 * i + 1] - t[2 * i], (i < 17 ? t[2 * i + 2] : t[36]) - t[2 * i + 1]);
+  for (int i = 0; i < 18; ++i) printf("image %2d: barrier wait %6lld   body %6lld\n", i, t[2 * i + 1] - t[2 * i], t[2 * i + 2] - t[2 * i + 1]);
 }
 #endif
 
@@ -277,17 +280,18 @@ bool gnn_tail_x3_supported(const GnnTailArgs& a) {
 
 hipError_t launch_gnn_tail_x3(const GnnTailArgs& a, hipStream_t s) {
   if (!gnn_tail_x3_supported(a)) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)((a.M + 255) / 256));
-  const size_t lds = 2 * (size_t)GT_IMAGE_BYTES + (size_t)(3 * a.d + a.n3 + 8 * 32 * GT_STAGE_RS) * sizeof(float);
-  static unsigned long long attr3 = 0, attr1 = 0;
   last_form = "gnn_tail_x3:bf16x3";
-  if (a.n3 == 384) {
-    raise_lds_limit(reinterpret_cast<const void*>(gnn_tail_x3_kernel<3>), (int)lds, attr3);
-    hipLaunchKernelGGL((gnn_tail_x3_kernel<3>), grid, dim3(512), lds, s, a);
-  } else {
-    raise_lds_limit(reinterpret_cast<const void*>(gnn_tail_x3_kernel<1>), (int)lds, attr1);
-    hipLaunchKernelGGL((gnn_tail_x3_kernel<1>), grid, dim3(512), lds, s, a);
-  }
+  static unsigned long long attr[4] = {0, 0, 0, 0};
+  auto go = [&](auto kern, int nw, int which) {
+    const size_t lds = 2 * (size_t)(nw / 2) * 12288 + (size_t)(3 * a.d + a.n3 + nw * 32 * GT_STAGE_RS) * sizeof(float);
+    raise_lds_limit(reinterpret_cast<const void*>(kern), (int)lds, attr[which]);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + 32 * nw - 1) / (32 * nw))), dim3(64 * nw), lds, s, a);
+  };
+#ifdef GT_NW8
+  if (a.n3 == 384) go(gnn_tail_x3_kernel<3, 8>, 8, 0); else go(gnn_tail_x3_kernel<1, 8>, 8, 1);
+#else
+  if (a.n3 == 384) go(gnn_tail_x3_kernel<3, 4>, 4, 2); else go(gnn_tail_x3_kernel<1, 4>, 4, 3);
+#endif
   return hipGetLastError();
 }
 

@@ -810,12 +810,12 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     const bool last = l + 1 == h->layers.size();
     const GemmW& nx = last ? h->final_proj : h->layers[l + 1].qkv;
     GnnSmallArgs ga{x, att, L.mlp1.wf, L.mlp1.b, L.mlp2.wf, L.mlp2.b, nx.wf, nx.b, last ? mdesc : qkv, R, d, nx.N};
-    // Throughput form: the same three products in one launch on the bf16 pipe (gnn_tail_x3.hip).  "gnn_tail" = auto takes it from
-    // 32768 rows (16 pairs of 1024 keypoints: below that a workgroup's 256 rows leave CUs idle and three gemm_x3 launches are faster)
-    // and ALWAYS under "latency_forms" = off, whose contract is that results do not depend on the batch size.
+    // Throughput form: the same three products in one launch on the bf16 pipe (gnn_tail_x3.hip): "gnn_tail" = auto takes it whenever the
+    // latency forms do not apply (M > 4096 rows; measured against three gemm_x3 launches: 40 vs 50 us at 8224 rows, 65 vs 86 at 32768,
+    // 256 vs 300 at 131072) -- so results do not depend on the batch size under "latency_forms" = off.
     GnnTailArgs ta{x, att, L.tail_stream, L.mlp1.b, L.mlp2.b, nx.b, last ? mdesc : qkv, R, d, nx.N};
     const bool tail_ok = !small_form && !h->opt.mfma_f32 && L.tail_stream && nx.Npad == nx.N && gnn_tail_x3_supported(ta);
-    const bool tail = tail_ok && (h->opt.gnn_tail == 1 || (h->opt.gnn_tail < 0 && (h->opt.latency_forms == 0 || R >= 32768)));
+    const bool tail = tail_ok && h->opt.gnn_tail != 0;
     if (small_form && h->opt.latency_forms != 2 && L.mlp1.Npad == 2 * d && L.mlp2.Npad == d && nx.Npad == nx.N && gnn_layer_small_supported(ga)) {
       RUN("gnn_layer", launch_gnn_layer_small(ga, s));
       have_next = !last;

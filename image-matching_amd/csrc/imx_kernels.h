@@ -15,8 +15,8 @@ struct Options {
   int latency_forms = -1;  // "latency_forms": -1 = "auto" (gemm_small for M <= 4096 rows, key-split attention for grids of
                            //         <= 256 workgroups, one launch per GNN layer tail), 0 = "off" (results do not depend on the batch size
                            //         bit for bit), 1 = "on", 2 = "unfused" (on, with the layer tail as three gemm_small launches: the A/B of the fusion)
-  int gnn_tail = -1;       // "gnn_tail": -1 = "auto" (the fused layer tail gnn_tail_x3 from 32768 rows, and always under latency_forms = off),
-                           //         0 = "unfused" (three gemm_x3 launches: the A/B of the fusion), 1 = "fused" (whenever the shape allows)
+  int gnn_tail = -1;       // "gnn_tail": -1 = "auto" = 1 = "fused" (the fused layer tail gnn_tail_x3 wherever the throughput forms run, d = 128),
+                           //         0 = "unfused" (three gemm_x3 launches: the A/B of the fusion)
   int conv_direct = 0;     // "conv": 0 = "wino" (Winograd F(2x4,3x3) on the fp32 MFMA; direct only for shapes it rejects), 1 = "direct"
 };
 

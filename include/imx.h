@@ -221,10 +221,9 @@ const char* imx_timing_form(imx_handle_t h, int index);
  *                           launches instead of one (same bytes: the A/B reference of the fused latency kernel);
  *   "conv"           "wino" (default) Winograd F(2x4,3x3) on the fp32 MFMA; "direct" the direct implicit-GEMM kernel for every 3x3
  *                           layer (the fallback for shapes Winograd rejects, and the A/B reference);
- *   "gnn_tail"       "auto" (default) from 32768 feature rows (16 pairs of 1024 keypoints) the tail of a GNN layer (mlp.0 -> mlp.3 +
- *                           residual -> the next layer's q|k|v or final_proj) is ONE launch on the bf16 pipe (descriptor_dim 128), and
- *                           always under "latency_forms" = "off" (batch-size independent results); "unfused" three launches (the A/B
- *                           reference); "fused" whenever the shape allows.
+ *   "gnn_tail"       "auto" (default) = "fused": wherever the throughput forms run (more than 4096 feature rows) the tail of a GNN layer
+ *                           (mlp.0 -> mlp.3 + residual -> the next layer's q|k|v or final_proj) is ONE launch on the bf16 pipe
+ *                           (descriptor_dim 128); "unfused" three launches (the A/B reference: same products, another summation order).
  * Unknown keys / values are an error.  imx_get_option returns the current value ("" for an unknown key); the pointer is valid
  * until the next call on the handle. */
 int imx_set_option(imx_handle_t h, const char* key, const char* value);
