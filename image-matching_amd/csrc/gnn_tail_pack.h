@@ -1,5 +1,6 @@
 // gnn_tail_pack.h -- host side of gnn_tail_x3.hip: the weights of one GNN layer tail (mlp.0' -> ReLU -> mlp.3 + residual -> the next
-// layer's q|k|v, or final_proj) as ONE stream of 48-KB LDS images, in the order the kernel consumes them.
+// layer's q|k|v, or final_proj) as ONE stream of LDS images, in the order the kernel consumes them (the kernel reads it as images of
+// two k-steps = 24 KB, or of four = 48 KB with 8-wave workgroups: the stream is step-major, so both views are the same bytes).
 //
 // Every product of the kernel is TRANSPOSED: D[channel][row] = sum_k W^T[channel][k] . act^T[k][row] on v_mfma_f32_32x32x16_bf16, the
 // weights as the A operand (lane (c, kb) holds eight k values of output channel c), the activations as the B operand (lane (row, kb)

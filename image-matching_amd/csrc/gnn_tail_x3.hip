@@ -15,10 +15,13 @@
 //     and x' stay in the registers of the wave: no LDS staging, no barrier, no HBM round trip for them;
 //   * the first product's B operand is loaded straight from global memory (a lane reads 64 contiguous bytes of its row per 32-k
 //     chunk) and split in registers (split3.h);
-//   * the only thing in LDS is the weight stream: 48-KB images (4 k-steps x 4 output blocks x 3 planes) in a ring of two, copied by
-//     all 512 threads one image ahead, ONE barrier per image (96 MFMAs per wave); eight waves share every image;
+//   * the only thing in LDS is the weight stream: images of 2 k-steps x 4 output blocks x 3 planes (24 KB; gnn_tail_pack.h writes them
+//     in consumption order) in a ring of two, copied by LDS-DMA one image ahead (global_load_lds: no staging registers, no ds_write
+//     pass), ONE barrier per image (48 MFMAs per wave) behind a COUNTED vmcnt; the four waves of a workgroup share every image;
 //   * mlp.0's 256 hidden channels are produced in two halves (64 accumulator registers each), each half consumed by mlp.3 right away
-//     (the first product's activations are read and split twice: +7 % VALU work, -64 registers).
+//     (the first product's activations are read and split twice: +7 % VALU work, -64 registers);
+//   * results and the residual go through a per-wave 32 x 32 transpose tile in LDS, so that every global access is a full 128-byte
+//     row segment.
 // Work per wave and 32 rows: 768 + 384 + 576 MFMAs (q|k|v) against ~1700 VALU instructions.
 #include "imx_kernels.h"
 #include "split3.h"
