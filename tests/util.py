@@ -69,6 +69,11 @@ def sinkhorn_drift_bound(u, v, iters):
     return iters * float(np.spacing(np.float32(top)))
 
 
+def _ratio(a, b):
+    """a / b for the diagnostic prints; a zero envelope (a 1x1 pair: the oracle's evaluations can agree with float64 to the bit) prints inf."""
+    return float(a) / float(b) if b else float("inf") if a else 1.0
+
+
 def additive_part(e):
     """The part of an error field e(i, j) of Z that is a row constant plus a column constant, e_u(i) + e_v(j) -- what an error of the
     Sinkhorn potentials u, v looks like in Z = S + u + v - norm -- by two-way means (least squares)."""
@@ -97,7 +102,7 @@ def assert_sinkhorn_anchored(Z, Z32s, Z64, what, drift_floor, iters=None, c=2.0,
     env_rem_max, env_rem_rms = max(np.abs(x).max() for x in rr), max(rms(x) for x in rr)
     env_add_max = max(np.abs(x).max() for x in ra)
     print(f"[sinkhorn-anchored] {what}: non-additive error max {np.abs(rh).max():.2e} rms {rms(rh):.2e} vs the oracle's fp32 envelope {env_rem_max:.2e} / {env_rem_rms:.2e} "
-          f"(x{np.abs(rh).max() / env_rem_max:.2f} / x{rms(rh) / env_rem_rms:.2f}); additive (potential) error max {np.abs(ah).max():.2e} vs the oracle's {env_add_max:.2e}, drift bound {drift_floor:.2e}")
+          f"(x{_ratio(np.abs(rh).max(), env_rem_max):.2f} / x{_ratio(rms(rh), env_rem_rms):.2f}); additive (potential) error max {np.abs(ah).max():.2e} vs the oracle's {env_add_max:.2e}, drift bound {drift_floor:.2e}")
     # one spacing at the potentials' magnitude = ONE rounding of the adds that assemble Z = (S + u) + v - norm: drifted potentials round
     # differently there, so two evaluations legitimately differ by it entry by entry; on a tiny problem (2x17: 54 entries) five draws
     # of the oracle do not sample that maximum, hence the explicit term.  It is 1/iterations of the drift bound -- no hiding place.
@@ -143,8 +148,8 @@ def assert_fp64_anchored(hip, ref32, f64, what, c=2.0, c_max=2.5, floor=0.0):
     mh, rh = eh.max(), np.sqrt((eh ** 2).mean())
     mr = max(np.abs(r - f64).max() for r in refs)
     rr = max(np.sqrt(((r - f64) ** 2).mean()) for r in refs)
-    print(f"[fp64-anchored] {what}: max err hip {mh:.3e} vs reference-fp32 {mr:.3e} (x{mh / mr:.2f}); "
-          f"rms hip {rh:.3e} vs {rr:.3e} (x{rh / rr:.2f}); max|f64| {np.abs(f64).max():.1f}; "
+    print(f"[fp64-anchored] {what}: max err hip {mh:.3e} vs reference-fp32 {mr:.3e} (x{_ratio(mh, mr):.2f}); "
+          f"rms hip {rh:.3e} vs {rr:.3e} (x{_ratio(rh, rr):.2f}); max|f64| {np.abs(f64).max():.1f}; "
           f"outside 1e-4+1e-4|ref|: hip-vs-reference {outside_fraction(hip, refs[0]):.2e}, hip-vs-f64 {outside_fraction(hip, f64):.2e}, "
           f"reference-vs-f64 {outside_fraction(refs[0], f64):.2e}" + (f" (envelope over {len(refs)} fp32 evaluations)" if len(refs) > 1 else ""))
     # the floor is a per-ENTRY worst case (iterations x spacing): it bounds the maximum only -- as an rms limit it would be ~100x the
@@ -152,7 +157,7 @@ def assert_fp64_anchored(hip, ref32, f64, what, c=2.0, c_max=2.5, floor=0.0):
     assert rh <= c * rr and mh <= max(c_max * mr, floor), \
         (f"{what}: HIP is further from the float64 evaluation than {c}x (rms) / {c_max}x (max) the reference's own fp32 result"
          f"{f' and than the fp32 drift bound {floor:.2e}' if floor else ''}: max {mh:.3e} vs {mr:.3e}, rms {rh:.3e} vs {rr:.3e}")
-    return mh / mr, rh / rr
+    return _ratio(mh, mr), _ratio(rh, rr)
 
 
 def sinkhorn_fp32_evaluations(S, alpha, iters, n_perm=4, seed=0):
