@@ -431,7 +431,11 @@ def c2_leg(matching, img01, steps):
 
 
 PIPES = {"f32": ("fp32 MFMA", PEAK_MFMA_F32_TFLOPS, 1.0),
-         "bf16x3": ("bf16 MFMA, six bf16 term products per fp32 product", PEAK_MFMA_BF16_TFLOPS, 6.0)}
+         "bf16x3": ("bf16 MFMA, six bf16 term products per fp32 product", PEAK_MFMA_BF16_TFLOPS, 6.0),
+         # attention_x3.hip's two-plane fp16 form: operands as h + m in fp16 (22 bits), products (h,h) (h,m) (m,h); the fp16 MFMA's dense
+         # peak is the bf16 one's
+         "f16x2": ("fp16 MFMA, three fp16 term products per fp32 product", PEAK_MFMA_BF16_TFLOPS, 3.0)}
+SPLIT_PIPES = ("bf16x3", "f16x2")
 
 
 def roofline_block(rows, wl, B, steps, dt, lib_build, workload):
@@ -493,7 +497,7 @@ def roofline_block(rows, wl, B, steps, dt, lib_build, workload):
         rf["traffic_note"] = traffic_note
     if bound == "mfma":
         rf["pipe"] = PIPES.get(pipe_of[name], PIPES["f32"])[0]
-    if abs(algorithmic - achieved) > 1e-9 and pipe_of[name] != "bf16x3":
+    if abs(algorithmic - achieved) > 1e-9 and pipe_of[name] not in SPLIT_PIPES:
         rf["algorithmic"] = {
             "rate": round(algorithmic, 3), "ratio_to_peak": round(algorithmic / peak, 4),
             "note": "reference direct-form FLOPs / launch time; the kernel executes fewer multiplies (Winograd F(2x4,3x3)), "
@@ -507,6 +511,7 @@ def roofline_block(rows, wl, B, steps, dt, lib_build, workload):
     rf["executed_pair_frac"] = round(at_peak_s / step_s, 4)
     rf["fp32_equivalent_pair_tflops"] = round(exe_step / step_s / 1e12, 2)
     rf["bf16x3_kernels"] = sorted(k for k, v in pipe_of.items() if v == "bf16x3")
+    rf["f16x2_kernels"] = sorted(k for k, v in pipe_of.items() if v == "f16x2")
     rf["algorithmic_pair_ratio"] = round(alg_step / step_s / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)
     rf["timed_groups_per_step"] = int(round(sum(per_step.values())))      # one group = one RUN() of imx_api.cpp (the Sinkhorn group holds 60 kernel launches)
     kern = {}
@@ -516,7 +521,7 @@ def roofline_block(rows, wl, B, steps, dt, lib_build, workload):
             k["form"] = form_of[n] if len(forms) == 1 else sorted(forms)
         if n in exe:
             k["executed_frac"] = round(pipe_flops(n) / (ms / launches * 1e-3) / 1e12 / pipe_peak(n), 4)
-            if pipe_of[n] == "bf16x3":
+            if pipe_of[n] in SPLIT_PIPES:
                 k["fp32_equivalent_tflops"] = round(exe[n] / (ms / launches * 1e-3) / 1e12, 2)
         elif n in work:
             k["hbm_frac"] = round(work[n][1] / (ms / launches * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
@@ -529,9 +534,12 @@ def roofline_block(rows, wl, B, steps, dt, lib_build, workload):
 
 def arithmetic_text(rf):
     x3 = rf.get("bf16x3_kernels", []) if rf else []
+    h2 = rf.get("f16x2_kernels", []) if rf else []
     return ("fp32 in, fp32 accumulate, fp32 out everywhere.  On the fp32 MFMA: the 3x3 convolutions (Winograd F(2x4,3x3)) and score_gemm.  "
             + (f"On the bf16 MFMA, each fp32 product carried as six bf16 term products (x = h + m + l exactly; error vs float64 below the "
                f"fp32 MFMA's: profiles/r02_mfma_bf16x3.txt), as reported by the library for this run: {', '.join(x3)}.  " if x3 else "")
+            + (f"On the fp16 MFMA, each fp32 product carried as three fp16 term products of two-plane operands (x s = h + m, 22 bits, s a power of two "
+               f"from the tensor's maximum; error vs float64 below the fp32 MFMA's: tools/ubench/attn_x3_bench.cpp): {', '.join(h2)}.  " if h2 else "")
             + "imx_set_option(h, 'mfma', 'f32') keeps every product on the fp32 MFMA (the parity tests hold both to the same bar).  "
               "On these default (heavy-tailed) weights |Z_hip - Z_reference| reaches ~1e-3 where the reference's own fp32 result is 2e-4..3e-3 from float64 "
               "(parity_in_run: match indices differ only on reference margins below that noise); on the trained-model-like weight set every element of "

@@ -467,6 +467,14 @@ __global__ __launch_bounds__(64 * NW) void attention_split_kernel(AttnArgs p, fl
 
 }  // namespace
 
+// the form choice of launch_attention, for callers that prepare something form-specific (the q / k / v maxima of the two-plane fp16 form)
+static bool attention_splits_keys(const AttnArgs& a) {
+  const int nmax = a.N0p > a.N1p ? a.N0p : a.N1p;
+  const long wgs = (long)((nmax + 127) / 128) * a.heads * 2 * a.B;
+  return a.latency_forms >= 0 ? a.latency_forms != 0 : (wgs <= 256 && nmax >= 256);
+}
+bool attention_takes_x3(const AttnArgs& a) { return !attention_splits_keys(a) && !a.mfma_f32 && attention_x3_supported(a); }
+
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   const int hd = a.d / a.heads;
   const int nmax = a.N0p > a.N1p ? a.N0p : a.N1p;
@@ -474,12 +482,12 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   const float scale = (float)(1.4426950408889634 / sqrt((double)hd));   // log2(e)/sqrt(HD)
   // Three forms, each with its reason:
   //   attention_split  small grids (one to four pairs): 32-query workgroups whose waves split the KEYS -- latency;
-  //   attention_x3     head dim 32 / 64, the throughput form: both products as six bf16 term products on the bf16 matrix pipe;
+  //   attention_x3     head dim 32 / 64, the throughput form: both products on the 16-bit matrix pipe -- as three fp16 term products of
+  //                    two-plane operands when the caller passes the q / k / v maxima (AttnArgs::amax), else six bf16 term products;
   //   attention_kernel fp32 MFMA: head dim 16 (descriptor_dim 64) and the "mfma" = "f32" A/B reference of the parity tests.
   // "latency_forms" = "off" keeps the throughput form for every batch size (then results do not depend on the batch size bit
   // for bit), "on" forces the key-split form.
-  const long wgs = (long)grid.x * grid.y * grid.z;
-  const bool split = a.latency_forms >= 0 ? a.latency_forms != 0 : (wgs <= 256 && nmax >= 256);
+  const bool split = attention_splits_keys(a);
   if (split) {
     dim3 sgrid((unsigned)((nmax + 31) / 32), (unsigned)a.heads, (unsigned)(2 * a.B));
     auto launch = [&](auto kern, int hdv, int nw) {

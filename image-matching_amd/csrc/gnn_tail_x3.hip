@@ -93,6 +93,20 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gnn_tail_x3_kernel(GnnTailArg
   const bool active = row0 < p.M;                                    // waves past M (a multiple of 32) compute on a clamped row and store nothing
   const int row = min(row0 + l31, p.M - 1);
   const u32x4* stream = reinterpret_cast<const u32x4*>(p.stream);
+  // (amax) is this lane's row inside its pair's keypoint count?  A wave's 32 rows belong to one (side, pair): the padded counts are
+  // multiples of 32 -- the division is wave-uniform
+  bool row_valid = false;
+  unsigned* amax_slot = nullptr;       // the three words of this wave's (side, pair)
+  if constexpr (NPASS == 3) {
+    if (p.amax && active) {
+      const int r0 = __builtin_amdgcn_readfirstlane(row0), s1 = p.B * p.N0p;
+      const int side = r0 >= s1 ? 1 : 0, Np = side ? p.N1p : p.N0p, rr = r0 - (side ? s1 : 0);
+      const int b = rr / Np, i0 = rr - b * Np;
+      const int n = side ? (p.n1 ? p.n1[b] : p.N1) : (p.n0 ? p.n0[b] : p.N0);
+      row_valid = i0 + l31 < n;
+      amax_slot = p.amax + (size_t)(side * p.B + b) * 4;
+    }
+  }
 
   // ---- the weight stream: image i -> ring slot i & 1 by LDS-DMA, one image ahead (six pieces per thread: 16-byte elements j * NT + tid)
   typedef __attribute__((address_space(3))) void lds_void;
@@ -264,6 +278,29 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gnn_tail_x3_kernel(GnnTailArg
       for (int blk = 0; blk < 4; ++blk) store_block(acc3[blk], p.out, p.n3, D * pass + 32 * blk);
     }
     pend = 16;
+    if constexpr (NPASS == 3) {
+      // max |q| / |k| / |v| (pass 0 / 1 / 2) over the valid rows of this wave's (side, pair), for the next layer's attention
+      // (GnnTailArgs::amax): a lane holds 64 values of ITS row -- 32 v_max3 with |.| modifiers, one select, a wave reduction, one
+      // atomic without return per wave and pass (32 waves share a word: the atomics sit in the wave's in-order VMEM queue like a store)
+      if (amax_slot) {
+        float mx = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(acc3[blk][r]), __builtin_fabsf(acc3[blk][r + 1])), mx);
+        unsigned mb = row_valid ? __builtin_bit_cast(unsigned, mx) : 0u;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o));
+#ifndef GT_AMAX_MODE
+#define GT_AMAX_MODE 1
+#endif
+        if (GT_AMAX_MODE == 1 && lane == 0 && mb) atomicMax(amax_slot + pass, mb);
+        if (GT_AMAX_MODE == 0 && lane == 0 && mb) atomicMax(p.amax + pass, mb);                                   // experiment: three words per launch
+        if (GT_AMAX_MODE == 2 && lane == 0 && mb == 0x12345u) atomicMax(amax_slot + pass, mb);                    // experiment: the arithmetic alone
+        if (GT_AMAX_MODE == 3 && lane == 0 && mb) __builtin_nontemporal_store(mb, p.amax + (blockIdx.x * NW + wave) * 4 + pass);   // experiment: plain store
+        pend += 1;
+      }
+    }
   }
 }
 
@@ -278,6 +315,7 @@ void gnn_tail_trace_dump() {
 #endif
 
 bool gnn_tail_x3_supported(const GnnTailArgs& a) {
+  if (a.amax && (a.n3 != 384 || a.B <= 0 || a.N0p % 32 || a.N1p % 32 || a.M != a.B * (a.N0p + a.N1p))) return false;
   return a.d == 128 && (a.n3 == 384 || a.n3 == 128) && a.M > 0 && a.M % 32 == 0 && a.stream && a.b1 && a.b2 && a.b3;
 }
 

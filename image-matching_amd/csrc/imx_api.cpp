@@ -797,7 +797,16 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   // NEXT layer's q|k|v (final_proj after the last layer) -- are ONE launch per layer (gnn_small.hip; same arithmetic, bit for bit,
   // as the three gemm_small launches it replaces).
   const bool small_form = h->opt.latency_forms >= 0 ? h->opt.latency_forms != 0 : R <= 4096;
-  bool have_next = false, have_mdesc = false;
+  bool have_next = false, have_mdesc = false, have_amax = false;
+  // "attention" = f16x2: the two-plane fp16 form of the throughput attention scales q, k, v by powers of two taken from their maxima
+  // over the valid rows of every (side, pair) -- [2 B][4] words per layer, zeroed once per forward; written by the fused layer tail that produces the layer's
+  // q|k|v (gnn_tail_x3's epilogue), else by qkv_amax (layer 0, whose q|k|v is a plain GEMM; the unfused A/B forms)
+  unsigned* amax = nullptr;
+  if (h->opt.attention != 0 && !h->opt.mfma_f32) {
+    WS(am, unsigned, "sg.amax", h->layers.size() * 2 * B * 16);
+    HIP_OK(h, hipMemsetAsync(am, 0, h->layers.size() * 2 * B * 16, s));
+    amax = am;
+  }
   for (size_t l = 0; l < h->layers.size(); ++l) {
     const GnnLayer& L = h->layers[l];
     if (!have_next && gemm(h, s, "qkv_proj", L.qkv, x, d, d, nullptr, 0, 0, nullptr, 0, qkv, 3 * d, R, false)) return -1;
@@ -806,6 +815,12 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     a.qkv = qkv; a.out = att; a.B = B; a.N0p = N0p; a.N1p = N1p; a.d = d; a.heads = HEADS;
     a.n0 = sd[0].n; a.n1 = sd[1].n; a.N0 = N0; a.N1 = N1; a.cross = c.gnn_layer_is_cross[l];
     a.mfma_f32 = h->opt.mfma_f32; a.latency_forms = h->opt.latency_forms;
+    const bool f16x2 = amax && attention_takes_x3(a);
+    if (f16x2) {
+      if (!have_amax) RUN("qkv_amax", launch_qkv_amax(a, amax + 8 * B * l, s));
+      a.amax = amax + 8 * B * l;
+    }
+    have_amax = false;
     RUN("attention", launch_attention(a, s));
     const bool last = l + 1 == h->layers.size();
     const GemmW& nx = last ? h->final_proj : h->layers[l + 1].qkv;
@@ -814,6 +829,10 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     // latency forms do not apply (M > 4096 rows; measured against three gemm_x3 launches: 40 vs 50 us at 8224 rows, 65 vs 86 at 32768,
     // 256 vs 300 at 131072) -- so results do not depend on the batch size under "latency_forms" = off.
     GnnTailArgs ta{x, att, L.tail_stream, L.mlp1.b, L.mlp2.b, nx.b, last ? mdesc : qkv, R, d, nx.N};
+    if (f16x2 && !last) {              // the next layer's attention takes the same form (same shapes): its maxima come out of this tail
+      ta.amax = amax + 8 * B * (l + 1);
+      ta.n0 = sd[0].n; ta.n1 = sd[1].n; ta.B = B; ta.N0p = N0p; ta.N1p = N1p; ta.N0 = N0; ta.N1 = N1;
+    }
     const bool tail_ok = !small_form && !h->opt.mfma_f32 && L.tail_stream && nx.Npad == nx.N && gnn_tail_x3_supported(ta);
     const bool tail = tail_ok && h->opt.gnn_tail != 0;
     if (small_form && h->opt.latency_forms != 2 && L.mlp1.Npad == 2 * d && L.mlp2.Npad == d && nx.Npad == nx.N && gnn_layer_small_supported(ga)) {
@@ -824,6 +843,7 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
       RUN("gnn_tail", launch_gnn_tail_x3(ta, s));
       have_next = !last;
       have_mdesc = last;
+      have_amax = ta.amax != nullptr;
     } else {
       if (gemm(h, s, "gnn_mlp1", L.mlp1, x, d, d, att, d, d, nullptr, 0, hid, 2 * d, R, true)) return -1;   // merge folded in
       if (gemm(h, s, "gnn_mlp2", L.mlp2, hid, 2 * d, 2 * d, nullptr, 0, 0, x, d, x, d, R, false)) return -1;
@@ -849,6 +869,8 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
                max0, idx0, max1, idx1, m0, m1, ms0, ms1};
   RUN("matches", launch_matches(ma, s));
   tap(h, "x", x, {R, d});
+  tap(h, "qkv", qkv, {R, 3 * d});                                           // the LAST layer's q|k|v ...
+  if (amax) tap(h, "amax", amax + 8 * (size_t)B * (h->layers.size() - 1), {2 * B, 4});      // ... and its maxima (bit patterns; fetched as floats)
   tap(h, "mdesc", mdesc, {R, d});
   tap(h, "scores_in", S, {B, N0p, N1p});
   tap(h, "u", u, {B, N0p + 1});
@@ -858,7 +880,7 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   return 0;
 }
 
-// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | direct, "gnn_tail" = auto | fused | unfused.  Returns 0, or -1 for an unknown key / value.
+// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | direct, "gnn_tail" = auto | fused | unfused, "attention" = auto | f16x2 | bf16x3.  Returns 0, or -1 for an unknown key / value.
 int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
   Options& o = h->opt;
   if (key == "mfma") {
@@ -867,6 +889,8 @@ int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
     if (v == "auto") o.latency_forms = -1; else if (v == "off" || v == "0") o.latency_forms = 0; else if (v == "on" || v == "1") o.latency_forms = 1; else if (v == "unfused") o.latency_forms = 2; else return -1;
   } else if (key == "gnn_tail") {
     if (v == "auto") o.gnn_tail = -1; else if (v == "unfused" || v == "0") o.gnn_tail = 0; else if (v == "fused" || v == "1") o.gnn_tail = 1; else return -1;
+  } else if (key == "attention") {
+    if (v == "auto") o.attention = -1; else if (v == "bf16x3" || v == "x3" || v == "0") o.attention = 0; else if (v == "f16x2" || v == "1") o.attention = 1; else return -1;
   } else if (key == "conv") {
     if (v == "wino") o.conv_direct = 0;
     else if (v == "direct") o.conv_direct = 1;
@@ -929,7 +953,7 @@ int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
     h->device = device_id;
     h->cfg = *cfg;
     // the environment seeds the options once, here; afterwards only imx_set_option changes them
-    for (const char* key : {"mfma", "latency_forms", "conv", "gnn_tail"}) {
+    for (const char* key : {"mfma", "latency_forms", "conv", "gnn_tail", "attention"}) {
       std::string env = std::string("IMX_") + key;
       for (char& ch : env) ch = (char)toupper((unsigned char)ch);
       if (const char* e = getenv(env.c_str()))
@@ -1362,7 +1386,7 @@ int imx_set_option(imx_handle_t h, const char* key, const char* value) {
   return guarded(h, "imx_set_option", [&]() -> int {
     if (!h) return -1;
     if (!key || !value) return fail(h, "imx_set_option: null argument");
-    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|direct, gnn_tail = auto|fused|unfused)", key, value);
+    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|direct, gnn_tail = auto|fused|unfused, attention = auto|f16x2|bf16x3)", key, value);
     return 0;
   });
 }
@@ -1376,6 +1400,7 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     else if (k == "latency_forms") h->opt_text = o.latency_forms < 0 ? "auto" : o.latency_forms == 2 ? "unfused" : o.latency_forms ? "on" : "off";
     else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : "wino";
     else if (k == "gnn_tail") h->opt_text = o.gnn_tail < 0 ? "auto" : o.gnn_tail ? "fused" : "unfused";
+    else if (k == "attention") h->opt_text = o.attention < 0 ? "auto" : o.attention ? "f16x2" : "bf16x3";
     else h->opt_text.clear();
     return h->opt_text.c_str();
   } catch (...) {

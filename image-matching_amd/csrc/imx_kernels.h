@@ -17,6 +17,8 @@ struct Options {
                            //         bit for bit), 1 = "on", 2 = "unfused" (on, with the layer tail as three gemm_small launches: the A/B of the fusion)
   int gnn_tail = -1;       // "gnn_tail": -1 = "auto" = 1 = "fused" (the fused layer tail gnn_tail_x3 wherever the throughput forms run, d = 128),
                            //         0 = "unfused" (three gemm_x3 launches: the A/B of the fusion)
+  int attention = -1;      // "attention": -1 = "auto" = 1 = "f16x2" (attention_x3.hip with two fp16 planes per operand, three term products: needs
+                           //         the q / k / v maxima, which the fused layer tail writes), 0 = "bf16x3" (three bf16 planes, six term products)
   int conv_direct = 0;     // "conv": 0 = "wino" (Winograd F(2x4,3x3) on the fp32 MFMA; direct only for shapes it rejects), 1 = "direct"
 };
 
@@ -188,8 +190,13 @@ struct AttnArgs {
   int cross;
   int mfma_f32;                  // Options::mfma_f32
   int latency_forms;             // Options::latency_forms
+  const unsigned* amax;          // [2 B][4]: bit patterns of max |q|, |k|, |v| over the valid rows of (side, pair) = (s, b) at [s B + b] (launch_qkv_amax,
+                                 // or the producing gnn_tail_x3); non-null selects the two-plane fp16 form of attention_x3.hip (three term
+                                 // products instead of six), null the bf16 x 3 form
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+hipError_t launch_qkv_amax(const AttnArgs& a, unsigned* amax, hipStream_t s);
+bool attention_takes_x3(const AttnArgs& a);      // launch_attention would run attention_x3.hip's kernels for these arguments
 // The tail of one GNN layer of the throughput path in one launch (gnn_tail_x3.hip): hidden = relu([x | att] W1' + b1); x += hidden W2 + b2;
 // out = x W3 + b3 (the next layer's q|k|v, n3 = 3 d, or final_proj, n3 = d) -- six bf16 term products per fp32 product; d = 128.
 // `stream` = gnn_tail_pack() of the three weight matrices (gnn_tail_pack.h).
@@ -200,6 +207,12 @@ struct GnnTailArgs {
   const float* b1; const float* b2; const float* b3;     // [2d], [d], [n3]
   float* out;                // [M][n3]
   int M, d, n3;
+  // n3 = 3 d only, optional: the maxima of |q|, |k|, |v| over the VALID rows of every (side, pair) of `out`, for the next layer's
+  // two-plane fp16 attention (AttnArgs::amax: [2 B][4] zeroed words, bit patterns through atomicMax).  Row layout of the SuperGlue
+  // workspace: side 0 pairs b = 0 .. B-1 (N0p rows each, n0[b] or N0 valid), then side 1 (N1p rows each).
+  unsigned* amax;
+  const int* n0; const int* n1;
+  int B, N0p, N1p, N0, N1;
 };
 bool gnn_tail_x3_supported(const GnnTailArgs& a);
 hipError_t launch_gnn_tail_x3(const GnnTailArgs& a, hipStream_t s);

@@ -211,7 +211,7 @@ int imx_timing_reset(imx_handle_t h);
 const char* imx_timing_form(imx_handle_t h, int index);
 
 /* Kernel-form options of a handle.  Defaults come from the environment ONCE, at imx_create (IMX_MFMA, IMX_LATENCY_FORMS,
- * IMX_CONV, IMX_GNN_TAIL); afterwards only this call changes them -- nothing reads the environment on the launch path.
+ * IMX_CONV, IMX_GNN_TAIL, IMX_ATTENTION); afterwards only this call changes them -- nothing reads the environment on the launch path.
  *   "mfma"           "x3"   (default) fp32 products as six bf16 term products on the bf16 matrix pipe where a kernel has that
  *                           form (every linear layer, attention at head dims 32/64); "f32" keeps every product on the fp32 MFMA
  *                           (the A/B reference the parity tests hold the default against);
@@ -223,7 +223,11 @@ const char* imx_timing_form(imx_handle_t h, int index);
  *                           layer (the fallback for shapes Winograd rejects, and the A/B reference);
  *   "gnn_tail"       "auto" (default) = "fused": wherever the throughput forms run (more than 4096 feature rows) the tail of a GNN layer
  *                           (mlp.0 -> mlp.3 + residual -> the next layer's q|k|v or final_proj) is ONE launch on the bf16 pipe
- *                           (descriptor_dim 128); "unfused" three launches (the A/B reference: same products, another summation order).
+ *                           (descriptor_dim 128); "unfused" three launches (the A/B reference: same products, another summation order);
+ *   "attention"      "auto" (default) = "f16x2": the throughput attention (head dims 32 / 64, "mfma" = "x3") cuts q, k, v and the softmax
+ *                           weights into TWO fp16 planes (22 bits; every operand scaled by a power of two taken from the maximum of its
+ *                           (side, pair) over the valid rows) and keeps three term products per k-step; "bf16x3" three bf16 planes and
+ *                           six term products (the A/B reference; both are closer to a float64 evaluation than the fp32 MFMA form).
  * Unknown keys / values are an error.  imx_get_option returns the current value ("" for an unknown key); the pointer is valid
  * until the next call on the handle. */
 int imx_set_option(imx_handle_t h, const char* key, const char* value);

@@ -59,11 +59,12 @@ def _pair_taps(eng, K):
     return x[:K].T, x[Kp:Kp + K].T
 
 
-@pytest.mark.parametrize("forms,mfma", [("auto", "x3"), ("off", "x3"), ("off", "f32")])
+@pytest.mark.parametrize("forms,mfma,attention", [("auto", "x3", "auto"), ("off", "x3", "auto"), ("off", "x3", "bf16x3"), ("off", "f32", "auto")])
 @pytest.mark.parametrize("name", ["strict_c3.npz", "strict_c5.npz"])
-def test_strict_bar_superglue_every_form(name, forms, mfma):
+def test_strict_bar_superglue_every_form(name, forms, mfma, attention):
     """SuperGlue alone, the reference's keypoints injected, on every kernel form a caller can reach (latency forms; the
-    throughput forms bench.py times; their fp32-MFMA counterparts): gnn17, scores_in and Z element-wise inside
+    throughput forms bench.py times -- attention on two fp16 planes; the same with attention on three bf16 planes; their fp32-MFMA
+    counterparts): gnn17, scores_in and Z element-wise inside
     1e-4 + 1e-4|ref| of the oracle's (every element) and of the reference's (fixture samples); matches0 / matches1 equal to the
     reference's; matching scores at the same tolerance."""
     g, per_seed = _strict_inputs(name)
@@ -73,7 +74,7 @@ def test_strict_bar_superglue_every_form(name, forms, mfma):
     eng = Engine(util.sp_config(d, K), util.sg_config(d), "cuda")
     sd_sg = util.sg_sd(d, variant="t")
     eng.load_state_dict(L.NET_SUPERGLUE, sd_sg)
-    eng.set_option("latency_forms", forms).set_option("mfma", mfma)
+    eng.set_option("latency_forms", forms).set_option("mfma", mfma).set_option("attention", attention)
     eng.set_debug(True)
     alpha = float(sd_sg["bin_score"])
     worst = {"gnn17": 0.0, "scores_in": 0.0, "Z": 0.0, "mscores": 0.0}
@@ -87,7 +88,7 @@ def test_strict_bar_superglue_every_form(name, forms, mfma):
         g0, g1 = _pair_taps(eng, K)
         S = eng.fetch("scores_in")[0, :K, :K]
         Z = util.transport_Z(S, eng.fetch("u")[0], eng.fetch("v")[0], K, K, alpha)
-        tag = f"{name} seed {seed} [{forms}/{mfma}]"
+        tag = f"{name} seed {seed} [{forms}/{mfma}/{attention}]"
         for key, mine, full in (("gnn17", np.stack([g0, g1]), np.stack([ref["gnn0"], ref["gnn1"]])), ("scores_in", S, ref["scores_in"]), ("Z", Z, ref["Z"])):
             util.assert_close(mine, full, f"{tag}: {key} vs the oracle, every element")
             worst[key] = max(worst[key], util.tolerance_used(mine, full))
@@ -100,7 +101,7 @@ def test_strict_bar_superglue_every_form(name, forms, mfma):
         util.assert_close(ms1[0][same1], g["mscores1"][s][same1], f"{tag}: matching_scores1")
         worst["mscores"] = max(worst["mscores"], util.tolerance_used(ms0[0][same0], g["mscores0"][s][same0]))
     n = len(g["seeds"])
-    print(f"[strict] {name} [{forms}/{mfma}]: {n} unselected seeds, {2 * K * n} match indices: 0 differ outside the threshold band; {band} rows have their "
+    print(f"[strict] {name} [{forms}/{mfma}/attention={attention}]: {n} unselected seeds, {2 * K * n} match indices: 0 differ outside the threshold band; {band} rows have their "
           f"reference score within 1e-4 of the threshold, {other} of them sit on the other side here; worst fraction of the 1e-4+1e-4|ref| tolerance used: "
           + ", ".join(f"{k} {v:.3f}" for k, v in worst.items()))
 
@@ -137,7 +138,7 @@ def test_strict_bar_as_one_batched_call_from_images(name, B):
     torch.cuda.synchronize()
     forms = {r[0]: r[3] for r in eng.timing_report(forms=True)}
     eng.set_timing(False)
-    assert forms["qkv_proj"] == "gemm_x3:bf16x3" and forms["attention"] == "attention_x3:bf16x3" and forms["conv2a"] == "conv3x3_wino24:f32", forms
+    assert forms["qkv_proj"] == "gemm_x3:bf16x3" and forms["attention"] == "attention_h2:f16x2" and forms["conv2a"] == "conv3x3_wino24:f32", forms
     alpha = float(util.sg_sd(d, variant="t")["bin_score"])
     summary = util.strict_compare_batch(g, out, eng, B, alpha, float(util.sg_config(d)["match_threshold"]))
     print(f"[strict e2e] {name} as one call of {B} pairs: {summary}")

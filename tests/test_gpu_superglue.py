@@ -174,7 +174,7 @@ def test_bad_option_is_refused_and_forms_are_reported():
         _run(eng, t, (1, 1, 120, 160))
         seen[(forms, mfma)] = {r[0]: r[3] for r in eng.timing_report(forms=True)}
         eng.set_timing(False)
-    assert seen[("off", "x3")]["qkv_proj"] == "gemm_x3:bf16x3" and seen[("off", "x3")]["attention"] == "attention_x3:bf16x3"
+    assert seen[("off", "x3")]["qkv_proj"] == "gemm_x3:bf16x3" and seen[("off", "x3")]["attention"] == "attention_h2:f16x2"
     assert seen[("off", "x3")]["gnn_tail"] == "gnn_tail_x3:bf16x3" and "gnn_mlp1" not in seen[("off", "x3")]      # round 4: one launch per layer tail
     assert seen[("off", "f32")]["gnn_mlp1"] == "gemm_tiled:f32" and "gnn_tail" not in seen[("off", "f32")]
     assert seen[("off", "f32")]["qkv_proj"] == "gemm_tiled:f32" and seen[("off", "f32")]["attention"] == "attention:f32"
@@ -220,6 +220,45 @@ def test_fused_layer_tail_of_the_throughput_path_vs_three_launches():
             res[mode] = _run(eng, t, (1, 1, 120, 160))
         assert np.array_equal(res["fused"][0], res["unfused"][0]) and np.array_equal(res["fused"][1], res["unfused"][1]), (n0, n1)
         np.testing.assert_allclose(res["fused"][2], res["unfused"][2], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("tail", ["fused", "unfused"])
+def test_two_plane_fp16_attention_vs_six_product_bf16(tail):
+    """The throughput attention's default form (round 4: operands as two fp16 planes scaled by a power of two from the (side, pair)'s
+    q / k / v maxima, three term products per k-step) against the six-product bf16 form it replaces ("attention" = "bf16x3"): the
+    reference's matches on the full-size fixture from both, GNN output and matching scores equal to rounding.  The maxima themselves
+    -- written by the fused layer tail's epilogue, or by qkv_amax where the q|k|v comes from a plain GEMM (layer 0; every layer under
+    "gnn_tail" = "unfused") -- equal the maxima of the valid rows of the last layer's q|k|v exactly."""
+    g = util.golden("c3_pair_s59.npz")
+    H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
+    data = {k: v.cuda() for k, v in _oracle_pair_inputs(seed, H, W, d, K).items()}
+    eng, L = _engine(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(d))
+    eng.set_option("latency_forms", "off").set_option("gnn_tail", tail)
+    eng.set_debug(True)
+    taps = {}
+    for mode in ("f16x2", "bf16x3"):
+        eng.set_option("attention", mode)
+        assert eng.get_option("attention") == mode
+        eng.timing_reset()
+        eng.set_timing(True)
+        out = _run(eng, data, (1, 1, H, W))
+        rows = {r[0]: r for r in eng.timing_report(forms=True)}
+        eng.set_timing(False)
+        assert rows["attention"][3] == ("attention_h2:f16x2" if mode == "f16x2" else "attention_x3:bf16x3"), rows["attention"]
+        assert rows.get("qkv_amax", (0, 0))[1] == (0 if mode == "bf16x3" else 1 if tail == "fused" else 18), rows.get("qkv_amax")
+        assert np.array_equal(out[0], g["matches0"]) and np.array_equal(out[1], g["matches1"]), f"attention={mode}"
+        taps[mode] = (eng.fetch("x").copy(), eng.fetch("scores_in").copy(), out[2].copy())
+        if mode == "f16x2":
+            amax, qkv = eng.fetch("amax"), eng.fetch("qkv")
+            Kp = (K + 31) // 32 * 32
+            for side, r0 in ((0, 0), (1, Kp)):
+                for j, what in enumerate("qkv"):
+                    want = np.abs(qkv[r0:r0 + K, j * d:(j + 1) * d]).max()
+                    assert amax[side, j] == want, f"max |{what}| of side {side}: {amax[side, j]} vs {want} (gnn_tail={tail})"
+    scale = np.abs(taps["bf16x3"][0]).max()
+    assert np.abs(taps["f16x2"][0] - taps["bf16x3"][0]).max() <= 2e-5 * scale, "GNN output: two fp16 planes vs three bf16 planes"
+    np.testing.assert_allclose(taps["f16x2"][2], taps["bf16x3"][2], rtol=0, atol=2e-5)
 
 
 def test_attention_key_split_and_throughput_forms_agree(monkeypatch):
