@@ -127,6 +127,17 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
     gpx[j] = pc % RW;
   }
   int ntile_done = 0;
+  // ConvArgs::amax_out: the largest output of every image (for the next layer's fp16-plane scale, conv3x3_wino24h.hip).  A workgroup walks
+  // a contiguous tile range, i.e. one or two images: the running maximum is flushed (wave reduction + one atomicMax) when the image changes
+  unsigned am_run = 0;
+  int am_b = -1;
+  auto am_flush = [&]() {
+    unsigned mb = am_run;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o));
+    if (lane == 0 && mb && am_b >= 0) atomicMax(p.amax_out + (am_b & 255), mb);      // image slot b % 256 (conv3x3_wino24h.hip: AMAX_SLOTS)
+    am_run = 0;
+  };
   const f32x4 bs4 = *reinterpret_cast<const f32x4*>(p.bias + cb * 16 + 4 * (lane >> 4));      // conv1b bias of this lane's four output channels
   f32x4 bf[NQ];                  // B operands of the coming chunk (chunk 0 here; refilled in place from then on)
 #pragma unroll
@@ -302,12 +313,17 @@ __global__ __launch_bounds__(256, 2) void conv1ab_wino24(ConvArgs p, int tiles_x
         const int ox = (x0 >> 1) + 2 * wc + hh;
         const unsigned off = (oy < Ho && ox < Wo) ? (unsigned)((oy * Wo + ox) * opx + choff) : 0x7ffffff0u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (int)off, 0, 0);
+        if (p.amax_out) {
+          if (bcur != am_b) { am_flush(); am_b = bcur; }           // uniform
+          am_run = max(am_run, __builtin_bit_cast(unsigned, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]))));      // after ReLU: >= 0
+        }
       }
     }
     IMX_TS(5)
     ++ntile_done;
   }
 #undef IMX_TS
+  if (p.amax_out) am_flush();
   if constexpr (TRACE) {
     if (lane == 0 && blockIdx.x < 1024) {
       unsigned* o = trace + (blockIdx.x * 4 + wave) * 8;

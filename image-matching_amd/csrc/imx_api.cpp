@@ -5,6 +5,7 @@
 #include "../../include/imx.h"
 #include "imx_kernels.h"
 #include "gnn_tail_pack.h"
+#include "wino24_pack.h"
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -45,6 +46,8 @@ struct DevBuf {
 struct ConvW {
   float* w = nullptr;    // direct form  [9][Cin][Cout] (conv3x3.hip: IMX_CONV=direct, and the fallback for shapes wino24 rejects)
   float* wu24 = nullptr; // Winograd F(2x4,3x3) form (conv1ab_wino24.hip / conv3x3_wino24.hip layout)
+  void* wuh = nullptr;   // the same as two fp16 planes scaled by a power of two (conv3x3_wino24h.hip; wino24_pack.h: wino24h_pack), cin % 64 == 0 only
+  float su_inv = 0.f;    // 1 / that power of two
   float* b = nullptr;
   int cin = 0, cout = 0;
 };
@@ -248,6 +251,17 @@ float* upload(imx_handle_t h, const std::vector<float>& v) {
   return static_cast<float*>(p);
 }
 
+void* upload_u16(imx_handle_t h, const std::vector<uint16_t>& v) {
+  void* p = nullptr;
+  if (hipMalloc(&p, v.size() * 2 + 16) != hipSuccess) return nullptr;
+  if (hipMemcpy(p, v.data(), v.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(p);
+    return nullptr;
+  }
+  h->weight_allocs[h->upload_net].push_back(p);
+  return p;
+}
+
 // per-output-channel scale s and shift t such that BN(conv + b) = conv*s + t
 void fold_bn(const std::map<std::string, HostTensor>& raw, const std::string& conv, const std::string& bn, int cout,
              std::vector<double>& s, std::vector<double>& t) {
@@ -282,35 +296,6 @@ void put_conv3(const std::map<std::string, HostTensor>& raw, const std::string& 
   }
 }
 
-// U = G2 g G4^T (4 x 6 per (co, ci); F(2,3) down the rows, F(4,3) along the columns), laid out as conv1ab_wino24.hip's MFMA
-// B fragments read it: [chunk of 8 ci][quad = position pair][co-block][lane = (ci pair)*16 + co%16][(position parity)*2 + ci%2],
-// position p = j*4 + i: a lane's four B registers of a quad are one buffer_load_dwordx4.
-std::vector<float> wino24_transform(const std::vector<float>& w, int cin, int cout) {
-  static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-  static const double G4[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                  {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-  const int nchunk = cin / 8;
-  std::vector<float> u((size_t)(cout / 64) * nchunk * 12288, 0.f);
-  for (int co = 0; co < cout; ++co)
-    for (int ci = 0; ci < cin; ++ci) {
-      double g[3][3];
-      for (int ky = 0; ky < 3; ++ky)
-        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((size_t)(ky * 3 + kx) * cin + ci) * cout + co];
-      const int chunk = ci / 8, kk = ci % 8, k = kk >> 1, sstep = kk & 1;
-      const int cog = co / 64, col = co % 64;
-      float* blk = u.data() + ((size_t)cog * nchunk + chunk) * 12288;
-      for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 6; ++j) {
-          double acc = 0.0;
-          for (int ky = 0; ky < 3; ++ky)
-            for (int kx = 0; kx < 3; ++kx) acc += G2[i][ky] * g[ky][kx] * G4[j][kx];
-          const int pos = j * 4 + i, quad = pos >> 1, e = (pos & 1) * 2 + sstep;
-          blk[(size_t)(((quad * 4 + (col >> 4)) * 64 + k * 16 + (col & 15)) * 4) + e] = (float)acc;
-        }
-    }
-  return u;
-}
-
 // bf16 helpers of the host-side splits (round to nearest even, bit patterns)
 uint16_t bf16_rne(float x) {
   uint32_t u;
@@ -332,6 +317,7 @@ int make_conv(imx_handle_t h, ConvW& out, const std::map<std::string, HostTensor
   put_conv3(raw, conv, bn, cin, cout, cout, 0, w, b);
   out.w = upload(h, w);
   out.wu24 = upload(h, wino24_transform(w, cin, cout));
+  if (cin % 64 == 0 && cout % 64 == 0) out.wuh = upload_u16(h, wino24h_pack(w, cin, cout, &out.su_inv));
   out.b = upload(h, b);
   out.cin = cin;
   out.cout = cout;
@@ -443,6 +429,7 @@ int finalize_superpoint(imx_handle_t h) {
     put_conv3(raw, "convDa", bn ? "bnDa" : "", 128, 256, 512, 256, w, b);
     h->conv[7].w = upload(h, w);
     h->conv[7].wu24 = upload(h, wino24_transform(w, 128, 512));
+    h->conv[7].wuh = upload_u16(h, wino24h_pack(w, 128, 512, &h->conv[7].su_inv));
     h->conv[7].b = upload(h, b);
     h->conv[7].cin = 128;
     h->conv[7].cout = 512;
@@ -633,8 +620,26 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
       blocked = conv3x3_wino24_supported(t);
     }
   }
+  // "conv" = "wino": the layers after the first run their Winograd products on the fp16 matrix pipe (conv3x3_wino24h.hip).  Each needs an
+  // upper bound of |input| per image: one zeroed word per (layer, image), written by the PRODUCING layer's epilogue through atomicMax --
+  // the fused first layer starts the chain, so without it (conv = direct, shapes the Winograd kernels reject) the fp32 forms run
+  unsigned* amax = nullptr;
+  bool all_h = true;
+  for (int i = 1; i < 8; ++i) all_h = all_h && h->conv[i].wuh != nullptr;
+  if (blocked && all_h && h->opt.conv_f16 && !h->opt.mfma_f32) {
+    WS(am, unsigned, "sp.amax", (size_t)8 * 256 * 4);          // one word per (layer, image slot b % 256)
+    HIP_OK(h, hipMemsetAsync(am, 0, (size_t)8 * 256 * 4, s));
+    amax = am;
+  }
+  int layer = 0;
   auto conv = [&](const char* name, const ConvW& w, const float* in, float* out, int hh, int ww, bool pool, bool first, bool last = false) -> int {
     ConvArgs a{};
+    const int li = layer++;
+    if (amax) {
+      a.amax_out = last ? nullptr : amax + (size_t)li * 256;
+      a.amax_in = li > 0 ? amax + (size_t)(li - 1) * 256 : nullptr;
+      a.wuh = w.wuh; a.u_scale_inv = w.su_inv;
+    }
     a.in_blocked = (blocked && !first) ? 1 : 0;
     a.out_blocked = (blocked && !last) ? 1 : 0;
     a.in = in; a.in2 = first ? img1 : nullptr; a.split = first ? split : 0;
@@ -642,7 +647,9 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
     a.B = B; a.H = hh; a.W = ww; a.Cin = w.cin; a.Cout = w.cout; a.relu = 1; a.pool = pool ? 1 : 0; a.first = first ? 1 : 0;
     const bool fused1 = a.first && a.pool && !h->opt.conv_direct;
     const bool wino = !a.first && !h->opt.conv_direct && conv3x3_wino24_supported(a);
-    RUN(name, fused1 ? launch_conv1ab_wino24(a, s) : wino ? launch_conv3x3_wino24(a, s) : launch_conv3x3(a, s));
+    const bool winoh = wino && amax && conv3x3_wino24h_supported(a);
+    if (amax && !fused1 && !winoh) return fail(h, "%s: the fp16-plane Winograd chain needs every layer to take part (internal)", name);
+    RUN(name, fused1 ? launch_conv1ab_wino24(a, s) : winoh ? launch_conv3x3_wino24h(a, s) : wino ? launch_conv3x3_wino24(a, s) : launch_conv3x3(a, s));
     return 0;
   };
   if (conv("conv1ab_pool", h->conv[0], img0, a1, H, W, true, true)) return -1;
@@ -880,7 +887,7 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   return 0;
 }
 
-// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | direct, "gnn_tail" = auto | fused | unfused, "attention" = auto | f16x2 | bf16x3.  Returns 0, or -1 for an unknown key / value.
+// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | wino32 | direct, "gnn_tail" = auto | fused | unfused, "attention" = auto | f16x2 | bf16x3.  Returns 0, or -1 for an unknown key / value.
 int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
   Options& o = h->opt;
   if (key == "mfma") {
@@ -892,7 +899,8 @@ int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
   } else if (key == "attention") {
     if (v == "auto") o.attention = -1; else if (v == "bf16x3" || v == "x3" || v == "0") o.attention = 0; else if (v == "f16x2" || v == "1") o.attention = 1; else return -1;
   } else if (key == "conv") {
-    if (v == "wino") o.conv_direct = 0;
+    if (v == "wino") { o.conv_direct = 0; o.conv_f16 = 1; }
+    else if (v == "wino32") { o.conv_direct = 0; o.conv_f16 = 0; }
     else if (v == "direct") o.conv_direct = 1;
     else return -1;
   } else {
@@ -1386,7 +1394,7 @@ int imx_set_option(imx_handle_t h, const char* key, const char* value) {
   return guarded(h, "imx_set_option", [&]() -> int {
     if (!h) return -1;
     if (!key || !value) return fail(h, "imx_set_option: null argument");
-    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|direct, gnn_tail = auto|fused|unfused, attention = auto|f16x2|bf16x3)", key, value);
+    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino32|direct, gnn_tail = auto|fused|unfused, attention = auto|f16x2|bf16x3)", key, value);
     return 0;
   });
 }
@@ -1398,7 +1406,7 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     const Options& o = h->opt;
     if (k == "mfma") h->opt_text = o.mfma_f32 ? "f32" : "x3";
     else if (k == "latency_forms") h->opt_text = o.latency_forms < 0 ? "auto" : o.latency_forms == 2 ? "unfused" : o.latency_forms ? "on" : "off";
-    else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : "wino";
+    else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : o.conv_f16 ? "wino" : "wino32";
     else if (k == "gnn_tail") h->opt_text = o.gnn_tail < 0 ? "auto" : o.gnn_tail ? "fused" : "unfused";
     else if (k == "attention") h->opt_text = o.attention < 0 ? "auto" : o.attention ? "f16x2" : "bf16x3";
     else h->opt_text.clear();

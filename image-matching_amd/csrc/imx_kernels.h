@@ -19,7 +19,9 @@ struct Options {
                            //         0 = "unfused" (three gemm_x3 launches: the A/B of the fusion)
   int attention = -1;      // "attention": -1 = "auto" = 1 = "f16x2" (attention_x3.hip with two fp16 planes per operand, three term products: needs
                            //         the q / k / v maxima, which the fused layer tail writes), 0 = "bf16x3" (three bf16 planes, six term products)
-  int conv_direct = 0;     // "conv": 0 = "wino" (Winograd F(2x4,3x3) on the fp32 MFMA; direct only for shapes it rejects), 1 = "direct"
+  int conv_direct = 0;     // "conv": 0 = "wino" / "wino32" (Winograd F(2x4,3x3); direct only for shapes it rejects), 1 = "direct"
+  int conv_f16 = 1;        //         "wino" (default): the layers after the first run the Winograd products on the fp16 matrix pipe (two planes per
+                           //         transformed operand, conv3x3_wino24h.hip; needs "mfma" = "x3"); "wino32": every product on the fp32 MFMA
 };
 
 // The form a launcher picked ("gemm_x3:bf16x3", "conv3x3_wino24:f32", ...: kernel family, then the matrix pipe it runs on or
@@ -59,6 +61,13 @@ struct ConvArgs {
   // channels of consecutive pixels is contiguous, which is what the Winograd kernels' per-chunk patch loads read (conv3x3_wino24.hip).
   // The direct kernel (conv3x3.hip) and the 1x1-conv GEMMs take NHWC only.
   int in_blocked, out_blocked;
+  // conv3x3_wino24h.hip (Winograd with both transformed operands as two fp16 planes): U planes [Cout/64][Cin/32][24][2][4][64][8] halves,
+  // 1 / (the power of two U was scaled by), and one word per image with the bit pattern of an upper bound of |input| (amax_in; written
+  // by the producing layer's epilogue).  amax_out (any Winograd kernel, optional): [B] zeroed words that receive this layer's maxima.
+  const void* wuh;
+  float u_scale_inv;
+  const unsigned* amax_in;
+  unsigned* amax_out;
 };
 // Cin % 16 == 0, Cout % 64 == 0.
 hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);       // direct form (conv3x3.hip)
@@ -67,6 +76,8 @@ hipError_t launch_conv1ab_wino24(const ConvArgs& a, hipStream_t s); // fused con
 // Cin % 64 == 0, Cout % 64 == 0, not first.
 bool conv3x3_wino24_supported(const ConvArgs& a);                   // false (e.g. an image of >= 2 GB per layer): callers fall back to the direct form
 hipError_t launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s); // Winograd F(2x4,3x3), persistent, in-stream transform
+bool conv3x3_wino24h_supported(const ConvArgs& a);                  // + wuh, amax_in
+hipError_t launch_conv3x3_wino24h(const ConvArgs& a, hipStream_t s); // the same on the fp16 matrix pipe: two planes per operand, three plane products
 
 
 // ---------------------------------------------------------------- GEMM (MFMA fp32): 1x1 conv / linear

@@ -181,21 +181,30 @@ def test_dense_forward_for_label_export_vs_reference_golden():
     util.assert_close(out["desc"], g["desc"], "desc")
 
 
-def test_direct_conv_fallback_vs_reference_golden(monkeypatch):
-    """"conv" = "direct" (here seeded through IMX_CONV, which imx_create reads once) puts every 3x3 layer on the direct implicit-GEMM kernel -- the A/B reference of
-    the default Winograd F(2x4,3x3) kernels and the fallback for shapes those reject.  It must reproduce the reference's
-    dense stages and keypoints on the ragged fixture (123x165: partial tiles on both axes) and on the 120x160 one."""
-    monkeypatch.setenv("IMX_CONV", "direct")
+@pytest.mark.parametrize("mode,form", [("direct", "conv3x3_direct"), ("wino32", "conv3x3_wino24:f32"), ("wino", "conv3x3_wino24h:f16x2")])
+def test_every_conv_form_vs_reference_golden(monkeypatch, mode, form):
+    """"conv" (here seeded through IMX_CONV, which imx_create reads once): "direct" puts every 3x3 layer on the direct implicit-GEMM
+    kernel (the fallback for shapes the Winograd kernels reject), "wino32" on Winograd F(2x4,3x3) with fp32-MFMA products, "wino" (the
+    default since round 4) runs the products of the layers after the first on the fp16 matrix pipe -- two planes per transformed
+    operand, scaled by a power of two from the producing layer's per-image maximum.  Each must reproduce the reference's dense stages
+    and keypoints on the ragged fixture (123x165: partial tiles on both axes) and on the 120x160 one."""
+    monkeypatch.setenv("IMX_CONV", mode)
     for name in ("sp_ragged.npz", "sp_small.npz"):
         g = util.golden(name)
         H, W, seed, K = int(g["H"]), int(g["W"]), int(g["seed"]), int(g["max_keypoints"])
         eng, L = _engine(128, K)
+        assert eng.get_option("conv") == mode
         eng.load_state_dict(L.NET_SUPERPOINT, util.sp_sd(128))
         x = torch.cat(util.pair(seed, H, W))
+        eng.timing_reset()
+        eng.set_timing(True)
         _check_against(eng, x, [g["keypoints0"], g["keypoints1"]], [g["scores0"], g["scores1"]],
                        [g["descriptors0"], g["descriptors1"]])
-        util.assert_close(_nchw(eng.fetch("x4")), g["x4"], "x4 (direct)")
-        util.assert_close(_nchw(eng.fetch("semi")), g["semi"], "semi (direct)")
+        forms = {r[0]: r[3] for r in eng.timing_report(forms=True)}
+        eng.set_timing(False)
+        assert forms["conv3b_pool"].startswith(form) and forms["convPaDa"].startswith(form), forms
+        util.assert_close(_nchw(eng.fetch("x4")), g["x4"], f"x4 ({mode})")
+        util.assert_close(_nchw(eng.fetch("semi")), g["semi"], f"semi ({mode})")
 
 
 @pytest.mark.parametrize("radius", [1, 2, 3, 4, 5, 6, 9, 13])

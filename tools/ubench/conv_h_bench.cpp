@@ -1,0 +1,128 @@
+// conv_h_bench.cpp -- conv3x3_wino24h (Winograd F(2x4,3x3) with both transformed operands as two fp16 planes, three plane products on
+// v_mfma_f32_16x16x32_f16) against conv3x3_wino24 (the same on the fp32 MFMA) on SuperPoint's layer shapes at C3's batch: times both,
+// compares them with each other and with a float64 direct convolution of sample pixels, checks the per-image output maxima.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -Iinclude -x hip tools/ubench/conv_h_bench.cpp \
+//         image-matching_amd/csrc/conv3x3_wino24.hip image-matching_amd/csrc/conv3x3_wino24h.hip -o tools/ubench/conv_h_bench
+//   usage: conv_h_bench [B H W Cin Cout pool blocked]     (default: every layer of the stack, B = 128)
+#include "../../image-matching_amd/csrc/imx_kernels.h"
+#include "../../image-matching_amd/csrc/wino24_pack.h"
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+using namespace imx;
+namespace imx { thread_local const char* last_form = nullptr; }
+
+static int run(int B, int H, int W, int Cin, int Cout, int pool, int blocked, float mag) {
+  const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+  std::vector<float> x((size_t)B * H * W * Cin), w((size_t)9 * Cin * Cout), bias(Cout);
+  srand(5);
+  auto rnd = []() { return rand() / (float)RAND_MAX; };
+  for (auto& v : x) { const float r = rnd(); v = r < 0.4f ? 0.f : (r - 0.4f) * mag; }        // post-ReLU-like: 40 % zeros
+  for (auto& v : w) v = (rnd() - 0.5f) * 0.12f;
+  for (auto& v : bias) v = (rnd() - 0.5f) * 0.2f;
+  std::vector<float> xin = x;
+  if (blocked) {           // (B, Cin/8, H, W, 8)
+    for (int b = 0; b < B; ++b)
+      for (int p = 0; p < H * W; ++p)
+        for (int c = 0; c < Cin; ++c) xin[(((size_t)b * (Cin / 8) + c / 8) * H * W + p) * 8 + c % 8] = x[((size_t)b * H * W + p) * Cin + c];
+  }
+  std::vector<unsigned> amax(B);
+  for (int b = 0; b < B; ++b) {
+    float m = 0;
+    for (size_t i = 0; i < (size_t)H * W * Cin; ++i) m = fmaxf(m, fabsf(x[(size_t)b * H * W * Cin + i]));
+    memcpy(&amax[b], &m, 4);
+  }
+  const std::vector<float> u32 = wino24_transform(w, Cin, Cout);
+  float su_inv = 0;
+  const std::vector<uint16_t> uh = wino24h_pack(w, Cin, Cout, &su_inv);
+  float *dx, *dw32, *db, *dout32, *douth; void* duh; unsigned *damax, *damax_out;
+  hipMalloc(&dx, x.size() * 4); hipMalloc(&dw32, u32.size() * 4); hipMalloc(&db, Cout * 4); hipMalloc(&duh, uh.size() * 2);
+  hipMalloc(&dout32, (size_t)B * Ho * Wo * Cout * 4); hipMalloc(&douth, (size_t)B * Ho * Wo * Cout * 4); hipMalloc(&damax, 256 * 4); hipMalloc(&damax_out, 256 * 4);
+  hipMemcpy(dx, xin.data(), x.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dw32, u32.data(), u32.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(db, bias.data(), Cout * 4, hipMemcpyHostToDevice); hipMemcpy(duh, uh.data(), uh.size() * 2, hipMemcpyHostToDevice);
+  hipMemset(damax, 0, 256 * 4); hipMemcpy(damax, amax.data(), (B < 256 ? B : 256) * 4, hipMemcpyHostToDevice); hipMemset(damax_out, 0, 256 * 4);
+  hipMemset(dout32, 0xff, (size_t)B * Ho * Wo * Cout * 4); hipMemset(douth, 0xff, (size_t)B * Ho * Wo * Cout * 4);
+  ConvArgs a{};
+  a.in = dx; a.wu24 = dw32; a.bias = db; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = 1; a.pool = pool; a.in_blocked = blocked;
+  a.wuh = duh; a.u_scale_inv = su_inv; a.amax_in = damax; a.amax_out = getenv("NOAMAX") ? nullptr : damax_out;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float ms[2] = {0, 0};
+  for (int form = 0; form < 2; ++form) {
+    a.out = form ? douth : dout32;
+    auto go = [&]() { return form ? launch_conv3x3_wino24h(a, 0) : launch_conv3x3_wino24(a, 0); };
+    hipError_t err = go();
+    hipDeviceSynchronize();
+    if (err != hipSuccess || hipGetLastError() != hipSuccess) { printf("launch failed (form %d): %s\n", form, hipGetErrorString(err)); return 1; }
+    for (int i = 0; i < 3; ++i) go();
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 10; ++i) go();
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms[form], e0, e1);
+    ms[form] /= 10;
+  }
+  std::vector<float> o32((size_t)B * Ho * Wo * Cout), oh(o32.size());
+  hipMemcpy(o32.data(), dout32, o32.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(oh.data(), douth, oh.size() * 4, hipMemcpyDeviceToHost);
+  double dmax = 0, omax = 0; size_t nan = 0;
+  for (size_t i = 0; i < oh.size(); ++i) {
+    if (!(oh[i] == oh[i])) { ++nan; continue; }
+    dmax = fmax(dmax, fabs((double)oh[i] - o32[i])); omax = fmax(omax, fabs((double)o32[i]));
+  }
+  // float64 direct reference on sample output pixels (all channels)
+  double e32 = 0, eh = 0; int ns = 0;
+  for (int sidx = 0; sidx < 48; ++sidx) {
+    const int b = (sidx * 37) % B, oy = (sidx * 53 + (sidx & 1 ? Ho - 1 : 0)) % Ho, ox = (sidx * 29 + (sidx & 2 ? Wo - 1 : 0)) % Wo;
+    for (int co = 0; co < Cout; ++co) {
+      double best = -1e300;
+      for (int py = 0; py < (pool ? 2 : 1); ++py)
+        for (int px = 0; px < (pool ? 2 : 1); ++px) {
+          const int y = pool ? 2 * oy + py : oy, xx = pool ? 2 * ox + px : ox;
+          double acc = bias[co];
+          for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+              const int iy = y + ky - 1, ix = xx + kx - 1;
+              if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+              const float* xp = &x[(((size_t)b * H + iy) * W + ix) * Cin];
+              const float* wp = &w[((size_t)(ky * 3 + kx) * Cin) * Cout + co];
+              for (int ci = 0; ci < Cin; ++ci) acc += (double)xp[ci] * wp[(size_t)ci * Cout];
+            }
+          best = fmax(best, acc);
+        }
+      best = fmax(best, 0.0);
+      const size_t oi = (((size_t)b * Ho + oy) * Wo + ox) * Cout + co;
+      e32 = fmax(e32, fabs(o32[oi] - best)); eh = fmax(eh, fabs(oh[oi] - best)); ++ns;
+    }
+  }
+  std::vector<unsigned> am(B);
+  hipMemcpy(am.data(), damax_out, B * 4, hipMemcpyDeviceToHost);
+  int bad = 0;
+  for (int b = 0; b < B; ++b) {
+    float m = 0;
+    for (size_t i = 0; i < (size_t)Ho * Wo * Cout; ++i) m = fmaxf(m, oh[(size_t)b * Ho * Wo * Cout + i]);
+    float got; memcpy(&got, &am[b], 4);
+    if (!(got >= m) || got > 1.5f * m + 1e-6f) { if (bad < 3) printf("  amax_out[%d] = %g, host max %g\n", b, got, m); ++bad; }
+  }
+  const double macs = (double)B * H * W * 9.0 * Cin * Cout;
+  printf("%4dx%-4d %3d->%-3d pool %d %s | fp32 wino %7.1f us  f16x2 wino %7.1f us (x%.2f, %5.1f TFLOP/s direct-equivalent) | max |h - f32| %.2e of %.2e%s | vs float64 (%d samples): f32 %.2e  f16x2 %.2e | amax_out bad %d\n",
+         H, W, Cin, Cout, pool, blocked ? "blocked" : "nhwc   ", ms[0] * 1e3, ms[1] * 1e3, ms[0] / ms[1], 2 * macs / (ms[1] * 1e-3) / 1e12, dmax, omax,
+         nan ? " NaN!" : "", ns, e32, eh, bad);
+  hipFree(dx); hipFree(dw32); hipFree(db); hipFree(duh); hipFree(dout32); hipFree(douth); hipFree(damax); hipFree(damax_out);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  const float mag = getenv("MAG") ? (float)atof(getenv("MAG")) : 3.f;
+  if (argc > 5) return run(atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argc > 6 ? atoi(argv[6]) : 0, argc > 7 ? atoi(argv[7]) : 0, mag);
+  const int B = argc > 1 ? atoi(argv[1]) : 128;
+  run(B, 240, 320, 64, 64, 0, 1, mag);      // conv2a
+  run(B, 240, 320, 64, 64, 1, 1, mag);      // conv2b + pool
+  run(B, 120, 160, 64, 128, 0, 1, mag);     // conv3a
+  run(B, 120, 160, 128, 128, 1, 1, mag);    // conv3b + pool
+  run(B, 60, 80, 128, 128, 0, 1, mag);      // conv4a / conv4b
+  run(B, 60, 80, 128, 512, 0, 1, mag);      // convPa | convDa
+  run(3, 37, 53, 64, 64, 1, 0, mag);        // ragged, NHWC, odd pooled size
+  run(2, 49, 48, 128, 64, 0, 0, mag);
+  return 0;
+}

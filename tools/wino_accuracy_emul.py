@@ -41,8 +41,33 @@ def lin(mat, x, dim):
     return torch.stack(rows).movedim(0, dim)
 
 
-def wino_conv(x, w, b, mh, mw, dt=torch.float32):
-    """x (B,C,H,W), w (Co,Ci,3,3) folded, pad 1.  Output tiles mh x mw."""
+def planes_f16(t, n, per_image=False):
+    """t (fp32) as n fp16 planes of t * s, s = the power of two that brings max |t| (of the tensor, or of every image t[b]) to
+    [2^13, 2^14) -- attention_x3.hip's FmtH2 (round 4).  Returns the planes as fp32 tensors and 1 / s."""
+    amax = t.abs().amax(dim=tuple(range(1, t.dim())), keepdim=True) if per_image else t.abs().max()
+    s = torch.exp2(13 - torch.floor(torch.log2(amax.double().clamp_min(1e-30)))).to(torch.float32)
+    r, out = (t * s).double(), []
+    for _ in range(n):
+        h = r.to(torch.float32).to(torch.float16)
+        out.append(h.to(torch.float32))
+        r = r - h.double()
+    return out, 1.0 / s
+
+
+PRODUCTS = {2: ((0, 0), (0, 1), (1, 0)), 3: ((0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (2, 0))}
+
+
+def direct_f16(x, w, b, n=2):
+    """the direct convolution with both operands as n fp16 planes (n = 2: three plane products, n = 3: six)"""
+    xp, xs = planes_f16(x, n, per_image=True)
+    wp, ws = planes_f16(w, n)
+    y = sum(F.conv2d(xp[i], wp[j], None, padding=1) for i, j in PRODUCTS[n])
+    return y * xs * ws + b[None, :, None, None]
+
+
+def wino_conv(x, w, b, mh, mw, dt=torch.float32, f16_planes=0):
+    """x (B,C,H,W), w (Co,Ci,3,3) folded, pad 1.  Output tiles mh x mw.  f16_planes = n: the transformed operands V and U as n fp16
+    planes each (PRODUCTS[n] plane products, fp32 accumulation)."""
     B, C, H, W = x.shape
     Hp, Wp = -(-H // mh) * mh, -(-W // mw) * mw
     xp = F.pad(x, (1, 1 + Wp - W, 1, 1 + Hp - H))
@@ -50,7 +75,12 @@ def wino_conv(x, w, b, mh, mw, dt=torch.float32):
     d = xp.unfold(2, th, mh).unfold(3, tw, mw)               # (B,C,ny,nx,th,tw)
     V = lin(BT[mw], lin(BT[mh], d, 4), 5)
     U = torch.from_numpy(np.einsum("ik,ockl,jl->ocij", G[mh], w.double().numpy(), G[mw])).to(dt)     # host, float64 -> fp32
-    M = torch.einsum("bcyxij,ocij->boyxij", V.to(dt), U)
+    if f16_planes:
+        Vp, vs = planes_f16(V, f16_planes, per_image=True)
+        Up, us = planes_f16(U, f16_planes)
+        M = sum(torch.einsum("bcyxij,ocij->boyxij", Vp[i], Up[j]) for i, j in PRODUCTS[f16_planes]) * vs * us
+    else:
+        M = torch.einsum("bcyxij,ocij->boyxij", V.to(dt), U)
     Y = lin(AT[mw], lin(AT[mh], M, 4), 5)                     # (B,Co,ny,nx,mh,mw)
     Y = Y.permute(0, 1, 2, 4, 3, 5).reshape(B, -1, Hp, Wp)[:, :, :H, :W]
     return Y + b.to(dt)[None, :, None, None]
@@ -93,7 +123,11 @@ def main():
     forms = {"direct fp32 (torch)": lambda x, w, b: F.conv2d(x, w, b, padding=1),
              "F(2x4,3x3)": lambda x, w, b: wino_conv(x, w, b, 2, 4),
              "F(4x4,3x3)": lambda x, w, b: wino_conv(x, w, b, 4, 4),
-             "F(2x2,3x3)": lambda x, w, b: wino_conv(x, w, b, 2, 2)}
+             "F(2x2,3x3)": lambda x, w, b: wino_conv(x, w, b, 2, 2),
+             "F(2x4), V U 2 x fp16": lambda x, w, b: wino_conv(x, w, b, 2, 4, f16_planes=2),
+             "F(2x4), V U 3 x fp16": lambda x, w, b: wino_conv(x, w, b, 2, 4, f16_planes=3),
+             "direct, 2 x fp16": lambda x, w, b: direct_f16(x, w, b, 2),
+             "direct, 3 x fp16": lambda x, w, b: direct_f16(x, w, b, 3)}
     for name, fn in forms.items():
         out = forward(x, sd, fn)
         cells = []
