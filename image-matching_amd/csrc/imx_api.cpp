@@ -93,6 +93,7 @@ struct imx_handle_s {
   int upload_net = 0;                    // net whose finalize is running (upload() files allocations under it)
   // SuperPoint
   float *w1 = nullptr, *b1 = nullptr;
+  float c1a_l1 = 0.f, c1a_bmax = 0.f;
   ConvW conv[8];   // conv1b, 2a, 2b, 3a, 3b, 4a, 4b, heads (convPa | convDa)
   GemmW pb, db;
   // SuperGlue
@@ -418,6 +419,15 @@ int finalize_superpoint(imx_handle_t h) {
     h->w1 = upload(h, w);
     h->b1 = upload(h, b);
     if (!h->w1 || !h->b1) return fail(h, "weight upload failed (conv1a)");
+    // |conv1a output| <= max|image patch| * c1a_l1 + c1a_bmax (conv1ab_wino24h.hip's per-tile scale)
+    h->c1a_l1 = 0.f; h->c1a_bmax = 0.f;
+    for (int c = 0; c < 64; ++c) {
+      float l1 = 0.f;
+      for (int t = 0; t < 9; ++t) l1 += std::fabs(w[t * 64 + c]);
+      h->c1a_l1 = std::max(h->c1a_l1, l1);
+      h->c1a_bmax = std::max(h->c1a_bmax, std::fabs(b[c]));
+    }
+    h->c1a_l1 = std::max(h->c1a_l1, 1e-30f);
   }
   const int cin[8] = {1, 64, 64, 64, 64, 128, 128, 128}, cout[8] = {64, 64, 64, 64, 128, 128, 128, 128};
   for (int i = 1; i < 8; ++i)
@@ -639,6 +649,7 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
       a.amax_out = last ? nullptr : amax + (size_t)li * 256;
       a.amax_in = li > 0 ? amax + (size_t)(li - 1) * 256 : nullptr;
       a.wuh = w.wuh; a.u_scale_inv = w.su_inv;
+      a.c1a_l1 = h->c1a_l1; a.c1a_bmax = h->c1a_bmax;
     }
     a.in_blocked = (blocked && !first) ? 1 : 0;
     a.out_blocked = (blocked && !last) ? 1 : 0;
@@ -649,7 +660,8 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
     const bool wino = !a.first && !h->opt.conv_direct && conv3x3_wino24_supported(a);
     const bool winoh = wino && amax && conv3x3_wino24h_supported(a);
     if (amax && !fused1 && !winoh) return fail(h, "%s: the fp16-plane Winograd chain needs every layer to take part (internal)", name);
-    RUN(name, fused1 ? launch_conv1ab_wino24(a, s) : winoh ? launch_conv3x3_wino24h(a, s) : wino ? launch_conv3x3_wino24(a, s) : launch_conv3x3(a, s));
+    const bool fused1h = fused1 && amax && conv1ab_wino24h_supported(a);
+    RUN(name, fused1h ? launch_conv1ab_wino24h(a, s) : fused1 ? launch_conv1ab_wino24(a, s) : winoh ? launch_conv3x3_wino24h(a, s) : wino ? launch_conv3x3_wino24(a, s) : launch_conv3x3(a, s));
     return 0;
   };
   if (conv("conv1ab_pool", h->conv[0], img0, a1, H, W, true, true)) return -1;

@@ -68,11 +68,15 @@ struct ConvArgs {
   float u_scale_inv;
   const unsigned* amax_in;
   unsigned* amax_out;
+  // conv1ab_wino24h.hip: the largest column L1 norm of the folded conv1a weights and the largest |bias| (bound of conv1a's outputs per unit of |image|)
+  float c1a_l1, c1a_bmax;
 };
 // Cin % 16 == 0, Cout % 64 == 0.
 hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);       // direct form (conv3x3.hip)
 // first && pool, Cin == Cout == 64.
 hipError_t launch_conv1ab_wino24(const ConvArgs& a, hipStream_t s); // fused conv1a + conv1b (Winograd F(2x4,3x3)) + pool
+bool conv1ab_wino24h_supported(const ConvArgs& a);                   // + wuh, c1a_l1
+hipError_t launch_conv1ab_wino24h(const ConvArgs& a, hipStream_t s); // the same with conv1b's products on the fp16 matrix pipe
 // Cin % 64 == 0, Cout % 64 == 0, not first.
 bool conv3x3_wino24_supported(const ConvArgs& a);                   // false (e.g. an image of >= 2 GB per layer): callers fall back to the direct form
 hipError_t launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s); // Winograd F(2x4,3x3), persistent, in-stream transform

@@ -203,6 +203,7 @@ def test_every_conv_form_vs_reference_golden(monkeypatch, mode, form):
         forms = {r[0]: r[3] for r in eng.timing_report(forms=True)}
         eng.set_timing(False)
         assert forms["conv3b_pool"].startswith(form) and forms["convPaDa"].startswith(form), forms
+        assert forms["conv1ab_pool"] == {"direct": "conv3x3_direct:f32", "wino32": "conv1ab_wino24:f32", "wino": "conv1ab_wino24h:f16x2"}[mode], forms
         util.assert_close(_nchw(eng.fetch("x4")), g["x4"], f"x4 ({mode})")
         util.assert_close(_nchw(eng.fetch("semi")), g["semi"], f"semi ({mode})")
 

@@ -2,7 +2,8 @@
 // v_mfma_f32_16x16x32_f16) against conv3x3_wino24 (the same on the fp32 MFMA) on SuperPoint's layer shapes at C3's batch: times both,
 // compares them with each other and with a float64 direct convolution of sample pixels, checks the per-image output maxima.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -Iinclude -x hip tools/ubench/conv_h_bench.cpp \
-//         image-matching_amd/csrc/conv3x3_wino24.hip image-matching_amd/csrc/conv3x3_wino24h.hip -o tools/ubench/conv_h_bench
+//         image-matching_amd/csrc/conv3x3_wino24.hip image-matching_amd/csrc/conv3x3_wino24h.hip image-matching_amd/csrc/conv1ab_wino24.hip \
+//         image-matching_amd/csrc/conv1ab_wino24h.hip -o tools/ubench/conv_h_bench
 //   usage: conv_h_bench [B H W Cin Cout pool blocked]     (default: every layer of the stack, B = 128)
 #include "../../image-matching_amd/csrc/imx_kernels.h"
 #include "../../image-matching_amd/csrc/wino24_pack.h"
@@ -112,8 +113,66 @@ static int run(int B, int H, int W, int Cin, int Cout, int pool, int blocked, fl
   return 0;
 }
 
+// the fused first layer: conv1ab_wino24h against conv1ab_wino24 (outputs against each other and their per-image maxima)
+static int run_first(int B, int H, int W, float mag) {
+  const int Ho = H / 2, Wo = W / 2, C = 64;
+  std::vector<float> im((size_t)B * H * W), w1(9 * 64), b1(64), w((size_t)9 * C * C), bias(C);
+  srand(7);
+  auto rnd = []() { return rand() / (float)RAND_MAX; };
+  for (auto& v : im) v = rnd() * mag;
+  for (auto& v : w1) v = (rnd() - 0.5f) * 0.8f;
+  for (auto& v : b1) v = (rnd() - 0.5f) * 0.3f;
+  for (auto& v : w) v = (rnd() - 0.5f) * 0.12f;
+  for (auto& v : bias) v = (rnd() - 0.5f) * 0.2f;
+  float l1 = 0, bmax = 0;
+  for (int c = 0; c < 64; ++c) { float t = 0; for (int k = 0; k < 9; ++k) t += fabsf(w1[k * 64 + c]); l1 = fmaxf(l1, t); bmax = fmaxf(bmax, fabsf(b1[c])); }
+  const std::vector<float> u32 = wino24_transform(w, C, C);
+  float su_inv = 0;
+  const std::vector<uint16_t> uh = wino24h_pack(w, C, C, &su_inv);
+  float *dim_, *dw1, *db1, *dw32, *db, *dout32, *douth; void* duh; unsigned* damax_out;
+  hipMalloc(&dim_, im.size() * 4); hipMalloc(&dw1, w1.size() * 4); hipMalloc(&db1, 256); hipMalloc(&dw32, u32.size() * 4); hipMalloc(&db, 256); hipMalloc(&duh, uh.size() * 2);
+  hipMalloc(&dout32, (size_t)B * Ho * Wo * C * 4); hipMalloc(&douth, (size_t)B * Ho * Wo * C * 4); hipMalloc(&damax_out, 1024);
+  hipMemcpy(dim_, im.data(), im.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dw1, w1.data(), w1.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(db1, b1.data(), 256, hipMemcpyHostToDevice); hipMemcpy(dw32, u32.data(), u32.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(db, bias.data(), 256, hipMemcpyHostToDevice); hipMemcpy(duh, uh.data(), uh.size() * 2, hipMemcpyHostToDevice);
+  ConvArgs a{};
+  a.in = dim_; a.in2 = dim_; a.split = B; a.wu24 = dw32; a.bias = db; a.w1 = dw1; a.b1 = db1; a.B = B; a.H = H; a.W = W; a.Cin = 64; a.Cout = 64;
+  a.relu = 1; a.pool = 1; a.first = 1; a.out_blocked = 1; a.wuh = duh; a.u_scale_inv = su_inv; a.c1a_l1 = l1; a.c1a_bmax = bmax; a.amax_out = damax_out;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float ms[2] = {0, 0};
+  std::vector<unsigned> am[2];
+  for (int form = 0; form < 2; ++form) {
+    a.out = form ? douth : dout32;
+    hipMemset(damax_out, 0, 1024);
+    auto go = [&]() { return form ? launch_conv1ab_wino24h(a, 0) : launch_conv1ab_wino24(a, 0); };
+    hipError_t err = go();
+    hipDeviceSynchronize();
+    if (err != hipSuccess || hipGetLastError() != hipSuccess) { printf("launch failed (first, form %d): %s\n", form, hipGetErrorString(err)); return 1; }
+    am[form].resize(256); hipMemcpy(am[form].data(), damax_out, 1024, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 2; ++i) go();
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 5; ++i) go();
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms[form], e0, e1);
+    ms[form] /= 5;
+  }
+  std::vector<float> o32((size_t)B * Ho * Wo * C), oh(o32.size());
+  hipMemcpy(o32.data(), dout32, o32.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(oh.data(), douth, oh.size() * 4, hipMemcpyDeviceToHost);
+  double dmax = 0, omax = 0; size_t nan = 0;
+  for (size_t i = 0; i < oh.size(); ++i) {
+    if (!(oh[i] == oh[i])) { ++nan; continue; }
+    dmax = fmax(dmax, fabs((double)oh[i] - o32[i])); omax = fmax(omax, fabs((double)o32[i]));
+  }
+  int bad = 0;
+  for (int b = 0; b < B && b < 256; ++b) if (am[0][b] != am[1][b]) { float x, y; memcpy(&x, &am[0][b], 4); memcpy(&y, &am[1][b], 4); if (fabsf(x - y) > 1e-4f * fabsf(x)) ++bad; }
+  printf("first layer %dx%d B=%d | fp32 wino %8.1f us  f16x2 wino %8.1f us (x%.2f) | max |h - f32| %.2e of %.2e%s | per-image maxima differing by > 1e-4: %d\n",
+         H, W, B, ms[0] * 1e3, ms[1] * 1e3, ms[0] / ms[1], dmax, omax, nan ? " NaN!" : "", bad);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const float mag = getenv("MAG") ? (float)atof(getenv("MAG")) : 3.f;
+  if (argc > 4 && !strcmp(argv[1], "first")) return run_first(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), getenv("MAG") ? mag : 1.f);
   if (argc > 5) return run(atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), argc > 6 ? atoi(argv[6]) : 0, argc > 7 ? atoi(argv[7]) : 0, mag);
   const int B = argc > 1 ? atoi(argv[1]) : 128;
   run(B, 240, 320, 64, 64, 0, 1, mag);      // conv2a
@@ -122,6 +181,8 @@ int main(int argc, char** argv) {
   run(B, 120, 160, 128, 128, 1, 1, mag);    // conv3b + pool
   run(B, 60, 80, 128, 128, 0, 1, mag);      // conv4a / conv4b
   run(B, 60, 80, 128, 512, 0, 1, mag);      // convPa | convDa
+  run_first(B, 480, 640, 1.f);
+  run_first(3, 123, 165, 1.f);              // ragged
   run(3, 37, 53, 64, 64, 1, 0, mag);        // ragged, NHWC, odd pooled size
   run(2, 49, 48, 128, 64, 0, 0, mag);
   return 0;
