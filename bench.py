@@ -497,11 +497,16 @@ def roofline_block(rows, wl, B, steps, dt, lib_build, workload):
         rf["traffic_note"] = traffic_note
     if bound == "mfma":
         rf["pipe"] = PIPES.get(pipe_of[name], PIPES["f32"])[0]
-    if abs(algorithmic - achieved) > 1e-9 and pipe_of[name] not in SPLIT_PIPES:
+    if abs(algorithmic - achieved) > 1e-9 and (pipe_of[name] not in SPLIT_PIPES or name.startswith("conv")):
         rf["algorithmic"] = {
-            "rate": round(algorithmic, 3), "ratio_to_peak": round(algorithmic / peak, 4),
+            "rate": round(algorithmic, 3), "ratio_to_peak": round(algorithmic / peak, 4), "ratio_to_fp32_mfma_peak": round(algorithmic / PEAK_MFMA_F32_TFLOPS, 4),
             "note": "reference direct-form FLOPs / launch time; the kernel executes fewer multiplies (Winograd F(2x4,3x3)), "
                     "so this ratio may exceed 1 and is NOT a utilisation"}
+    if bound == "mfma" and pipe_of[name] == "f16x2" and name.startswith("conv"):
+        rf["frac_note"] = ("round 4 moved this kernel's products from the fp32 MFMA (157.3 TFLOP/s) to three fp16 plane products on the 16-bit pipe "
+                           "(2500 TFLOP/s): `achieved` counts the executed plane products against THAT peak, so `frac` fell while the launch got shorter "
+                           "(r04_v9: 10.4 ms at 0.647 of the fp32 peak); the kernel is now bound by the L2 -> register stream of the transformed weights "
+                           "and by VALU issue (transform + split), DESIGN.md section 5h")
     # whole-pair view: time the matrix pipes would need at their dense peaks (fp32 MFMA 157.3, bf16 MFMA 2500 TFLOP/s) / step time
     per_step = {n: e[0] / steps for n, e in by.items()}          # launches per step
     step_s = dt / steps
@@ -535,11 +540,13 @@ def roofline_block(rows, wl, B, steps, dt, lib_build, workload):
 def arithmetic_text(rf):
     x3 = rf.get("bf16x3_kernels", []) if rf else []
     h2 = rf.get("f16x2_kernels", []) if rf else []
-    return ("fp32 in, fp32 accumulate, fp32 out everywhere.  On the fp32 MFMA: the 3x3 convolutions (Winograd F(2x4,3x3)) and score_gemm.  "
+    f32k = sorted(k for k, v in (rf.get("kernels", {}) if rf else {}).items() if str(v.get("form", "")).endswith(":f32"))
+    return ("fp32 in, fp32 accumulate, fp32 out everywhere.  The 3x3 convolutions are Winograd F(2x4,3x3).  On the fp32 MFMA: "
+            + (", ".join(f32k) if f32k else "nothing") + " and score_gemm.  "
             + (f"On the bf16 MFMA, each fp32 product carried as six bf16 term products (x = h + m + l exactly; error vs float64 below the "
                f"fp32 MFMA's: profiles/r02_mfma_bf16x3.txt), as reported by the library for this run: {', '.join(x3)}.  " if x3 else "")
             + (f"On the fp16 MFMA, each fp32 product carried as three fp16 term products of two-plane operands (x s = h + m, 22 bits, s a power of two "
-               f"from the tensor's maximum; error vs float64 below the fp32 MFMA's: tools/ubench/attn_x3_bench.cpp): {', '.join(h2)}.  " if h2 else "")
+               f"from the tensor's maximum; error vs float64 below the fp32 MFMA's: tools/ubench/attn_x3_bench.cpp, conv_h_bench.cpp): {', '.join(h2)}.  " if h2 else "")
             + "imx_set_option(h, 'mfma', 'f32') keeps every product on the fp32 MFMA (the parity tests hold both to the same bar).  "
               "On these default (heavy-tailed) weights |Z_hip - Z_reference| reaches ~1e-3 where the reference's own fp32 result is 2e-4..3e-3 from float64 "
               "(parity_in_run: match indices differ only on reference margins below that noise); on the trained-model-like weight set every element of "

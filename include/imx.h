@@ -219,8 +219,11 @@ const char* imx_timing_form(imx_handle_t h, int index);
  *                           the attention (grids of <= 256 workgroups) and one launch per GNN layer tail; "off" never (results
  *                           then do not depend on the batch size bit for bit); "on" whenever the shape allows; "unfused" = "on" with the GNN layer tail as three
  *                           launches instead of one (same bytes: the A/B reference of the fused latency kernel);
- *   "conv"           "wino" (default) Winograd F(2x4,3x3) on the fp32 MFMA; "direct" the direct implicit-GEMM kernel for every 3x3
- *                           layer (the fallback for shapes Winograd rejects, and the A/B reference);
+ *   "conv"           "wino" (default) Winograd F(2x4,3x3) with its products on the fp16 matrix pipe: both transformed operands as two
+ *                           fp16 planes scaled by a power of two (per tile in the fused first layer, per image -- from the producing
+ *                           layer's maximum -- in the others), three plane products ("mfma" = "x3" only); "wino32" the same with every
+ *                           product on the fp32 MFMA (the A/B reference); "direct" the direct implicit-GEMM kernel for every 3x3 layer
+ *                           (the fallback for shapes Winograd rejects);
  *   "gnn_tail"       "auto" (default) = "fused": wherever the throughput forms run (more than 4096 feature rows) the tail of a GNN layer
  *                           (mlp.0 -> mlp.3 + residual -> the next layer's q|k|v or final_proj) is ONE launch on the bf16 pipe
  *                           (descriptor_dim 128); "unfused" three launches (the A/B reference: same products, another summation order);
