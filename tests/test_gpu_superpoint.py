@@ -208,6 +208,47 @@ def test_every_conv_form_vs_reference_golden(monkeypatch, mode, form):
         util.assert_close(_nchw(eng.fetch("semi")), g["semi"], f"semi ({mode})")
 
 
+def test_fp16_plane_convolutions_on_inputs_that_stress_their_scales():
+    """conv = wino (round 4): the Winograd products run on two fp16 planes per operand, scaled by powers of two taken from the tile's image
+    patch (first layer) and from the producing layer's per-image maximum (the others).  Inputs that stress exactly that: an all-black
+    image (maxima of zero / bias-only activations), images of very different magnitudes in ONE batch (x 255, x 1e-3: every image
+    carries its own scale), an image that is black except for one bright corner (tiles whose own maximum is zero next to one that is
+    not), and a batch of 260 images (the maxima live in 256 slots: images 256.. share slots with 0..).  Dense semi / descriptors against
+    the oracle, 1e-4 of each tensor's range."""
+    from oracle import superpoint_ref
+    from image_matching_amd import _lib as L
+    from image_matching_amd.engine import Engine
+    H, W, d = 72, 104, 128
+    cfg = util.sp_config(d, 64)
+    sd = util.sp_sd(d)
+    eng = Engine(cfg, util.sg_config(d), "cuda")
+    eng.load_state_dict(L.NET_SUPERPOINT, sd)
+    base = [util.pair(900 + i, H, W)[i & 1] for i in range(6)]
+    corner = torch.zeros(1, 1, H, W)
+    corner[..., :9, :13] = base[4][..., :9, :13]
+    xs = torch.cat([torch.zeros(1, 1, H, W), base[0], base[1] * 255.0, base[2] * 1e-3, corner, base[3]])
+    eng.timing_reset()
+    eng.set_timing(True)
+    semi, desc = eng.superpoint_dense(xs.cuda())
+    forms = {r[0]: r[3] for r in eng.timing_report(forms=True)}
+    eng.set_timing(False)
+    assert forms["conv1ab_pool"] == "conv1ab_wino24h:f16x2" and forms["conv4b"] == "conv3x3_wino24h:f16x2", forms
+    ref = superpoint_ref.superpoint_forward(xs, sd, cfg, return_dense=True)
+    for b in range(xs.shape[0]):
+        for name, mine, want in (("semi", semi[b].cpu().numpy(), ref["semi"][b].numpy()), ("desc", desc[b].cpu().numpy(), ref["desc"][b].numpy())):
+            scale = max(1.0, float(np.abs(want).max()))
+            assert np.isfinite(mine).all(), f"image {b} {name}: non-finite values"
+            assert np.abs(mine - want).max() <= 1e-4 * scale, f"image {b} {name}: {np.abs(mine - want).max():.3e} vs range {scale:.3e}"
+    big = torch.cat([base[i % 6] * (1.0 + (i % 7)) for i in range(260)])
+    semi, desc = eng.superpoint_dense(big.cuda())
+    pick = [0, 5, 255, 256, 259]
+    ref = superpoint_ref.superpoint_forward(big[pick], sd, cfg, return_dense=True)
+    for k, b in enumerate(pick):
+        scale = max(1.0, float(ref["semi"][k].abs().max()))
+        assert np.abs(semi[b].cpu().numpy() - ref["semi"][k].numpy()).max() <= 1e-4 * scale, f"image {b} of 260: semi"
+        util.assert_close(desc[b].cpu().numpy(), ref["desc"][k].numpy(), f"image {b} of 260: descriptors")
+
+
 @pytest.mark.parametrize("radius", [1, 2, 3, 4, 5, 6, 9, 13])
 def test_nms_every_radius_bit_exact_vs_oracle(radius):
     """simple_nms is compare-only, so both forms (radius <= 4: the staged three-kernel form with bit-row masks; any other radius:
