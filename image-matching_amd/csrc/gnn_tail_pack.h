@@ -15,6 +15,7 @@
 //     2 images  mlp.3,  4 k-steps each              k-steps (b, h2) of this half's hidden blocks, 4 output blocks
 //   6 images    next product (q|k|v: 3 passes of 128 output channels; final_proj: 1 pass = 2 images), 4 k-steps (ob, h2) each
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -88,6 +89,93 @@ inline std::vector<uint16_t> gnn_tail_pack(const float* w1, int ld1, const float
               put(img, t, blk, lane, j, w3[(size_t)k * ld3 + c]);
             }
       }
+  return out;
+}
+
+// gnn_tail_h2.hip: the same stream with every weight as TWO fp16 planes of w s, s = the power of two that brings its matrix's largest
+// |value| to [2^13, 2^14); images of [step][block][plane (2)][lane][8 halves] (8 KB per k-step).  Also returns what the kernel's
+// bounds need: the reciprocals of the three scales and the largest column L1 norm of w1 / w2 (a column = one output channel).
+struct GnnTailH2Consts { float w1_inv, w2_inv, w3_inv, l1_1, l1_2; };
+inline uint16_t gt_f16_rne(float x) {      // fp32 -> fp16 bit pattern, round to nearest even (normal range and subnormals; the scaled weights never overflow)
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  u &= 0x7fffffffu;
+  if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+  if (u < 0x38800000u) {
+    if (u < 0x33000000u) return (uint16_t)sign;
+    const int e = (int)(u >> 23);
+    const uint32_t m = (u & 0x7fffffu) | 0x800000u;
+    const int sh = 126 - e;
+    const uint32_t q = m >> sh, rem = m & ((1u << sh) - 1u), half = 1u << (sh - 1);
+    return (uint16_t)(sign | (q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u)));
+  }
+  const uint32_t r = u + 0xfffu + ((u >> 13) & 1u);
+  return (uint16_t)(sign | ((r - 0x38000000u) >> 13));
+}
+inline float gt_f16_f(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  uint32_t u;
+  float f;
+  if (e == 0) { f = (float)m * 5.9604644775390625e-8f; memcpy(&u, &f, 4); u |= sign; }
+  else u = sign | ((e + 112u) << 23) | (m << 13);
+  memcpy(&f, &u, 4);
+  return f;
+}
+inline std::vector<uint16_t> gnn_tail_pack_h2(const float* w1, int ld1, const float* w2, int ld2, const float* w3, int ld3, int d, int n3,
+                                              GnnTailH2Consts* consts) {
+  auto scale_of = [](const float* w, int rows, int cols, int ld, float* l1) {
+    double mx = 0.0, best = 0.0;
+    for (int c = 0; c < cols; ++c) {
+      double acc = 0.0;
+      for (int k = 0; k < rows; ++k) { const double a = std::fabs((double)w[(size_t)k * ld + c]); acc += a; if (a > mx) mx = a; }
+      if (acc > best) best = acc;
+    }
+    if (l1) *l1 = (float)best;
+    int e = 0;
+    if (mx > 0) std::frexp(mx, &e);
+    return std::ldexp(1.0, 14 - e);
+  };
+  const double s1 = scale_of(w1, 2 * d, 2 * d, ld1, &consts->l1_1), s2 = scale_of(w2, 2 * d, d, ld2, &consts->l1_2), s3 = scale_of(w3, d, n3, ld3, nullptr);
+  consts->w1_inv = (float)(1.0 / s1); consts->w2_inv = (float)(1.0 / s2); consts->w3_inv = (float)(1.0 / s3);
+  const int per_step = 4 * 2 * 64 * 8;                                  // 16-bit values per k-step
+  const int n_step = 2 * (16 + 8) + 8 * (n3 / d);
+  std::vector<uint16_t> out((size_t)n_step * per_step, 0);
+  auto put = [&](size_t step, int block, int lane, int j, double v) {
+    const float x = (float)v;
+    const uint16_t h = gt_f16_rne(x), m = gt_f16_rne(x - gt_f16_f(h));
+    out[step * per_step + (((size_t)block * 2 + 0) * 64 + lane) * 8 + j] = h;
+    out[step * per_step + (((size_t)block * 2 + 1) * 64 + lane) * 8 + j] = m;
+  };
+  size_t step = 0;
+  for (int half = 0; half < 2; ++half) {
+    for (int s = 0; s < 16; ++s, ++step)               // mlp.0': k-step s covers input k = 32 (s / 2) + 16 kb + 8 (s & 1) + j  ([x | att] order)
+      for (int blk = 0; blk < 4; ++blk)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int k = 32 * (s / 2) + 16 * (lane >> 5) + 8 * (s & 1) + j, c = 32 * (4 * half + blk) + (lane & 31);
+            put(step, blk, lane, j, (double)w1[(size_t)k * ld1 + c] * s1);
+          }
+    for (int s = 0; s < 8; ++s, ++step) {              // mlp.3: k-steps (b, h2) of this half's hidden blocks
+      const int b = 4 * half + s / 2, h2 = s & 1;
+      for (int blk = 0; blk < 4; ++blk)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int k = 32 * b + 16 * h2 + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5), c = 32 * blk + (lane & 31);
+            put(step, blk, lane, j, (double)w2[(size_t)k * ld2 + c] * s2);
+          }
+    }
+  }
+  for (int pass = 0; pass < n3 / d; ++pass)
+    for (int s = 0; s < 8; ++s, ++step) {              // next product: k-steps (ob, h2) over x' channels
+      const int ob = s / 2, h2 = s & 1;
+      for (int blk = 0; blk < 4; ++blk)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int k = 32 * ob + 16 * h2 + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5), c = d * pass + 32 * blk + (lane & 31);
+            put(step, blk, lane, j, (double)w3[(size_t)k * ld3 + c] * s3);
+          }
+    }
   return out;
 }
 

@@ -61,6 +61,9 @@ struct GemmW {
 struct GnnLayer {
   GemmW qkv, merge, mlp1, mlp2;
   float* tail_stream = nullptr;    // gnn_tail_pack() of (mlp.0', mlp.3, the NEXT layer's q|k|v or final_proj): gnn_tail_x3.hip, d = 128 only
+  void* tail_stream_h2 = nullptr;  // gnn_tail_pack_h2() of the same three matrices (two fp16 planes): gnn_tail_h2.hip
+  GnnTailH2Consts h2c{};           // reciprocal weight scales and column L1 norms
+  float bmax_1 = 0.f, bmax_2 = 0.f;   // largest |bias| of mlp.0' and mlp.3
 };
 struct Tap {
   const void* p;
@@ -544,6 +547,7 @@ int finalize_superglue(imx_handle_t h) {
           wf[(size_t)(d + kk) * np1 + n] = (float)acc;
         }
       if (upload_gemm(h, L.mlp1, wf, bf, 2 * d, 2 * d, np1, (p + ".mlp.0 (+merge)").c_str())) return -1;
+      for (int n = 0; n < 2 * d; ++n) L.bmax_1 = std::max(L.bmax_1, std::fabs(bf[n]));
       host_w1.push_back(wf);
       host_ld1.push_back(np1);
     }
@@ -552,6 +556,7 @@ int finalize_superglue(imx_handle_t h) {
       int np2 = 0;
       build_gemm_host(raw, p + ".mlp.3", "", 2 * d, d, nullptr, w2, b2, np2);
       if (upload_gemm(h, L.mlp2, w2, b2, 2 * d, d, np2, (p + ".mlp.3").c_str())) return -1;
+      for (int n = 0; n < d; ++n) L.bmax_2 = std::max(L.bmax_2, std::fabs(b2[n]));
       host_w2.push_back(w2);
       host_ld2.push_back(np2);
     }
@@ -571,6 +576,10 @@ int finalize_superglue(imx_handle_t h) {
       memcpy(bits.data(), st.data(), st.size() * sizeof(uint16_t));
       h->layers[l].tail_stream = upload(h, bits);
       if (!h->layers[l].tail_stream) return fail(h, "weight upload failed (layer %d tail stream)", l);
+      h->layers[l].tail_stream_h2 = upload_u16(h, gnn_tail_pack_h2(host_w1[l].data(), host_ld1[l], host_w2[l].data(), host_ld2[l],
+                                                                   last ? wfin.data() : host_qkv[l + 1].data(), last ? npf : 3 * d, d, last ? d : 3 * d,
+                                                                   &h->layers[l].h2c));
+      if (!h->layers[l].tail_stream_h2) return fail(h, "weight upload failed (layer %d fp16 tail stream)", l);
     }
   }
   return 0;
@@ -820,12 +829,17 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   // "attention" = f16x2: the two-plane fp16 form of the throughput attention scales q, k, v by powers of two taken from their maxima
   // over the valid rows of every (side, pair) -- [2 B][4] words per layer, zeroed once per forward; written by the fused layer tail that produces the layer's
   // q|k|v (gnn_tail_x3's epilogue), else by qkv_amax (layer 0, whose q|k|v is a plain GEMM; the unfused A/B forms)
+  // (the same buffer carries, behind the q / k / v tables, one word per (layer, side, pair) for max |x|: gnn_tail_h2.hip's bounds)
   unsigned* amax = nullptr;
+  unsigned* amax_x = nullptr;
   if (h->opt.attention != 0 && !h->opt.mfma_f32) {
-    WS(am, unsigned, "sg.amax", h->layers.size() * 2 * B * 16);
-    HIP_OK(h, hipMemsetAsync(am, 0, h->layers.size() * 2 * B * 16, s));
+    const size_t nl = h->layers.size(), words = nl * 2 * B * 4 + (nl + 1) * 2 * B;
+    WS(am, unsigned, "sg.amax", words * 4);
+    HIP_OK(h, hipMemsetAsync(am, 0, words * 4, s));
     amax = am;
+    amax_x = am + nl * 2 * B * 4;
   }
+  bool have_amax_x = false;
   for (size_t l = 0; l < h->layers.size(); ++l) {
     const GnnLayer& L = h->layers[l];
     if (!have_next && gemm(h, s, "qkv_proj", L.qkv, x, d, d, nullptr, 0, 0, nullptr, 0, qkv, 3 * d, R, false)) return -1;
@@ -854,15 +868,30 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     }
     const bool tail_ok = !small_form && !h->opt.mfma_f32 && L.tail_stream && nx.Npad == nx.N && gnn_tail_x3_supported(ta);
     const bool tail = tail_ok && h->opt.gnn_tail != 0;
+    // "gnn_tail" = auto / fused: the same launch as three fp16 plane products (gnn_tail_h2.hip) where the two-plane attention runs (its
+    // v maxima bound att) -- the maxima of x come from the previous layer's tail, for layer 0 from rows_amax
+    bool tail_h2 = false;
+    if (tail && f16x2 && h->opt.gnn_tail != 2 && L.tail_stream_h2) {
+      ta.stream_h2 = L.tail_stream_h2;
+      ta.w1_inv = L.h2c.w1_inv; ta.w2_inv = L.h2c.w2_inv; ta.w3_inv = L.h2c.w3_inv;
+      ta.l1_1 = L.h2c.l1_1; ta.l1_2 = L.h2c.l1_2; ta.bmax_1 = L.bmax_1; ta.bmax_2 = L.bmax_2;
+      ta.amax_x_in = amax_x + (size_t)2 * B * l; ta.amax_v = amax + 8 * B * l; ta.amax_x_out = last ? nullptr : amax_x + (size_t)2 * B * (l + 1);
+      ta.cross = c.gnn_layer_is_cross[l];
+      ta.n0 = sd[0].n; ta.n1 = sd[1].n; ta.B = B; ta.N0p = N0p; ta.N1p = N1p; ta.N0 = N0; ta.N1 = N1;
+      tail_h2 = gnn_tail_h2_supported(ta);
+      if (tail_h2 && !have_amax_x) RUN("rows_amax", launch_rows_amax(x, d, B, N0p, N1p, sd[0].n, sd[1].n, N0, N1, amax_x + (size_t)2 * B * l, s));
+    }
+    have_amax_x = false;
     if (small_form && h->opt.latency_forms != 2 && L.mlp1.Npad == 2 * d && L.mlp2.Npad == d && nx.Npad == nx.N && gnn_layer_small_supported(ga)) {
       RUN("gnn_layer", launch_gnn_layer_small(ga, s));
       have_next = !last;
       have_mdesc = last;
     } else if (tail) {
-      RUN("gnn_tail", launch_gnn_tail_x3(ta, s));
+      RUN("gnn_tail", tail_h2 ? launch_gnn_tail_h2(ta, s) : launch_gnn_tail_x3(ta, s));
       have_next = !last;
       have_mdesc = last;
       have_amax = ta.amax != nullptr;
+      have_amax_x = tail_h2 && !last;
     } else {
       if (gemm(h, s, "gnn_mlp1", L.mlp1, x, d, d, att, d, d, nullptr, 0, hid, 2 * d, R, true)) return -1;   // merge folded in
       if (gemm(h, s, "gnn_mlp2", L.mlp2, hid, 2 * d, 2 * d, nullptr, 0, 0, x, d, x, d, R, false)) return -1;
@@ -899,7 +928,7 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   return 0;
 }
 
-// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | wino32 | direct, "gnn_tail" = auto | fused | unfused, "attention" = auto | f16x2 | bf16x3.  Returns 0, or -1 for an unknown key / value.
+// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | wino32 | direct, "gnn_tail" = auto | fused | bf16x3 | unfused, "attention" = auto | f16x2 | bf16x3.  Returns 0, or -1 for an unknown key / value.
 int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
   Options& o = h->opt;
   if (key == "mfma") {
@@ -907,7 +936,8 @@ int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
   } else if (key == "latency_forms") {
     if (v == "auto") o.latency_forms = -1; else if (v == "off" || v == "0") o.latency_forms = 0; else if (v == "on" || v == "1") o.latency_forms = 1; else if (v == "unfused") o.latency_forms = 2; else return -1;
   } else if (key == "gnn_tail") {
-    if (v == "auto") o.gnn_tail = -1; else if (v == "unfused" || v == "0") o.gnn_tail = 0; else if (v == "fused" || v == "1") o.gnn_tail = 1; else return -1;
+    if (v == "auto") o.gnn_tail = -1; else if (v == "unfused" || v == "0") o.gnn_tail = 0; else if (v == "fused" || v == "1") o.gnn_tail = 1;
+    else if (v == "bf16x3") o.gnn_tail = 2; else return -1;
   } else if (key == "attention") {
     if (v == "auto") o.attention = -1; else if (v == "bf16x3" || v == "x3" || v == "0") o.attention = 0; else if (v == "f16x2" || v == "1") o.attention = 1; else return -1;
   } else if (key == "conv") {
@@ -1406,7 +1436,7 @@ int imx_set_option(imx_handle_t h, const char* key, const char* value) {
   return guarded(h, "imx_set_option", [&]() -> int {
     if (!h) return -1;
     if (!key || !value) return fail(h, "imx_set_option: null argument");
-    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino32|direct, gnn_tail = auto|fused|unfused, attention = auto|f16x2|bf16x3)", key, value);
+    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3)", key, value);
     return 0;
   });
 }
@@ -1419,7 +1449,7 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     if (k == "mfma") h->opt_text = o.mfma_f32 ? "f32" : "x3";
     else if (k == "latency_forms") h->opt_text = o.latency_forms < 0 ? "auto" : o.latency_forms == 2 ? "unfused" : o.latency_forms ? "on" : "off";
     else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : o.conv_f16 ? "wino" : "wino32";
-    else if (k == "gnn_tail") h->opt_text = o.gnn_tail < 0 ? "auto" : o.gnn_tail ? "fused" : "unfused";
+    else if (k == "gnn_tail") h->opt_text = o.gnn_tail < 0 ? "auto" : o.gnn_tail == 2 ? "bf16x3" : o.gnn_tail ? "fused" : "unfused";
     else if (k == "attention") h->opt_text = o.attention < 0 ? "auto" : o.attention ? "f16x2" : "bf16x3";
     else h->opt_text.clear();
     return h->opt_text.c_str();

@@ -15,8 +15,9 @@ struct Options {
   int latency_forms = -1;  // "latency_forms": -1 = "auto" (gemm_small for M <= 4096 rows, key-split attention for grids of
                            //         <= 256 workgroups, one launch per GNN layer tail), 0 = "off" (results do not depend on the batch size
                            //         bit for bit), 1 = "on", 2 = "unfused" (on, with the layer tail as three gemm_small launches: the A/B of the fusion)
-  int gnn_tail = -1;       // "gnn_tail": -1 = "auto" = 1 = "fused" (the fused layer tail gnn_tail_x3 wherever the throughput forms run, d = 128),
-                           //         0 = "unfused" (three gemm_x3 launches: the A/B of the fusion)
+  int gnn_tail = -1;       // "gnn_tail": -1 = "auto" = 1 = "fused" (one launch per layer tail wherever the throughput forms run, d = 128: gnn_tail_h2 --
+                           //         three fp16 plane products -- beside the two-plane attention, else gnn_tail_x3), 2 = "bf16x3" (gnn_tail_x3: six bf16
+                           //         plane products), 0 = "unfused" (three gemm_x3 launches: the A/B of the fusion)
   int attention = -1;      // "attention": -1 = "auto" = 1 = "f16x2" (attention_x3.hip with two fp16 planes per operand, three term products: needs
                            //         the q / k / v maxima, which the fused layer tail writes), 0 = "bf16x3" (three bf16 planes, six term products)
   int conv_direct = 0;     // "conv": 0 = "wino" / "wino32" (Winograd F(2x4,3x3); direct only for shapes it rejects), 1 = "direct"
@@ -228,9 +229,22 @@ struct GnnTailArgs {
   unsigned* amax;
   const int* n0; const int* n1;
   int B, N0p, N1p, N0, N1;
+  // gnn_tail_h2.hip (three fp16 plane products of two-plane operands): the weights as gnn_tail_pack_h2() wrote them, the reciprocals of the
+  // powers of two they were scaled by, the largest column L1 norms / |bias| of mlp.0' and mlp.3 (bounds of the hidden activations and
+  // of x'), the (side, pair) maxima of this layer's x (amax_x_in, [2 B] bit patterns) and of its attention's v (amax_v: the [2 B][4]
+  // table AttnArgs::amax of the same layer), whether that attention was a cross layer, and where the maxima of x' go (amax_x_out,
+  // [2 B] zeroed words, or null)
+  const void* stream_h2;
+  float w1_inv, w2_inv, w3_inv, l1_1, bmax_1, l1_2, bmax_2;
+  const unsigned* amax_x_in; const unsigned* amax_v; unsigned* amax_x_out;
+  int cross;
 };
 bool gnn_tail_x3_supported(const GnnTailArgs& a);
 hipError_t launch_gnn_tail_x3(const GnnTailArgs& a, hipStream_t s);
+bool gnn_tail_h2_supported(const GnnTailArgs& a);
+hipError_t launch_gnn_tail_h2(const GnnTailArgs& a, hipStream_t s);
+// max |x| over the valid rows of every (side, pair) of a [B (N0p + N1p)][d] tensor -> amax[2 B] (zeroed words), d = 128: layer 0's amax_x_in
+hipError_t launch_rows_amax(const float* x, int d, int B, int N0p, int N1p, const int* n0, const int* n1, int N0, int N1, unsigned* amax, hipStream_t s);
 
 // both products as six bf16 term products on the bf16 matrix pipe (attention_x3.hip): head dim 32 or 64
 bool attention_x3_supported(const AttnArgs& a);

@@ -224,9 +224,11 @@ const char* imx_timing_form(imx_handle_t h, int index);
  *                           layer's maximum -- in the others), three plane products ("mfma" = "x3" only); "wino32" the same with every
  *                           product on the fp32 MFMA (the A/B reference); "direct" the direct implicit-GEMM kernel for every 3x3 layer
  *                           (the fallback for shapes Winograd rejects);
- *   "gnn_tail"       "auto" (default) = "fused": wherever the throughput forms run (more than 4096 feature rows) the tail of a GNN layer
- *                           (mlp.0 -> mlp.3 + residual -> the next layer's q|k|v or final_proj) is ONE launch on the bf16 pipe
- *                           (descriptor_dim 128); "unfused" three launches (the A/B reference: same products, another summation order);
+ *   "gnn_tail"       "auto" (default) = "fused": wherever the throughput forms run (more than 4096 feature rows, descriptor_dim 128) the
+ *                           tail of a GNN layer (mlp.0 -> mlp.3 + residual -> the next layer's q|k|v or final_proj) is ONE launch: three fp16
+ *                           plane products of two-plane operands beside the two-plane attention (the operands' powers of two come from
+ *                           bounds: the (side, pair) maxima of x and v, the weights' column L1 norms), else six bf16 plane products;
+ *                           "bf16x3" the six-product launch; "unfused" three launches (the A/B reference: another summation order);
  *   "attention"      "auto" (default) = "f16x2": the throughput attention (head dims 32 / 64, "mfma" = "x3") cuts q, k, v and the softmax
  *                           weights into TWO fp16 planes (22 bits; every operand scaled by a power of two taken from the maximum of its
  *                           (side, pair) over the valid rows) and keeps three term products per k-step; "bf16x3" three bf16 planes and

@@ -417,7 +417,7 @@ def test_repeated_launches_of_the_timed_batch_are_bitwise_identical():
     ref = {k: v.clone() for k, v in m.match_batch(i0, i1, want_desc=True).items()}
     forms = {r[0]: r[3] for r in eng.timing_report(forms=True)}
     eng.set_timing(False)
-    assert forms["gnn_tail"] == "gnn_tail_x3:bf16x3" and forms["attention"] == "attention_h2:f16x2", forms
+    assert forms["gnn_tail"] == "gnn_tail_h2:f16x2" and forms["attention"] == "attention_h2:f16x2", forms
     for it in range(11):
         out = m.match_batch(i0, i1, want_desc=True)
         for k in ref:

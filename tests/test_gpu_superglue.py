@@ -175,7 +175,7 @@ def test_bad_option_is_refused_and_forms_are_reported():
         seen[(forms, mfma)] = {r[0]: r[3] for r in eng.timing_report(forms=True)}
         eng.set_timing(False)
     assert seen[("off", "x3")]["qkv_proj"] == "gemm_x3:bf16x3" and seen[("off", "x3")]["attention"] == "attention_h2:f16x2"
-    assert seen[("off", "x3")]["gnn_tail"] == "gnn_tail_x3:bf16x3" and "gnn_mlp1" not in seen[("off", "x3")]      # round 4: one launch per layer tail
+    assert seen[("off", "x3")]["gnn_tail"] == "gnn_tail_h2:f16x2" and "gnn_mlp1" not in seen[("off", "x3")]      # round 4: one launch per layer tail
     assert seen[("off", "f32")]["gnn_mlp1"] == "gemm_tiled:f32" and "gnn_tail" not in seen[("off", "f32")]
     assert seen[("off", "f32")]["qkv_proj"] == "gemm_tiled:f32" and seen[("off", "f32")]["attention"] == "attention:f32"
     assert seen[("on", "x3")]["qkv_proj"] == "gemm_small:f32" and seen[("on", "x3")]["attention"] == "attention_split:f32"
@@ -195,7 +195,7 @@ def test_fused_layer_tail_of_the_throughput_path_vs_three_launches():
     eng.set_option("latency_forms", "off")
     eng.set_debug(True)
     taps = {}
-    for mode in ("fused", "unfused"):
+    for mode in ("fused", "bf16x3", "unfused"):      # fused = gnn_tail_h2 (three fp16 plane products, round 4), bf16x3 = gnn_tail_x3 (six bf16 ones)
         eng.set_option("gnn_tail", mode)
         assert eng.get_option("gnn_tail") == mode
         eng.timing_reset()
@@ -203,23 +203,28 @@ def test_fused_layer_tail_of_the_throughput_path_vs_three_launches():
         out = _run(eng, data, (1, 1, H, W))
         forms = {r[0]: r[3] for r in eng.timing_report(forms=True)}
         eng.set_timing(False)
-        assert ("gnn_tail" in forms) == (mode == "fused") and ("gnn_mlp1" in forms) == (mode == "unfused"), forms
+        assert ("gnn_tail" in forms) == (mode != "unfused") and ("gnn_mlp1" in forms) == (mode == "unfused"), forms
+        if mode != "unfused":
+            assert forms["gnn_tail"] == ("gnn_tail_h2:f16x2" if mode == "fused" else "gnn_tail_x3:bf16x3"), forms
+            assert ("rows_amax" in forms) == (mode == "fused"), forms
         assert np.array_equal(out[0], g["matches0"]) and np.array_equal(out[1], g["matches1"]), f"gnn_tail={mode}"
         taps[mode] = (eng.fetch("x").copy(), eng.fetch("scores_in").copy(), out[2].copy())
     scale = np.abs(taps["unfused"][0]).max()
-    assert np.abs(taps["fused"][0] - taps["unfused"][0]).max() <= 2e-5 * scale, "GNN output: fused vs three launches"
-    np.testing.assert_allclose(taps["fused"][2], taps["unfused"][2], rtol=0, atol=2e-5)
+    for mode in ("fused", "bf16x3"):
+        assert np.abs(taps[mode][0] - taps["unfused"][0]).max() <= 2e-5 * scale, f"GNN output: {mode} vs three launches"
+        np.testing.assert_allclose(taps[mode][2], taps["unfused"][2], rtol=0, atol=2e-5)
     # ragged: 150 x 97 keypoints (R = 160 + 128 = 288 rows: one workgroup, three waves without rows) and a batch of 3 with counts
     gs = util.golden("sg_small.npz")
     for n0, n1 in ((150, 97), (gs["keypoints0"].shape[1], gs["keypoints1"].shape[1])):
         t = {k: torch.from_numpy(gs[k]).cuda() for k in KEYS}
         t = {k: (v[:, :, :n0 if k.endswith("0") else n1] if k.startswith("desc") else v[:, :n0 if k.endswith("0") else n1]).contiguous() for k, v in t.items()}
         res = {}
-        for mode in ("fused", "unfused"):
+        for mode in ("fused", "bf16x3", "unfused"):
             eng.set_option("gnn_tail", mode)
             res[mode] = _run(eng, t, (1, 1, 120, 160))
-        assert np.array_equal(res["fused"][0], res["unfused"][0]) and np.array_equal(res["fused"][1], res["unfused"][1]), (n0, n1)
-        np.testing.assert_allclose(res["fused"][2], res["unfused"][2], rtol=0, atol=2e-5)
+        for mode in ("fused", "bf16x3"):
+            assert np.array_equal(res[mode][0], res["unfused"][0]) and np.array_equal(res[mode][1], res["unfused"][1]), (mode, n0, n1)
+            np.testing.assert_allclose(res[mode][2], res["unfused"][2], rtol=0, atol=2e-5)
 
 
 @pytest.mark.parametrize("tail", ["fused", "unfused"])
