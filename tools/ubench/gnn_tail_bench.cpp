@@ -110,7 +110,7 @@ int main(int argc, char** argv) {
       t.amax_x_in = dax_in; t.amax_v = dav; t.amax_x_out = dax_out; t.cross = 0;
     }
     if (form == 2) {
-      if (n3 != 384 || M % (2 * PB * 32)) break;
+      if (n3 != 384 || M % (2 * PB * 32)) continue;
       hipMemset(damax, 0, 2 * PB * 16);
       t.amax = damax; t.B = PB; t.N0p = PN; t.N1p = PN; t.N0 = PN - 5; t.N1 = PN - 37;
     }
