@@ -288,14 +288,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24h(ConvArgs p, int tiles_
   unsigned amax_run = 0;           // this lane's largest stored value of the current item (bit pattern; values >= 0 after ReLU, |.| otherwise)
 #pragma unroll 1
   for (;;) {
+    // the item's bias and un-scale factor are requested HERE: loaded in the epilogue they cost it an L2 round trip per item
+    const f32x4 bs4 = *reinterpret_cast<const f32x4*>(p.bias + cur.cob * NT + cb * 16 + 4 * (lane >> 4));
+    const float inv = p.u_scale_inv / v_scale(p.amax_in[cur.b & (AMAX_SLOTS - 1)]);
     chunk_step(BoolC<true>{}, 0);
 #pragma unroll 1
     for (int c = 1; c < nchunk; ++c) chunk_step(BoolC<false>{}, c);
 
     // ---- item done: output transform, un-scale + bias, ReLU, (2x2 max-pool), stores straight from registers (conv3x3_wino24.hip)
     {
-      const f32x4 bs4 = *reinterpret_cast<const f32x4*>(p.bias + cur.cob * NT + cb * 16 + 4 * (lane >> 4));
-      const float inv = p.u_scale_inv / v_scale(p.amax_in[cur.b & (AMAX_SLOTS - 1)]);
       const f32x4 inv4 = {inv, inv, inv, inv};
       f32x4 y[2][4];
       w24_output_transform(acc, k8, y);
