@@ -507,6 +507,15 @@ def roofline_block(rows, wl, B, steps, dt, lib_build, workload):
                            "(2500 TFLOP/s): `achieved` counts the executed plane products against THAT peak, so `frac` fell while the launch got shorter "
                            "(r04_v9: 10.4 ms at 0.647 of the fp32 peak); the kernel is now bound by the L2 -> register stream of the transformed weights "
                            "and by VALU issue (transform + split), DESIGN.md section 5h")
+        if name == "conv1ab_pool":
+            # what actually limits it: every wave streams its own copy of the transformed weights U (64 x 64 x 24 positions x two fp16 planes =
+            # 393216 bytes per 8x16-pixel tile) through the CU's vector-memory return path, 64 bytes per clock and CU
+            tiles = 2 * B * ((H + 7) // 8) * ((W + 15) // 16)
+            ubytes = tiles * 64 * 64 * 24 * 4
+            rf["limiter"] = {"what": "vector-memory return path (L1 -> registers) of the transformed weights U", "bytes_per_launch": ubytes,
+                             "rate_TBps": round(ubytes / avg_s / 1e12, 2), "peak_TBps_at_2400MHz": round(64 * 256 * 2.4e9 / 1e12, 2),
+                             "frac": round(ubytes / avg_s / (64 * 256 * 2.4e9), 4),
+                             "note": "64 B/clk per CU x 256 CUs; HBM traffic of the same launch is `traffic` (~1.03 x the algorithmic bytes)"}
     # whole-pair view: time the matrix pipes would need at their dense peaks (fp32 MFMA 157.3, bf16 MFMA 2500 TFLOP/s) / step time
     per_step = {n: e[0] / steps for n, e in by.items()}          # launches per step
     step_s = dt / steps
