@@ -57,6 +57,13 @@ constexpr unsigned OOB = 0x7ffffff0u;          // byte offset beyond any image: 
 #endif
 
 struct Item { int b, y0, x0, cob; };
+#ifdef H_TRACE
+// phase clocks (tools/ubench/conv_h_bench.cpp, -DH_TRACE): cycles of wave 0 of every 32nd workgroup in each phase of chunk_step
+__device__ long long h_trace_buf[16 * 8];
+#define H_STAMP(i_) { const long long t_ = __builtin_amdgcn_s_memtime(); tr[i_] += t_ - tlast; tlast = t_; }
+#else
+#define H_STAMP(i_)
+#endif
 template <bool V>
 struct BoolC { static constexpr bool value = V; };
 
@@ -273,16 +280,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24h(ConvArgs p, int tiles_
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+#ifdef H_TRACE
+  long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
   auto chunk_step = [&](auto firstc, int c) __attribute__((always_inline)) {
+    H_STAMP(5)                     // (epilogue and item bookkeeping)
     if (H_EXP != 2) transform();
+    H_STAMP(0)
     __syncthreads();               // V complete; raw free
+    H_STAMP(1)
     mfma_phase(firstc, c);
+    H_STAMP(2)
     if (H_EXP != 3) {
       store_raw();                 // the next chunk's patch (requested a chunk ago)
       issue_load();
     }
     advance_loader();
+    H_STAMP(3)
     __syncthreads();               // raw complete; V free
+    H_STAMP(4)
   };
 
   unsigned amax_run = 0;           // this lane's largest stored value of the current item (bit pattern; values >= 0 after ReLU, |.| otherwise)
@@ -367,6 +383,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino24h(ConvArgs p, int tiles_
     for (int i = tid; i < AMAX_SLOTS; i += 256)
       if (amax_tab[i]) atomicMax(p.amax_out + i, amax_tab[i]);
   }
+#ifdef H_TRACE
+  if (tid == 0 && (blockIdx.x & 31) == 0 && (blockIdx.x >> 5) < 16)
+    for (int i = 0; i < 8; ++i) h_trace_buf[(blockIdx.x >> 5) * 8 + i] = tr[i];
+#endif
 }
 
 template <bool POOL, bool RELU>
@@ -390,6 +410,10 @@ hipError_t launch_h(const ConvArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 }  // namespace
+
+#ifdef H_TRACE
+void conv_h_trace_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(h_trace_buf), sizeof(long long) * 16 * 8); }
+#endif
 
 bool conv3x3_wino24h_supported(const ConvArgs& a) {
   if (a.first || a.Cin % 64 || a.Cout % NT || !a.wuh || !a.amax_in || !(a.u_scale_inv > 0.f)) return false;

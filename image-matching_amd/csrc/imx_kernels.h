@@ -83,6 +83,10 @@ bool conv3x3_wino24_supported(const ConvArgs& a);                   // false (e.
 hipError_t launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s); // Winograd F(2x4,3x3), persistent, in-stream transform
 bool conv3x3_wino24h_supported(const ConvArgs& a);                  // + wuh, amax_in
 hipError_t launch_conv3x3_wino24h(const ConvArgs& a, hipStream_t s); // the same on the fp16 matrix pipe: two planes per operand, three plane products
+bool conv3x3_wino24u_supported(const ConvArgs& a);                  // = conv3x3_wino24h_supported
+hipError_t launch_conv3x3_wino24u(const ConvArgs& a, hipStream_t s); // conv3x3_wino24h's arithmetic, a U fragment shared by two tiles (one workgroup per CU)
+bool conv3x3_wino24p_supported(const ConvArgs& a);                  // = conv3x3_wino24h_supported
+hipError_t launch_conv3x3_wino24p(const ConvArgs& a, hipStream_t s); // conv3x3_wino24h's arithmetic: tile pairs, positions split over two waves (8 waves per CU)
 
 
 // ---------------------------------------------------------------- GEMM (MFMA fp32): 1x1 conv / linear

@@ -15,6 +15,15 @@
 #include <vector>
 using namespace imx;
 namespace imx { thread_local const char* last_form = nullptr; }
+#ifdef H_TRACE
+namespace imx { void conv_h_trace_read(long long* out); }
+#endif
+#ifdef U_TRACE
+namespace imx { void conv_u_trace_read(long long* out); }
+#endif
+#ifdef P_TRACE
+namespace imx { void conv_p_trace_read(long long* out); }
+#endif
 
 static int run(int B, int H, int W, int Cin, int Cout, int pool, int blocked, float mag) {
   const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
@@ -39,21 +48,23 @@ static int run(int B, int H, int W, int Cin, int Cout, int pool, int blocked, fl
   const std::vector<float> u32 = wino24_transform(w, Cin, Cout);
   float su_inv = 0;
   const std::vector<uint16_t> uh = wino24h_pack(w, Cin, Cout, &su_inv);
-  float *dx, *dw32, *db, *dout32, *douth; void* duh; unsigned *damax, *damax_out;
+  float *dx, *dw32, *db, *dout32, *douth, *doutu; void* duh; unsigned *damax, *damax_out;
   hipMalloc(&dx, x.size() * 4); hipMalloc(&dw32, u32.size() * 4); hipMalloc(&db, Cout * 4); hipMalloc(&duh, uh.size() * 2);
-  hipMalloc(&dout32, (size_t)B * Ho * Wo * Cout * 4); hipMalloc(&douth, (size_t)B * Ho * Wo * Cout * 4); hipMalloc(&damax, 256 * 4); hipMalloc(&damax_out, 256 * 4);
+  hipMalloc(&dout32, (size_t)B * Ho * Wo * Cout * 4); hipMalloc(&douth, (size_t)B * Ho * Wo * Cout * 4); hipMalloc(&doutu, (size_t)B * Ho * Wo * Cout * 4); hipMalloc(&damax, 256 * 4); hipMalloc(&damax_out, 256 * 4);
   hipMemcpy(dx, xin.data(), x.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dw32, u32.data(), u32.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(db, bias.data(), Cout * 4, hipMemcpyHostToDevice); hipMemcpy(duh, uh.data(), uh.size() * 2, hipMemcpyHostToDevice);
   hipMemset(damax, 0, 256 * 4); hipMemcpy(damax, amax.data(), (B < 256 ? B : 256) * 4, hipMemcpyHostToDevice); hipMemset(damax_out, 0, 256 * 4);
-  hipMemset(dout32, 0xff, (size_t)B * Ho * Wo * Cout * 4); hipMemset(douth, 0xff, (size_t)B * Ho * Wo * Cout * 4);
+  hipMemset(dout32, 0xff, (size_t)B * Ho * Wo * Cout * 4); hipMemset(douth, 0xff, (size_t)B * Ho * Wo * Cout * 4); hipMemset(doutu, 0xff, (size_t)B * Ho * Wo * Cout * 4);
   ConvArgs a{};
   a.in = dx; a.wu24 = dw32; a.bias = db; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = 1; a.pool = pool; a.in_blocked = blocked;
   a.wuh = duh; a.u_scale_inv = su_inv; a.amax_in = damax; a.amax_out = getenv("NOAMAX") ? nullptr : damax_out;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  float ms[2] = {0, 0};
-  for (int form = 0; form < 2; ++form) {
-    a.out = form ? douth : dout32;
-    auto go = [&]() { return form ? launch_conv3x3_wino24h(a, 0) : launch_conv3x3_wino24(a, 0); };
+  float ms[3] = {0, 0, 0};
+  std::vector<unsigned> amu(B);
+  for (int form = 0; form < 3; ++form) {
+    a.out = form == 2 ? doutu : form ? douth : dout32;
+    if (form == 2) { std::vector<unsigned> am0(256); hipMemcpy(am0.data(), damax_out, 1024, hipMemcpyDeviceToHost); amu.assign(am0.begin(), am0.begin() + (B < 256 ? B : 256)); hipMemset(damax_out, 0, 1024); }
+    auto go = [&]() { return form == 2 ? (getenv("FORM_U") ? launch_conv3x3_wino24u(a, 0) : launch_conv3x3_wino24p(a, 0)) : form ? launch_conv3x3_wino24h(a, 0) : launch_conv3x3_wino24(a, 0); };
     hipError_t err = go();
     hipDeviceSynchronize();
     if (err != hipSuccess || hipGetLastError() != hipSuccess) { printf("launch failed (form %d): %s\n", form, hipGetErrorString(err)); return 1; }
@@ -64,12 +75,72 @@ static int run(int B, int H, int W, int Cin, int Cout, int pool, int blocked, fl
     hipEventElapsedTime(&ms[form], e0, e1);
     ms[form] /= 10;
   }
+#ifdef U_TRACE
+  {
+    long long tr[16 * 8];
+    conv_u_trace_read(tr);
+    double s[8] = {0}; int n = 0;
+    for (int g = 0; g < 16; ++g) { if (!tr[g * 8 + 2]) continue; ++n; for (int i = 0; i < 8; ++i) s[i] += (double)tr[g * 8 + i]; }
+    const double items = (double)(((W + 15) / 16) * ((H + 7) / 8) * B / 2) * (Cout / 64) / 256.0, chunks = items * (Cin / 32);
+    printf("  U trace (wave 0 of %d workgroups; cycles per chunk of a tile PAIR): transform %.0f | barrier %.0f | MFMA phase %.0f | raw store + loads %.0f | barrier %.0f | epilogue per item %.0f | total per chunk %.0f\n",
+           n, s[0] / n / chunks, s[1] / n / chunks, s[2] / n / chunks, s[3] / n / chunks, s[4] / n / chunks, s[5] / n / items,
+           (s[0] + s[1] + s[2] + s[3] + s[4] + s[5]) / n / chunks);
+  }
+#endif
+#ifdef P_TRACE
+  {
+    long long tr[16 * 8];
+    conv_p_trace_read(tr);
+    double s[8] = {0}; int n = 0;
+    for (int g = 0; g < 16; ++g) { if (!tr[g * 8 + 2]) continue; ++n; for (int i = 0; i < 8; ++i) s[i] += (double)tr[g * 8 + i]; }
+    const double items = (double)(((W + 15) / 16) * ((H + 7) / 8) * B / 2) * (Cout / 64) / 256.0, chunks = items * (Cin / 32);
+    printf("  P trace (wave 0 of %d workgroups; cycles per chunk of a tile PAIR): loads + transform %.0f | barrier %.0f | MFMA phase %.0f | raw store %.0f | barrier %.0f | epilogue per item %.0f | total per chunk %.0f\n",
+           n, s[0] / n / chunks, s[1] / n / chunks, s[2] / n / chunks, s[3] / n / chunks, s[4] / n / chunks, s[5] / n / items,
+           (s[0] + s[1] + s[2] + s[3] + s[4] + s[5]) / n / chunks);
+  }
+#endif
+#ifdef H_TRACE
+  {
+    long long tr[16 * 8];
+    conv_h_trace_read(tr);
+    double s[8] = {0}; int n = 0;
+    for (int g = 0; g < 16; ++g) { if (!tr[g * 8 + 2]) continue; ++n; for (int i = 0; i < 8; ++i) s[i] += (double)tr[g * 8 + i]; }
+    const double items = (double)((W + 15) / 16) * ((H + 7) / 8) * B * (Cout / 64) / 512.0, chunks = items * (Cin / 32);
+    printf("  trace (wave 0 of %d workgroups; cycles per chunk): transform %.0f | barrier %.0f | MFMA phase %.0f | raw store + loads %.0f | barrier %.0f | epilogue per item %.0f | total per chunk %.0f\n",
+           n, s[0] / n / chunks, s[1] / n / chunks, s[2] / n / chunks, s[3] / n / chunks, s[4] / n / chunks, s[5] / n / items,
+           (s[0] + s[1] + s[2] + s[3] + s[4] + s[5]) / n / chunks);
+  }
+#endif
   std::vector<float> o32((size_t)B * Ho * Wo * Cout), oh(o32.size());
   hipMemcpy(o32.data(), dout32, o32.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(oh.data(), douth, oh.size() * 4, hipMemcpyDeviceToHost);
   double dmax = 0, omax = 0; size_t nan = 0;
   for (size_t i = 0; i < oh.size(); ++i) {
     if (!(oh[i] == oh[i])) { ++nan; continue; }
     dmax = fmax(dmax, fabs((double)oh[i] - o32[i])); omax = fmax(omax, fabs((double)o32[i]));
+  }
+  size_t udiff = 0;
+  {
+    std::vector<float> ou(oh.size());
+    hipMemcpy(ou.data(), doutu, ou.size() * 4, hipMemcpyDeviceToHost);
+    size_t byc[4] = {0, 0, 0, 0}, bypar[2] = {0, 0}; int shown = 0;
+    for (size_t i = 0; i < oh.size(); ++i)
+      if (memcmp(&ou[i], &oh[i], 4) != 0) {
+        ++udiff;
+        const int c = (int)(i % Cout), x = (int)((i / Cout) % Wo), y = (int)((i / Cout / Wo) % Ho), b = (int)(i / Cout / Wo / Ho);
+        const int tx = (pool ? 2 * x : x) / 16, ty = (pool ? 2 * y : y) / 8, t = (b * ((H + 7) / 8) + ty) * ((W + 15) / 16) + tx;
+        ++byc[(c % 64) / 16]; ++bypar[t & 1];
+        if (getenv("SHOWDIFF") && shown++ < 12) printf("    diff b %d y %d x %d c %d (tile %d): pair %.6g  h %.6g\n", b, y, x, c, t, ou[i], oh[i]);
+      }
+    if (udiff && getenv("SHOWDIFF")) {
+      size_t nz = 0, nan = 0, eq_nz = 0; double mx = 0;
+      for (size_t i = 0; i < ou.size(); ++i) { if (ou[i] != ou[i]) ++nan; else if (ou[i] != 0) { ++nz; mx = fmax(mx, fabs(ou[i])); if (ou[i] == oh[i]) ++eq_nz; } }
+      printf("    pair output: %zu nonzero (%zu equal to h), %zu NaN, max %.4g of %zu\n", nz, eq_nz, nan, mx, ou.size());
+    }
+    if (udiff && getenv("SHOWDIFF")) printf("    by channel block: %zu %zu %zu %zu; by tile parity: %zu %zu\n", byc[0], byc[1], byc[2], byc[3], bypar[0], bypar[1]);
+    std::vector<unsigned> amn(256);
+    hipMemcpy(amn.data(), damax_out, 1024, hipMemcpyDeviceToHost);
+    for (int b = 0; b < B && b < 256; ++b) udiff += amn[b] != amu[b];
+    hipMemcpy(damax_out, amu.data(), (B < 256 ? B : 256) * 4, hipMemcpyHostToDevice);     // (the check below reads the h form's maxima)
   }
   // float64 direct reference on sample output pixels (all channels)
   double e32 = 0, eh = 0; int ns = 0;
@@ -106,10 +177,10 @@ static int run(int B, int H, int W, int Cin, int Cout, int pool, int blocked, fl
     if (!(got >= m) || got > 1.5f * m + 1e-6f) { if (bad < 3) printf("  amax_out[%d] = %g, host max %g\n", b, got, m); ++bad; }
   }
   const double macs = (double)B * H * W * 9.0 * Cin * Cout;
-  printf("%4dx%-4d %3d->%-3d pool %d %s | fp32 wino %7.1f us  f16x2 wino %7.1f us (x%.2f, %5.1f TFLOP/s direct-equivalent) | max |h - f32| %.2e of %.2e%s | vs float64 (%d samples): f32 %.2e  f16x2 %.2e | amax_out bad %d\n",
-         H, W, Cin, Cout, pool, blocked ? "blocked" : "nhwc   ", ms[0] * 1e3, ms[1] * 1e3, ms[0] / ms[1], 2 * macs / (ms[1] * 1e-3) / 1e12, dmax, omax,
+  printf("%4dx%-4d %3d->%-3d pool %d %s | fp32 wino %7.1f us  f16x2 wino %7.1f us (x%.2f, %5.1f TFLOP/s direct-equivalent)  pair %7.1f us (x%.2f vs h; %zu words differ) | max |h - f32| %.2e of %.2e%s | vs float64 (%d samples): f32 %.2e  f16x2 %.2e | amax_out bad %d\n",
+         H, W, Cin, Cout, pool, blocked ? "blocked" : "nhwc   ", ms[0] * 1e3, ms[1] * 1e3, ms[0] / ms[1], 2 * macs / (ms[1] * 1e-3) / 1e12, ms[2] * 1e3, ms[1] / ms[2], udiff, dmax, omax,
          nan ? " NaN!" : "", ns, e32, eh, bad);
-  hipFree(dx); hipFree(dw32); hipFree(db); hipFree(duh); hipFree(dout32); hipFree(douth); hipFree(damax); hipFree(damax_out);
+  hipFree(dx); hipFree(dw32); hipFree(db); hipFree(duh); hipFree(dout32); hipFree(douth); hipFree(doutu); hipFree(damax); hipFree(damax_out);
   return 0;
 }
 
