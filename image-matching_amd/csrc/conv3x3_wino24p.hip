@@ -34,9 +34,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-// (v_store below names m0 as clobbered: hipcc reserves m0 and warns about any mention of it; nothing else in this kernel uses it)
-#pragma clang diagnostic ignored "-Winline-asm"
-
 namespace imx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -63,7 +60,7 @@ constexpr int XCH = NLP * 64 * 16;             // bytes of one wave's accumulato
 constexpr unsigned OOB = 0x7ffffff0u;          // byte offset beyond any image: buffer loads return 0
 #ifdef P_TRACE
 // phase clocks (tools/ubench/conv_h_bench.cpp, -DP_TRACE): cycles of wave 0 of every 16th workgroup in each phase of chunk_step
-__device__ long long p_trace_buf[16 * 8];
+__device__ long long p_trace_buf[16 * 16];
 #define P_STAMP(i_) { const long long t_ = __builtin_amdgcn_s_memtime(); tr[i_] += t_ - tlast; tlast = t_; }
 #else
 #define P_STAMP(i_)
@@ -106,7 +103,7 @@ __device__ __forceinline__ float v_scale_inv(unsigned amax_bits) {
   return __builtin_bit_cast(float, (e - 8u) << 23);
 }
 
-template <bool POOL, bool RELU>
+template <bool POOL, bool RELU, bool FASTW>
 __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, int tiles_y, int ntiles, int nitems) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
   float* raw = reinterpret_cast<float*>(smem_p + NG * VGRP * 2);               // [NG][NSUB][RAWC]   (V [NG][2][VPLANE] halves sits at 0)
@@ -123,6 +120,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
   // XCD-aware start index (conv3x3_wino24.hip)
   const int vb = (grid & 7) == 0 ? ((int)blockIdx.x & 7) * (grid >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
   if (vb >= nitems) return;
+#ifdef P_PRIO
+  if (ph == P_PRIO - 1) __builtin_amdgcn_s_setprio(2);      // experiment: the issue arbiter favours the older four waves
+#endif
   const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.wuh, 0, ncob * nchunk * NPOS * UPOS * 2, 0x00020000);
   const int uoff_lane = (cb * 64 + lane) * 16 + ph * 2 * (UPOS * 2);           // bytes: plane 0 of position 2 ph of a (block, chunk)
   const int img_bytes = H * W * Cin * 4;
@@ -135,8 +135,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
   const int tk = lane & 3, tw = lane >> 2, twr = tw >> 2, twc = tw & 3;
   const f32x2 m5 = {-5.f, -5.f}, one2 = {1.f, 1.f}, mone2 = {-1.f, -1.f};
   const float* rp = raw + (tg * NSUB + tq) * RAWC + ((2 * twr) * RW + 4 * twc) * RSC + 2 * tk;     // + (row * RW + column) * RSC
-  // V stores: position p = j*4 + i, group tq, lane = (tw, tk) -> bytes (p*4 + tq) * 256 + lane * 4 of the plane
-  const unsigned v_m0 = lds0 + (unsigned)(tg * (VGRP * 2) + tq * 256);
+
   // B-operand reads: lane = (wtile n = lane & 15, group kg = lane >> 4) -> 16 bytes at position * 1024 + lane * 16 of a plane.  One
   // opaque base per tile (the second tile's planes lie beyond the 64 KB an LDS offset field reaches from the first tile's base:
   // hipcc would materialise an address register per position), the wave's 2 ph folded in; K = the tile this wave finishes (tile
@@ -163,42 +162,50 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
   int ldst[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) { int a, b, c; ldst[k] = tg * NSUB * RAWC + loader_slot(tid & 255, k, a, b, c); }
-  // an item = (pair of consecutive tiles, 64-channel output block); a wave only ever needs ITS tile of the pair
-  auto decode_tile = [&](int it) __attribute__((always_inline)) -> Tile {
+  // an item = (pair of consecutive tiles, 64-channel output block); a wave only ever needs ITS tile of the pair.  Items vb + k grid:
+  // the host makes grid a multiple of ncob whenever a workgroup has more than one item, so the output block is fixed (vb % ncob) and
+  // the tile advances by dt = NG grid / ncob per item -- stepped with carries (three divisions per item and wave, plus the loader's
+  // three, were a tenth of the epilogue's instructions)
+  const int cob = vb % ncob;
+  const int dt = NG * (grid / ncob), dtx = dt % tiles_x, dty = (dt / tiles_x) % tiles_y, dtb = dt / (tiles_x * tiles_y);
+  Tile cur, nxt;                 // cur: the item whose chunks are multiplied; nxt: the one after it = the loader's, once it has wrapped
+  {
+    const int t = NG * (vb / ncob) + tg;
+    cur.live = t < ntiles;
+    cur.x0 = t % tiles_x;        // (tile coordinates; pixels = * OW, * OH)
+    cur.y0 = (t / tiles_x) % tiles_y;
+    cur.b = t / (tiles_x * tiles_y);
+  }
+  auto step_tile = [&](const Tile& t) __attribute__((always_inline)) -> Tile {
     Tile r;
-    const int t = NG * (it / ncob) + tg;
-    r.live = t < ntiles;
-    const int tt = r.live ? t : 0;
-    r.x0 = (tt % tiles_x) * OW;
-    r.y0 = ((tt / tiles_x) % tiles_y) * OH;
-    r.b = tt / (tiles_x * tiles_y);
+    int x = t.x0 + dtx, y = t.y0 + dty, b = t.b + dtb;
+    if (x >= tiles_x) { x -= tiles_x; ++y; }
+    if (y >= tiles_y) { y -= tiles_y; ++b; }
+    r.x0 = x; r.y0 = y; r.b = b;
+    r.live = b < p.B;
     return r;
   };
-  // cur / cur_cob: the item whose chunks are multiplied; nxt_cob: the output block of the one after it (its U block is prefetched
-  // during cur's last chunk); litem: the loader's item (chunk s + 1 is requested at the start of step s and stored at its end)
-  int item_c = vb;
-  Tile cur = decode_tile(vb);
-  int cur_cob = vb % ncob, nxt_cob = vb + grid < nitems ? (vb + grid) % ncob : cur_cob;
-  int litem = item_c, lchunk = 0;
+  int item_c = vb, lchunk = 0;
   __amdgpu_buffer_rsrc_t lrs;
   unsigned goff[2];
   float lsv;                                                      // s_v of the loader's tile
   const bool inb = p.in_blocked != 0;
   const int pxb = inb ? 8 * 4 : Cin * 4;                          // bytes from one pixel to the next
   const int sub_step = inb ? H * W * 8 * 4 : 8 * 4;               // bytes from one 8-channel group to the next
-  auto loader_tile = [&](const Tile& t, bool live) __attribute__((always_inline)) {
+  auto loader_tile = [&](const Tile& t) __attribute__((always_inline)) {
     const int t8 = (wave_s & 3) * 64 + lane_now();
     int lpy[2], lpx[2], lhalf[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) loader_slot(t8, k, lpy[k], lpx[k], lhalf[k]);
-    const bool lv = live && t.live;
+    const bool lv = t.live != 0;
     const int b = __builtin_amdgcn_readfirstlane(lv ? t.b : 0);
     lrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)b * H * W * Cin), 0, lv ? img_bytes : 0, 0x00020000);
     lsv = v_scale(amax_c[b & (AMAX_SLOTS - 1)]);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int gy = t.y0 + lpy[k], gx = t.x0 + lpx[k];
-      goff[k] = (lv && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (unsigned)((gy * W + gx) * pxb + lhalf[k] * 16) : OOB;
+      const int gy = t.y0 * OH + lpy[k], gx = t.x0 * OW + lpx[k];
+      const bool in = (int)lv & (int)((unsigned)gy < (unsigned)H) & (int)((unsigned)gx < (unsigned)W);
+      goff[k] = in ? (unsigned)((gy * W + gx) * pxb + lhalf[k] * 16) : OOB;
     }
   };
   f32x4 rr[NSUB][2];
@@ -216,10 +223,9 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
   auto advance_loader = [&]() __attribute__((always_inline)) {
     if (__builtin_expect(++lchunk == nchunk, 0)) {   // the loader moves on to this workgroup's next item
       lchunk = 0;
-      litem += grid;
-      const bool live = litem < nitems;
-      const Tile lt = decode_tile(live ? litem : vb);
-      loader_tile(lt, live);
+      nxt = step_tile(cur);
+      if (item_c + grid >= nitems) nxt.live = 0;
+      loader_tile(nxt);
       asm volatile("" ::: "memory");
     }
   };
@@ -247,11 +253,11 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
 
   for (int i = tid; i < AMAX_SLOTS; i += 512) amax_tab[i] = 0;       // (visible after the fill's barrier)
   // ---- pipeline fill: chunk 0 of the first item into raw, the U ring of chunk 0
-  loader_tile(cur, true);
+  loader_tile(cur);
   issue_load();
   store_raw();
 #pragma unroll
-  for (int g = 0; g < RING; ++g) u_load(g, cur_cob, 0, g);
+  for (int g = 0; g < RING; ++g) u_load(g, cob, 0, g);
   __syncthreads();
 
   f32x4 accK[NLP], accS[NLP];    // this wave's positions of the tile it finishes / of its partner's tile; an item's first chunk
@@ -260,18 +266,24 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
   // ---- store geometry (conv3x3_wino24.hip)
   const int Ho_k = POOL ? H >> 1 : H, Wo_k = POOL ? W >> 1 : W;
   const bool outb = p.out_blocked != 0;
-  const bool fastw = (W % OW) == 0 && (!outb || (H % OH) == 0);
+  constexpr bool fastw = FASTW;    // whole tiles only: (W % OW) == 0 && (!out_blocked || (H % OH) == 0) -- the stores need no mask
   const int opx = outb ? 8 * 4 : Cout * 4;
   const f32x4 zero4c = {0.f, 0.f, 0.f, 0.f};
 
-  auto v_store = [&](int plane, int pos, unsigned bits) __attribute__((always_inline)) {
-    const unsigned a = v_m0 + (unsigned)(plane * (VPLANE * 2) + pos * 1024);     // (one s_add per store)
-    // (s_nop: a scalar write of m0 needs one wait state before an add-TID LDS instruction reads it; hipcc inserts hazard nops
-    // between instructions it schedules, not inside an asm string -- without it the store lands at the PREVIOUS store's address)
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tds_write_addtid_b32 %0" : : "v"(bits), "s"(a) : "memory", "m0");
+  // V stores: h and m of a channel pair, 4 bytes each, at (position * 4 + tq) * 256 + lane * 4 of their planes (hipcc pairs the two
+  // planes' stores into one ds_write2st64_b32).  (ds_write_addtid_b32 -- no address register, twice the LDS rate -- was built first:
+  // with its m0 setup and the wait state a scalar write of m0 needs before an add-TID instruction it is FOUR instructions per store,
+  // and this phase is bound by instruction issue, not by the LDS.)
+  _Float16* const vwr = (_Float16*)((__attribute__((address_space(3))) unsigned char*)(uintptr_t)(lds0 + (unsigned)(tg * (VGRP * 2) + tq * 256 + lane * 4)));
+  auto v_store2 = [&](int pos, f16x2 h, f16x2 m) __attribute__((always_inline)) {
+    *reinterpret_cast<f16x2*>(vwr + pos * 512) = h;
+    *reinterpret_cast<f16x2*>(vwr + VPLANE + pos * 512) = m;
   };
   // phase A: this wave's sub-patch (scaled) -> its four transformed rows in the V planes.  Rows of B2^T: r0 - r2, r1 + r2, r2 - r1,
   // r1 - r3 (as fma(+-1, b, a): conv3x3_wino24h.hip's instruction)
+#ifdef P_TRACE
+  long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
   auto transform = [&]() __attribute__((always_inline)) {
     f32x2 r1[6], r2[6], rx[6];
     auto row_load = [&](f32x2 (&d)[6], int row) __attribute__((always_inline)) {
@@ -288,30 +300,45 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
       for (int jj = 0; jj < 6; ++jj) {
         f16x2 h, m;
         split_h2(T[jj], h, m);
-        v_store(0, jj * 4 + i, __builtin_bit_cast(unsigned, h));
-        v_store(1, jj * 4 + i, __builtin_bit_cast(unsigned, m));
+        v_store2(jj * 4 + i, h, m);
       }
     };
     row_load(r1, 1);
     row_load(r2, 2);
     row_load(rx, 0);
     row_out(1, one2, r2, r1);        // r1 + r2
+    P_STAMP(9)
     row_out(2, mone2, r1, r2);       // r2 - r1
+    P_STAMP(10)
     row_out(0, mone2, r2, rx);       // r0 - r2
+    P_STAMP(11)
     row_load(rx, 3);
     row_out(3, mone2, rx, r1);       // r1 - r3
+    P_STAMP(12)
   };
   // phase B: 72 MFMAs; per position one U fragment (two planes) against the B operands of both tiles; the U slot is refilled in
   // place with the wave's position lp + RING (of this chunk, or of the next chunk / the next item's block)
   auto mfma_phase = [&](auto firstc, int c) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(firstc)::value;
     const bool lastc = c + 1 == nchunk;
-    const int ncb = lastc ? nxt_cob : cur_cob, nch = lastc ? 0 : c + 1;
+    const int nch = lastc ? 0 : c + 1;
+    // the B operands of position lp + 1 are requested beneath the MFMAs of position lp (without this the phase waits for the LDS
+    // once per position -- ~270 cycles per position and wave against 96 of MFMAs: the trace of the first build)
+    f16x8 bq[2][4];              // [buffer][K h, K m, S h, S m]
+    auto b_load = [&](int buf, int lp) __attribute__((always_inline)) {
+      const int po = ((lp >> 1) * 4 + (lp & 1)) * 512;       // halves (the wave's 2 ph sits in the bases)
+      bq[buf][0] = *reinterpret_cast<const f16x8*>(vrdK + po);
+      bq[buf][1] = *reinterpret_cast<const f16x8*>(vrdK + VPLANE + po);
+      bq[buf][2] = *reinterpret_cast<const f16x8*>(vrdS + po);
+      bq[buf][3] = *reinterpret_cast<const f16x8*>(vrdS + VPLANE + po);
+    };
+    b_load(0, 0);
 #pragma unroll
     for (int lp = 0; lp < NLP; ++lp) {
-      const int po = ((lp >> 1) * 4 + (lp & 1)) * 512;       // halves (the wave's 2 ph sits in the bases)
-      const f16x8 bKh = *reinterpret_cast<const f16x8*>(vrdK + po), bKm = *reinterpret_cast<const f16x8*>(vrdK + VPLANE + po);
-      const f16x8 bSh = *reinterpret_cast<const f16x8*>(vrdS + po), bSm = *reinterpret_cast<const f16x8*>(vrdS + VPLANE + po);
+      const int buf = lp & 1;
+      if (lp + 1 < NLP) b_load(buf ^ 1, lp + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8 bKh = bq[buf][0], bKm = bq[buf][1], bSh = bq[buf][2], bSm = bq[buf][3];
       const f16x8 ah = __builtin_bit_cast(f16x8, ub[lp % RING][0]), am = __builtin_bit_cast(f16x8, ub[lp % RING][1]);
       accK[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bKm, FIRST ? zero4c : accK[lp], 0, 0, 0);
       accS[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bSm, FIRST ? zero4c : accS[lp], 0, 0, 0);
@@ -321,23 +348,20 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
       accS[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bSh, accS[lp], 0, 0, 0);
       {
         const int np = lp + RING;
-        if (np < NLP) u_load(lp % RING, cur_cob, c, np);
-        else u_load(lp % RING, ncb, nch, np - NLP);
+        if (np < NLP) u_load(lp % RING, cob, c, np);
+        else u_load(lp % RING, cob, nch, np - NLP);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-#ifdef P_TRACE
-  long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#endif
   // The patches of chunk s + 1 are requested at the START of chunk step s (after the barrier that closes step s - 1, and after the
   // epilogue when that step ended an item): their registers are dead through the epilogue and the loader's item bookkeeping.
   auto chunk_step = [&](auto firstc, int c) __attribute__((always_inline)) {
     P_STAMP(5)                     // (epilogue and item bookkeeping)
     advance_loader();
     issue_load();
+    P_STAMP(8)                     // item bookkeeping + patch loads issued
     transform();
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the V stores are inline assembly, which hipcc's wait counting does not see
     P_STAMP(0)
     __syncthreads();               // V complete; raw free
     P_STAMP(1)
@@ -360,6 +384,26 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
     // last matrix phase), the partner's accumulators of THIS wave's tile come back: all 24 positions of 16 channels x 16 wtiles
     typedef __attribute__((address_space(3))) f32x4* lds4p;
     const int lq = lane_now();
+    // (requested here, ahead of the exchange's barriers: scalar-cache latency)
+    // the item's bias (sixteen scalars of this wave's channel block; a lane keeps the four of its quarter) and un-scale factor
+    f32x4 bs4;
+    {
+      const int bo = __builtin_amdgcn_readfirstlane(cob * NT + cb * 16);
+      const int kq = lq >> 4;
+      typedef const f32x4 __attribute__((address_space(4)))* cf4p;
+      const cf4p b4 = (cf4p)(bias_c + bo);
+      const f32x4 b0 = b4[0], b1 = b4[1], b2 = b4[2], b3 = b4[3];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bs4[q] = kq == 0 ? b0[q] : kq == 1 ? b1[q] : kq == 2 ? b2[q] : b3[q];
+    }
+    Tile tl;                       // (through readfirstlane: hipcc does not see that these are wave-uniform and wraps every store
+    tl.b = __builtin_amdgcn_readfirstlane(cur.b);            // whose descriptor derives from them in a waterfall loop)
+    tl.y0 = __builtin_amdgcn_readfirstlane(cur.y0) * OH;
+    tl.x0 = __builtin_amdgcn_readfirstlane(cur.x0) * OW;
+    tl.live = __builtin_amdgcn_readfirstlane(cur.live);
+    const float inv = p.u_scale_inv * v_scale_inv(amax_c[tl.b & (AMAX_SLOTS - 1)]);
+
+
     const unsigned xw = lds0 + (unsigned)(wave_s * XCH + lq * 16), xr = lds0 + (unsigned)((wave_s ^ 4) * XCH + lq * 16);
 #pragma unroll
     for (int lp = 0; lp < NLP; ++lp) *(lds4p)(uintptr_t)(xw + lp * 1024) = accS[lp];
@@ -368,24 +412,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
 #pragma unroll
     for (int lp = 0; lp < NLP; ++lp) got[lp] = *(lds4p)(uintptr_t)(xr + lp * 1024);
     __syncthreads();               // (the next transform overwrites the region)
-
-    // the item's bias (sixteen scalars of this wave's channel block; a lane keeps the four of its quarter) and un-scale factor
-    f32x4 bs4;
-    {
-      const int bo = __builtin_amdgcn_readfirstlane(cur_cob * NT + cb * 16);
-      const int kq = lq >> 4;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float b0 = bias_c[bo + q], b1 = bias_c[bo + 4 + q], b2 = bias_c[bo + 8 + q], b3 = bias_c[bo + 12 + q];
-        bs4[q] = kq == 0 ? b0 : kq == 1 ? b1 : kq == 2 ? b2 : b3;
-      }
-    }
-    Tile tl;                       // (through readfirstlane: hipcc does not see that these are wave-uniform and wraps every store
-    tl.b = __builtin_amdgcn_readfirstlane(cur.b);            // whose descriptor derives from them in a waterfall loop)
-    tl.y0 = __builtin_amdgcn_readfirstlane(cur.y0);
-    tl.x0 = __builtin_amdgcn_readfirstlane(cur.x0);
-    tl.live = __builtin_amdgcn_readfirstlane(cur.live);
-    const float inv = p.u_scale_inv * v_scale_inv(amax_c[tl.b & (AMAX_SLOTS - 1)]);
 
     // ---- output transform, un-scale + bias, ReLU, (2x2 max-pool), stores straight from registers (conv3x3_wino24h.hip); position
     // j*4 + i: rows 2 ph, 2 ph + 1 are this wave's, the other two the partner's
@@ -409,7 +435,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
       const int Ho = Ho_k, Wo = Wo_k;
       typedef unsigned su32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
       const int ibase = __builtin_amdgcn_readfirstlane(((POOL ? tl.y0 >> 1 : tl.y0) * Wo + (POOL ? tl.x0 >> 1 : tl.x0)) * opx +
-                                                       (outb ? cur_cob * (NT / 8) * (Ho * Wo * 8 * 4) : cur_cob * NT * 4));
+                                                       (outb ? cob * (NT / 8) * (Ho * Wo * 8 * 4) : cob * NT * 4));
       const int fbase = fastw ? ibase : 0;
       // a dead tile (the odd tile out at the end of the grid) stores through an empty descriptor
       const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)tl.b * Ho * Wo * Cout + (fbase >> 2)), 0,
@@ -464,9 +490,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
     }
     item_c += grid;
     if (item_c >= nitems) break;
-    cur = decode_tile(item_c);
-    cur_cob = item_c % ncob;
-    if (item_c + grid < nitems) nxt_cob = (item_c + grid) % ncob;
+    cur = nxt;
   }
   if (p.amax_out) {
     __syncthreads();
@@ -474,12 +498,17 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
       if (amax_tab[i]) atomicMax(p.amax_out + i, amax_tab[i]);
   }
 #ifdef P_TRACE
+#ifdef P_TRACE_WAVES          // the eight waves of workgroup 0 instead of wave 0 of sixteen workgroups
+  if (lane == 0 && blockIdx.x == 0)
+    for (int i = 0; i < 16; ++i) p_trace_buf[wave_s * 16 + i] = tr[i];
+#else
   if (tid == 0 && (blockIdx.x & 15) == 0 && (blockIdx.x >> 4) < 16)
-    for (int i = 0; i < 8; ++i) p_trace_buf[(blockIdx.x >> 4) * 8 + i] = tr[i];
+    for (int i = 0; i < 16; ++i) p_trace_buf[(blockIdx.x >> 4) * 16 + i] = tr[i];
+#endif
 #endif
 }
 
-template <bool POOL, bool RELU>
+template <bool POOL, bool RELU, bool FASTW>
 hipError_t launch_p(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = (a.W + OW - 1) / OW, tiles_y = (a.H + OH - 1) / OH;
   const int ntiles = tiles_x * tiles_y * a.B;
@@ -492,10 +521,12 @@ hipError_t launch_p(const ConvArgs& a, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
     ncu = prop.multiProcessorCount;
   }
-  auto k = conv3x3_wino24p<POOL, RELU>;
+  auto k = conv3x3_wino24p<POOL, RELU, FASTW>;
   static unsigned long long attr = 0;
   raise_lds_limit(reinterpret_cast<const void*>(k), (int)lds, attr);
-  const dim3 grid((unsigned)(nitems < ncu ? nitems : ncu));     // persistent: one workgroup per CU
+  const int ncob = a.Cout / NT;
+  const dim3 grid((unsigned)(nitems <= ncu ? nitems : ncu - ncu % ncob));     // persistent: one workgroup per CU; a multiple of ncob (item stepping)
+  if (grid.x == 0) return hipErrorInvalidValue;
   last_form = "conv3x3_wino24p:f16x2";
   hipLaunchKernelGGL(k, grid, dim3(512), lds, s, a, tiles_x, tiles_y, ntiles, nitems);
   return hipGetLastError();
@@ -503,15 +534,35 @@ hipError_t launch_p(const ConvArgs& a, hipStream_t s) {
 }  // namespace
 
 #ifdef P_TRACE
-void conv_p_trace_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(p_trace_buf), sizeof(long long) * 16 * 8); }
+void conv_p_trace_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(p_trace_buf), sizeof(long long) * 16 * 16); }
 #endif
 
 bool conv3x3_wino24p_supported(const ConvArgs& a) { return conv3x3_wino24h_supported(a); }
 
+// The pair form has one workgroup per CU: below one item per CU (one or two image pairs at the coarse layers) the tile-per-workgroup
+// form, with twice the items and two workgroups per CU, fills more of the chip.
+bool conv3x3_wino24p_preferred(const ConvArgs& a) {
+  if (!conv3x3_wino24p_supported(a)) return false;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    ncu = prop.multiProcessorCount;
+  }
+  const long long tiles = (long long)((a.W + OW - 1) / OW) * ((a.H + OH - 1) / OH) * a.B;
+  return ((tiles + NG - 1) / NG) * (a.Cout / NT) >= ncu;
+}
+
 hipError_t launch_conv3x3_wino24p(const ConvArgs& a, hipStream_t s) {
   if (!conv3x3_wino24p_supported(a)) return hipErrorInvalidValue;
-  if (a.pool) return a.relu ? launch_p<true, true>(a, s) : launch_p<true, false>(a, s);
-  return a.relu ? launch_p<false, true>(a, s) : launch_p<false, false>(a, s);
+  const bool fastw = (a.W % OW) == 0 && (!a.out_blocked || (a.H % OH) == 0);
+  if (fastw) {
+    if (a.pool) return a.relu ? launch_p<true, true, true>(a, s) : launch_p<true, false, true>(a, s);
+    return a.relu ? launch_p<false, true, true>(a, s) : launch_p<false, false, true>(a, s);
+  }
+  if (a.pool) return a.relu ? launch_p<true, true, false>(a, s) : launch_p<true, false, false>(a, s);
+  return a.relu ? launch_p<false, true, false>(a, s) : launch_p<false, false, false>(a, s);
 }
 
 }  // namespace imx

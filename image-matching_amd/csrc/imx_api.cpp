@@ -670,7 +670,11 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
     const bool winoh = wino && amax && conv3x3_wino24h_supported(a);
     if (amax && !fused1 && !winoh) return fail(h, "%s: the fp16-plane Winograd chain needs every layer to take part (internal)", name);
     const bool fused1h = fused1 && amax && conv1ab_wino24h_supported(a);
-    RUN(name, fused1h ? launch_conv1ab_wino24h(a, s) : fused1 ? launch_conv1ab_wino24(a, s) : winoh ? launch_conv3x3_wino24h(a, s) : wino ? launch_conv3x3_wino24(a, s) : launch_conv3x3(a, s));
+    // the fp16-plane layers: tile pairs with the positions split over two waves where that fills the chip (conv3x3_wino24p.hip: a U
+    // fragment serves two tiles), one tile per workgroup otherwise ("conv" = "wino_h": always) -- the same arithmetic, bit for bit
+    const bool winop = winoh && h->opt.conv_f16 == 1 && conv3x3_wino24p_preferred(a);
+    RUN(name, fused1h ? launch_conv1ab_wino24h(a, s) : fused1 ? launch_conv1ab_wino24(a, s) : winop ? launch_conv3x3_wino24p(a, s) : winoh ? launch_conv3x3_wino24h(a, s) :
+              wino ? launch_conv3x3_wino24(a, s) : launch_conv3x3(a, s));
     return 0;
   };
   if (conv("conv1ab_pool", h->conv[0], img0, a1, H, W, true, true)) return -1;
@@ -928,7 +932,7 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   return 0;
 }
 
-// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | wino32 | direct, "gnn_tail" = auto | fused | bf16x3 | unfused, "attention" = auto | f16x2 | bf16x3.  Returns 0, or -1 for an unknown key / value.
+// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | wino_h | wino32 | direct, "gnn_tail" = auto | fused | bf16x3 | unfused, "attention" = auto | f16x2 | bf16x3.  Returns 0, or -1 for an unknown key / value.
 int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
   Options& o = h->opt;
   if (key == "mfma") {
@@ -942,6 +946,7 @@ int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
     if (v == "auto") o.attention = -1; else if (v == "bf16x3" || v == "x3" || v == "0") o.attention = 0; else if (v == "f16x2" || v == "1") o.attention = 1; else return -1;
   } else if (key == "conv") {
     if (v == "wino") { o.conv_direct = 0; o.conv_f16 = 1; }
+    else if (v == "wino_h") { o.conv_direct = 0; o.conv_f16 = 2; }
     else if (v == "wino32") { o.conv_direct = 0; o.conv_f16 = 0; }
     else if (v == "direct") o.conv_direct = 1;
     else return -1;
@@ -1436,7 +1441,7 @@ int imx_set_option(imx_handle_t h, const char* key, const char* value) {
   return guarded(h, "imx_set_option", [&]() -> int {
     if (!h) return -1;
     if (!key || !value) return fail(h, "imx_set_option: null argument");
-    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3)", key, value);
+    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino_h|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3)", key, value);
     return 0;
   });
 }
@@ -1448,7 +1453,7 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     const Options& o = h->opt;
     if (k == "mfma") h->opt_text = o.mfma_f32 ? "f32" : "x3";
     else if (k == "latency_forms") h->opt_text = o.latency_forms < 0 ? "auto" : o.latency_forms == 2 ? "unfused" : o.latency_forms ? "on" : "off";
-    else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : o.conv_f16 ? "wino" : "wino32";
+    else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : o.conv_f16 == 2 ? "wino_h" : o.conv_f16 ? "wino" : "wino32";
     else if (k == "gnn_tail") h->opt_text = o.gnn_tail < 0 ? "auto" : o.gnn_tail == 2 ? "bf16x3" : o.gnn_tail ? "fused" : "unfused";
     else if (k == "attention") h->opt_text = o.attention < 0 ? "auto" : o.attention ? "f16x2" : "bf16x3";
     else h->opt_text.clear();

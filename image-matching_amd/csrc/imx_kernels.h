@@ -21,7 +21,7 @@ struct Options {
   int attention = -1;      // "attention": -1 = "auto" = 1 = "f16x2" (attention_x3.hip with two fp16 planes per operand, three term products: needs
                            //         the q / k / v maxima, which the fused layer tail writes), 0 = "bf16x3" (three bf16 planes, six term products)
   int conv_direct = 0;     // "conv": 0 = "wino" / "wino32" (Winograd F(2x4,3x3); direct only for shapes it rejects), 1 = "direct"
-  int conv_f16 = 1;        //         "wino" (default): the layers after the first run the Winograd products on the fp16 matrix pipe (two planes per
+  int conv_f16 = 1;        //         (2 = "wino_h": conv3x3_wino24h for every layer, never the tile-pair form conv3x3_wino24p)  "wino" (default): the layers after the first run the Winograd products on the fp16 matrix pipe (two planes per
                            //         transformed operand, conv3x3_wino24h.hip; needs "mfma" = "x3"); "wino32": every product on the fp32 MFMA
 };
 
@@ -83,9 +83,8 @@ bool conv3x3_wino24_supported(const ConvArgs& a);                   // false (e.
 hipError_t launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s); // Winograd F(2x4,3x3), persistent, in-stream transform
 bool conv3x3_wino24h_supported(const ConvArgs& a);                  // + wuh, amax_in
 hipError_t launch_conv3x3_wino24h(const ConvArgs& a, hipStream_t s); // the same on the fp16 matrix pipe: two planes per operand, three plane products
-bool conv3x3_wino24u_supported(const ConvArgs& a);                  // = conv3x3_wino24h_supported
-hipError_t launch_conv3x3_wino24u(const ConvArgs& a, hipStream_t s); // conv3x3_wino24h's arithmetic, a U fragment shared by two tiles (one workgroup per CU)
 bool conv3x3_wino24p_supported(const ConvArgs& a);                  // = conv3x3_wino24h_supported
+bool conv3x3_wino24p_preferred(const ConvArgs& a);                  // supported and at least one item (tile pair x 64 channels) per CU
 hipError_t launch_conv3x3_wino24p(const ConvArgs& a, hipStream_t s); // conv3x3_wino24h's arithmetic: tile pairs, positions split over two waves (8 waves per CU)
 
 

@@ -319,7 +319,7 @@ class Engine:
 
     # ------------------------------------------------------------------ kernel-form options (include/imx.h: imx_set_option)
     def set_option(self, key, value):
-        """'mfma' = 'x3' | 'f32', 'latency_forms' = 'auto' | 'off' | 'on' | 'unfused', 'conv' = 'wino' | 'wino32' | 'direct',
+        """'mfma' = 'x3' | 'f32', 'latency_forms' = 'auto' | 'off' | 'on' | 'unfused', 'conv' = 'wino' | 'wino_h' | 'wino32' | 'direct',
         'gnn_tail' = 'auto' | 'fused' | 'bf16x3' | 'unfused', 'attention' = 'auto' | 'f16x2' | 'bf16x3'."""
         self._check(self.lib.imx_set_option(self.handle, key.encode(), str(value).encode()))
         return self

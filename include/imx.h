@@ -221,7 +221,10 @@ const char* imx_timing_form(imx_handle_t h, int index);
  *                           launches instead of one (same bytes: the A/B reference of the fused latency kernel);
  *   "conv"           "wino" (default) Winograd F(2x4,3x3) with its products on the fp16 matrix pipe: both transformed operands as two
  *                           fp16 planes scaled by a power of two (per tile in the fused first layer, per image -- from the producing
- *                           layer's maximum -- in the others), three plane products ("mfma" = "x3" only); "wino32" the same with every
+ *                           layer's maximum -- in the others), three plane products ("mfma" = "x3" only); a layer with at least one
+ *                           (tile pair x 64 output channels) item per CU runs on tile pairs (conv3x3_wino24p: a transformed-weight
+ *                           fragment serves two tiles), the others one tile per workgroup (conv3x3_wino24h) -- the same arithmetic,
+ *                           bit for bit; "wino_h" never uses the pair form (the A/B reference of that choice); "wino32" the same with every
  *                           product on the fp32 MFMA (the A/B reference); "direct" the direct implicit-GEMM kernel for every 3x3 layer
  *                           (the fallback for shapes Winograd rejects);
  *   "gnn_tail"       "auto" (default) = "fused": wherever the throughput forms run (more than 4096 feature rows, descriptor_dim 128) the

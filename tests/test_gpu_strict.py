@@ -138,7 +138,7 @@ def test_strict_bar_as_one_batched_call_from_images(name, B):
     torch.cuda.synchronize()
     forms = {r[0]: r[3] for r in eng.timing_report(forms=True)}
     eng.set_timing(False)
-    assert forms["qkv_proj"] == "gemm_x3:bf16x3" and forms["attention"] == "attention_h2:f16x2" and forms["conv2a"] == "conv3x3_wino24h:f16x2", forms
+    assert forms["qkv_proj"] == "gemm_x3:bf16x3" and forms["attention"] == "attention_h2:f16x2" and forms["conv2a"] == "conv3x3_wino24p:f16x2", forms
     alpha = float(util.sg_sd(d, variant="t")["bin_score"])
     summary = util.strict_compare_batch(g, out, eng, B, alpha, float(util.sg_config(d)["match_threshold"]))
     print(f"[strict e2e] {name} as one call of {B} pairs: {summary}")

@@ -249,6 +249,40 @@ def test_fp16_plane_convolutions_on_inputs_that_stress_their_scales():
         util.assert_close(desc[b].cpu().numpy(), ref["desc"][k].numpy(), f"image {b} of 260: descriptors")
 
 
+@pytest.mark.parametrize("H,W,B", [(120, 160, 24), (80, 96, 35), (123, 165, 40)])
+def test_tile_pair_winograd_form_is_bit_identical_to_the_tile_per_workgroup_form(H, W, B):
+    """Round 5: conv3x3_wino24p.hip runs the fp16-plane Winograd layers on PAIRS of tiles, the 24 positions split over two waves whose
+    accumulators meet through LDS before conv3x3_wino24h's epilogue -- chosen per layer where there is at least one item per CU
+    ("conv" = "wino"), the tile-per-workgroup kernel otherwise ("conv" = "wino_h": always).  Every output of the pair form sees
+    conv3x3_wino24h's arithmetic in the same order, so the two settings must agree BIT FOR BIT on semi and the descriptors -- which
+    carries every parity statement made for conv3x3_wino24h over to the pair form.  Shapes: whole tiles; 80x96 with 35 images (an odd
+    number of tiles at the second level: the last pair has a dead tile); ragged 123x165 (partial tiles, masked stores)."""
+    from image_matching_amd import _lib as L
+    from image_matching_amd.engine import Engine
+    d = 128
+    eng = Engine(util.sp_config(d, 64), util.sg_config(d), "cuda")
+    eng.load_state_dict(L.NET_SUPERPOINT, util.sp_sd(d))
+    xs = torch.cat([util.pair(700 + i, H, W)[i & 1] * (1.0 + (i % 5)) for i in range(B)]).cuda()
+    got = {}
+    for mode in ("wino_h", "wino"):
+        eng.set_option("conv", mode)
+        assert eng.get_option("conv") == mode
+        eng.timing_reset()
+        eng.set_timing(True)
+        semi, desc = eng.superpoint_dense(xs)
+        torch.cuda.synchronize()
+        got[mode] = (semi.clone(), desc.clone(), {r[0]: r[3] for r in eng.timing_report(forms=True)})
+        eng.set_timing(False)
+    fh, fp = got["wino_h"][2], got["wino"][2]
+    layers = ("conv2a", "conv2b_pool", "conv3a", "conv3b_pool", "conv4a", "conv4b", "convPaDa")
+    assert all(fh[k] == "conv3x3_wino24h:f16x2" for k in layers), fh
+    assert fp["conv2a"] == "conv3x3_wino24p:f16x2" and fp["convPaDa"] == "conv3x3_wino24p:f16x2", fp
+    assert all(fp[k] in ("conv3x3_wino24p:f16x2", "conv3x3_wino24h:f16x2") for k in layers), fp
+    assert torch.equal(got["wino"][0], got["wino_h"][0]), "semi differs between the pair form and the tile-per-workgroup form"
+    assert torch.equal(got["wino"][1], got["wino_h"][1]), "descriptors differ between the pair form and the tile-per-workgroup form"
+    assert torch.isfinite(got["wino"][0]).all()
+
+
 @pytest.mark.parametrize("radius", [1, 2, 3, 4, 5, 6, 9, 13])
 def test_nms_every_radius_bit_exact_vs_oracle(radius):
     """simple_nms is compare-only, so both forms (radius <= 4: the staged three-kernel form with bit-row masks; any other radius:

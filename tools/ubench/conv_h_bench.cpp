@@ -18,9 +18,6 @@ namespace imx { thread_local const char* last_form = nullptr; }
 #ifdef H_TRACE
 namespace imx { void conv_h_trace_read(long long* out); }
 #endif
-#ifdef U_TRACE
-namespace imx { void conv_u_trace_read(long long* out); }
-#endif
 #ifdef P_TRACE
 namespace imx { void conv_p_trace_read(long long* out); }
 #endif
@@ -64,7 +61,7 @@ static int run(int B, int H, int W, int Cin, int Cout, int pool, int blocked, fl
   for (int form = 0; form < 3; ++form) {
     a.out = form == 2 ? doutu : form ? douth : dout32;
     if (form == 2) { std::vector<unsigned> am0(256); hipMemcpy(am0.data(), damax_out, 1024, hipMemcpyDeviceToHost); amu.assign(am0.begin(), am0.begin() + (B < 256 ? B : 256)); hipMemset(damax_out, 0, 1024); }
-    auto go = [&]() { return form == 2 ? (getenv("FORM_U") ? launch_conv3x3_wino24u(a, 0) : launch_conv3x3_wino24p(a, 0)) : form ? launch_conv3x3_wino24h(a, 0) : launch_conv3x3_wino24(a, 0); };
+    auto go = [&]() { return form == 2 ? launch_conv3x3_wino24p(a, 0) : form ? launch_conv3x3_wino24h(a, 0) : launch_conv3x3_wino24(a, 0); };
     hipError_t err = go();
     hipDeviceSynchronize();
     if (err != hipSuccess || hipGetLastError() != hipSuccess) { printf("launch failed (form %d): %s\n", form, hipGetErrorString(err)); return 1; }
@@ -75,28 +72,20 @@ static int run(int B, int H, int W, int Cin, int Cout, int pool, int blocked, fl
     hipEventElapsedTime(&ms[form], e0, e1);
     ms[form] /= 10;
   }
-#ifdef U_TRACE
-  {
-    long long tr[16 * 8];
-    conv_u_trace_read(tr);
-    double s[8] = {0}; int n = 0;
-    for (int g = 0; g < 16; ++g) { if (!tr[g * 8 + 2]) continue; ++n; for (int i = 0; i < 8; ++i) s[i] += (double)tr[g * 8 + i]; }
-    const double items = (double)(((W + 15) / 16) * ((H + 7) / 8) * B / 2) * (Cout / 64) / 256.0, chunks = items * (Cin / 32);
-    printf("  U trace (wave 0 of %d workgroups; cycles per chunk of a tile PAIR): transform %.0f | barrier %.0f | MFMA phase %.0f | raw store + loads %.0f | barrier %.0f | epilogue per item %.0f | total per chunk %.0f\n",
-           n, s[0] / n / chunks, s[1] / n / chunks, s[2] / n / chunks, s[3] / n / chunks, s[4] / n / chunks, s[5] / n / items,
-           (s[0] + s[1] + s[2] + s[3] + s[4] + s[5]) / n / chunks);
-  }
-#endif
 #ifdef P_TRACE
   {
-    long long tr[16 * 8];
+    long long tr[16 * 16];
     conv_p_trace_read(tr);
-    double s[8] = {0}; int n = 0;
-    for (int g = 0; g < 16; ++g) { if (!tr[g * 8 + 2]) continue; ++n; for (int i = 0; i < 8; ++i) s[i] += (double)tr[g * 8 + i]; }
+    double s[16] = {0}; int n = 0;
+    for (int g = 0; g < 16; ++g) { if (!tr[g * 16 + 2]) continue; ++n; for (int i = 0; i < 16; ++i) s[i] += (double)tr[g * 16 + i]; }
     const double items = (double)(((W + 15) / 16) * ((H + 7) / 8) * B / 2) * (Cout / 64) / 256.0, chunks = items * (Cin / 32);
+    if (getenv("TRACE_WAVES"))
+      for (int g = 0; g < 8; ++g)
+        printf("    wave %d: transform tail %.0f | barrier %.0f | MFMA %.0f | raw store %.0f | barrier %.0f | epilogue/item %.0f | bookkeeping + loads %.0f | row 1 %.0f | row 2 %.0f | row 0 %.0f | row 3 %.0f\n", g, tr[g * 16] / chunks, tr[g * 16 + 1] / chunks,
+               tr[g * 16 + 2] / chunks, tr[g * 16 + 3] / chunks, tr[g * 16 + 4] / chunks, tr[g * 16 + 5] / items, tr[g * 16 + 8] / chunks, tr[g * 16 + 9] / chunks, tr[g * 16 + 10] / chunks, tr[g * 16 + 11] / chunks, tr[g * 16 + 12] / chunks);
     printf("  P trace (wave 0 of %d workgroups; cycles per chunk of a tile PAIR): loads + transform %.0f | barrier %.0f | MFMA phase %.0f | raw store %.0f | barrier %.0f | epilogue per item %.0f | total per chunk %.0f\n",
            n, s[0] / n / chunks, s[1] / n / chunks, s[2] / n / chunks, s[3] / n / chunks, s[4] / n / chunks, s[5] / n / items,
-           (s[0] + s[1] + s[2] + s[3] + s[4] + s[5]) / n / chunks);
+           (s[0] + s[1] + s[2] + s[3] + s[4] + s[5] + s[8] + s[9] + s[10] + s[11] + s[12]) / n / chunks);
   }
 #endif
 #ifdef H_TRACE
