@@ -7,6 +7,7 @@
 #   ERROR: No matching distribution found for opencv-python-headless==4.5.5.64
 # and `python -c "import cv2"` -> ModuleNotFoundError.  The rows therefore stay "partial" (parity vs cv2 unpinned; each kernel is
 # bit-exact against a restatement of OpenCV's published algorithm under oracle/).
+# The same on the GPU box (round 5): tools/try_opencv_gpu_box.txt -- no cv2, no index, no DNS there either.
 set -x
 python -c "import cv2; print(cv2.__version__)" || true
 pip download opencv-python-headless==4.5.5.64 -d /tmp/cvwheel --no-deps || true
