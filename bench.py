@@ -507,15 +507,38 @@ def roofline_block(rows, wl, B, steps, dt, lib_build, workload):
                            "(2500 TFLOP/s): `achieved` counts the executed plane products against THAT peak, so `frac` fell while the launch got shorter "
                            "(r04_v9: 10.4 ms at 0.647 of the fp32 peak); the kernel is now bound by the L2 -> register stream of the transformed weights "
                            "and by VALU issue (transform + split), DESIGN.md section 5h")
-        if name == "conv1ab_pool":
-            # what actually limits it: every wave streams its own copy of the transformed weights U (64 x 64 x 24 positions x two fp16 planes =
-            # 393216 bytes per 8x16-pixel tile) through the CU's vector-memory return path, 64 bytes per clock and CU
-            tiles = 2 * B * ((H + 7) // 8) * ((W + 15) // 16)
-            ubytes = tiles * 64 * 64 * 24 * 4
-            rf["limiter"] = {"what": "vector-memory return path (L1 -> registers) of the transformed weights U", "bytes_per_launch": ubytes,
-                             "rate_TBps": round(ubytes / avg_s / 1e12, 2), "peak_TBps_at_2400MHz": round(64 * 256 * 2.4e9 / 1e12, 2),
-                             "frac": round(ubytes / avg_s / (64 * 256 * 2.4e9), 4),
-                             "note": "64 B/clk per CU x 256 CUs; HBM traffic of the same launch is `traffic` (~1.03 x the algorithmic bytes)"}
+    # what limits the dominant kernel, FROM COUNTERS: tools/gpu_pmc_limiter.sh -> profiles/r*_pmc_limiter.json, taken on
+    # this build (same rule as `traffic`); rounds 1-4 computed this figure from a byte count (tiles x 393216 B of transformed weights)
+    try:
+        import glob
+        lim = None
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_limiter.json")), reverse=True):
+            with open(path) as fh:
+                cand = json.load(fh)
+            if cand.get("build") == lib_build:
+                lim, lim_path = cand, path
+                break
+        if lim is None:
+            rf["limiter_note"] = "dropped: no profiles/r*_pmc_limiter.json was taken on this build"
+        elif workload != "c3" or lim["pairs_per_gpu"] != B:
+            rf["limiter_note"] = f"dropped: the counter passes were taken at {lim['pairs_per_gpu']} C3 pairs per step, this run is {workload} at {B}"
+        elif name in lim["kernels"]:
+            k = lim["kernels"][name]
+            rf["limiter"] = {
+                "what": "share of the launch's cycles in which each unit is busy, rocprofv3 PMC passes on this build: the L1 (TCP) data path that "
+                        "returns the transformed weights U to the registers (64-byte accesses against 64 B/clk per CU), the matrix pipes, the "
+                        "vector ALU (input transform + fp16 split + epilogue), the LDS; `wait` = wave time at an s_waitcnt",
+                "source": os.path.relpath(lim_path, ROOT),
+                "l1_data_path": k.get("l1_data_path_frac"), "mfma_busy": k.get("mfma_busy"), "valu_active": k.get("valu_active_per_simd_cycle"),
+                "lds_active": k.get("lds_active_per_simd_cycle"), "wait": k.get("wait_any_of_wave_cycles"),
+                "l1_l2_read_bytes_per_launch": k.get("l1_l2_read_bytes"), "l1_l2_read_bytes_per_cu_cycle": k.get("l1_l2_read_bytes_per_cu_cycle"),
+                "l2_read_latency_cycles": k.get("l2_read_latency_cycles"), "frac": k.get("l1_data_path_frac")}
+            also = {n: {"l1_data_path": v.get("l1_data_path_frac"), "mfma_busy": v.get("mfma_busy"), "valu_active": v.get("valu_active_per_simd_cycle"),
+                        "wait": v.get("wait_any_of_wave_cycles")} for n, v in lim["kernels"].items() if n != name}
+            if also:
+                rf["limiter"]["other_kernels"] = also
+    except (OSError, ValueError, KeyError) as e:
+        rf["limiter_note"] = f"no usable PMC limiter file: {e}"
     # whole-pair view: time the matrix pipes would need at their dense peaks (fp32 MFMA 157.3, bf16 MFMA 2500 TFLOP/s) / step time
     per_step = {n: e[0] / steps for n, e in by.items()}          # launches per step
     step_s = dt / steps
