@@ -15,6 +15,7 @@
 //     2 images  mlp.3,  4 k-steps each              k-steps (b, h2) of this half's hidden blocks, 4 output blocks
 //   6 images    next product (q|k|v: 3 passes of 128 output channels; final_proj: 1 pass = 2 images), 4 k-steps (ob, h2) each
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -95,7 +96,11 @@ inline std::vector<uint16_t> gnn_tail_pack(const float* w1, int ld1, const float
 // gnn_tail_h2.hip: the same stream with every weight as TWO fp16 planes of w s, s = the power of two that brings its matrix's largest
 // |value| to [2^13, 2^14); images of [step][block][plane (2)][lane][8 halves] (8 KB per k-step).  Also returns what the kernel's
 // bounds need: the reciprocals of the three scales and the largest column L1 norm of w1 / w2 (a column = one output channel).
-struct GnnTailH2Consts { float w1_inv, w2_inv, w3_inv, l1_1, l1_2; };
+// loose_h / loose_x: estimates of how far gnn_tail_h2's BOUNDS of the hidden activations h and of x' sit above typical values --
+// (largest column L1 norm) / (median column L2 norm) of mlp.0' (times the same ratio of mlp.3 for x'), times an activation crest
+// factor of 2^4.  The bound is brought to 2^13 (pow2_of_bound); a value keeps both fp16 planes down to 2^-3, so beyond 2^16 the
+// typical operand starts to lose its low plane and imx_api.cpp runs that layer's tail on three bf16 planes instead.
+struct GnnTailH2Consts { float w1_inv, w2_inv, w3_inv, l1_1, l1_2, loose_h, loose_x; };
 inline uint16_t gt_f16_rne(float x) {      // fp32 -> fp16 bit pattern, round to nearest even (normal range and subnormals; the scaled weights never overflow)
   uint32_t u;
   memcpy(&u, &x, 4);
@@ -124,19 +129,28 @@ inline float gt_f16_f(uint16_t h) {
 }
 inline std::vector<uint16_t> gnn_tail_pack_h2(const float* w1, int ld1, const float* w2, int ld2, const float* w3, int ld3, int d, int n3,
                                               GnnTailH2Consts* consts) {
-  auto scale_of = [](const float* w, int rows, int cols, int ld, float* l1) {
+  auto scale_of = [](const float* w, int rows, int cols, int ld, float* l1, double* gain_ratio = nullptr) {
     double mx = 0.0, best = 0.0;
+    std::vector<double> l2(cols, 0.0);
     for (int c = 0; c < cols; ++c) {
-      double acc = 0.0;
-      for (int k = 0; k < rows; ++k) { const double a = std::fabs((double)w[(size_t)k * ld + c]); acc += a; if (a > mx) mx = a; }
+      double acc = 0.0, sq = 0.0;
+      for (int k = 0; k < rows; ++k) { const double a = std::fabs((double)w[(size_t)k * ld + c]); acc += a; sq += a * a; if (a > mx) mx = a; }
       if (acc > best) best = acc;
+      l2[c] = std::sqrt(sq);
     }
     if (l1) *l1 = (float)best;
+    if (gain_ratio) {
+      std::nth_element(l2.begin(), l2.begin() + cols / 2, l2.end());
+      *gain_ratio = l2[cols / 2] > 0 ? best / l2[cols / 2] : 1e30;
+    }
     int e = 0;
     if (mx > 0) std::frexp(mx, &e);
     return std::ldexp(1.0, 14 - e);
   };
-  const double s1 = scale_of(w1, 2 * d, 2 * d, ld1, &consts->l1_1), s2 = scale_of(w2, 2 * d, d, ld2, &consts->l1_2), s3 = scale_of(w3, d, n3, ld3, nullptr);
+  double g1 = 1.0, g2 = 1.0;
+  const double s1 = scale_of(w1, 2 * d, 2 * d, ld1, &consts->l1_1, &g1), s2 = scale_of(w2, 2 * d, d, ld2, &consts->l1_2, &g2), s3 = scale_of(w3, d, n3, ld3, nullptr);
+  consts->loose_h = (float)std::min(1e30, 16.0 * g1);
+  consts->loose_x = (float)std::min(1e30, 16.0 * g1 * g2);
   consts->w1_inv = (float)(1.0 / s1); consts->w2_inv = (float)(1.0 / s2); consts->w3_inv = (float)(1.0 / s3);
   const int per_step = 4 * 2 * 64 * 8;                                  // 16-bit values per k-step
   const int n_step = 2 * (16 + 8) + 8 * (n3 / d);

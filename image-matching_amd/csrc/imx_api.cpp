@@ -46,6 +46,7 @@ struct DevBuf {
 struct ConvW {
   float* w = nullptr;    // direct form  [9][Cin][Cout] (conv3x3.hip: IMX_CONV=direct, and the fallback for shapes wino24 rejects)
   float* wu24 = nullptr; // Winograd F(2x4,3x3) form (conv1ab_wino24.hip / conv3x3_wino24.hip layout)
+  float u_spread = 1.f;  // wino24h_pack: max |U| / median over output channels of their max |U| (the fp16-plane guard)
   void* wuh = nullptr;   // the same as two fp16 planes scaled by a power of two (conv3x3_wino24h.hip; wino24_pack.h: wino24h_pack), cin % 64 == 0 only
   float su_inv = 0.f;    // 1 / that power of two
   float* b = nullptr;
@@ -321,7 +322,7 @@ int make_conv(imx_handle_t h, ConvW& out, const std::map<std::string, HostTensor
   put_conv3(raw, conv, bn, cin, cout, cout, 0, w, b);
   out.w = upload(h, w);
   out.wu24 = upload(h, wino24_transform(w, cin, cout));
-  if (cin % 64 == 0 && cout % 64 == 0) out.wuh = upload_u16(h, wino24h_pack(w, cin, cout, &out.su_inv));
+  if (cin % 64 == 0 && cout % 64 == 0) out.wuh = upload_u16(h, wino24h_pack(w, cin, cout, &out.su_inv, &out.u_spread));
   out.b = upload(h, b);
   out.cin = cin;
   out.cout = cout;
@@ -442,7 +443,7 @@ int finalize_superpoint(imx_handle_t h) {
     put_conv3(raw, "convDa", bn ? "bnDa" : "", 128, 256, 512, 256, w, b);
     h->conv[7].w = upload(h, w);
     h->conv[7].wu24 = upload(h, wino24_transform(w, 128, 512));
-    h->conv[7].wuh = upload_u16(h, wino24h_pack(w, 128, 512, &h->conv[7].su_inv));
+    h->conv[7].wuh = upload_u16(h, wino24h_pack(w, 128, 512, &h->conv[7].su_inv, &h->conv[7].u_spread));
     h->conv[7].b = upload(h, b);
     h->conv[7].cin = 128;
     h->conv[7].cout = 512;
@@ -585,6 +586,9 @@ int finalize_superglue(imx_handle_t h) {
   return 0;
 }
 
+// the guards of the fp16-plane forms: see wino24_pack.h (spread) and gnn_tail_pack.h (loose_h / loose_x)
+constexpr float kConvSpreadMax = 16384.f, kTailLooseMax = 65536.f;
+
 hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 int pad32(int n) { return ((n + 31) / 32) * 32; }
 
@@ -644,27 +648,44 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   // the fused first layer starts the chain, so without it (conv = direct, shapes the Winograd kernels reject) the fp32 forms run
   unsigned* amax = nullptr;
   bool all_h = true;
-  for (int i = 1; i < 8; ++i) all_h = all_h && h->conv[i].wuh != nullptr;
+  // ... and weights whose transformed values fit ONE power-of-two scale per layer: a layer whose typical output channel sits more than
+  // 2^14 below the largest |U| (a checkpoint with one runaway channel) would push that channel's weights under 2^-3 x 2^13 / 2^14 and
+  // lose the low plane -- the whole chain then runs the fp32-MFMA Winograd kernels ("conv" reports it through imx_timing_form)
+  for (int i = 1; i < 8; ++i) all_h = all_h && h->conv[i].wuh != nullptr && h->conv[i].u_spread <= kConvSpreadMax;
+  // The maxima live in 256 slots per layer (the kernels' LDS tables): a batch of more than 256 images runs its 3x3 layers in slices of
+  // 256 images, each with its own tables, so that an image's scales -- and with them its low-order bits -- never depend on which other
+  // images share the call (tests/test_gpu_superpoint.py: image b of a 260-image batch equals the same image alone).
+  constexpr int kSlice = 256;
+  const int nslice = (B + kSlice - 1) / kSlice;
   if (blocked && all_h && h->opt.conv_f16 && !h->opt.mfma_f32) {
-    WS(am, unsigned, "sp.amax", (size_t)8 * 256 * 4);          // one word per (layer, image slot b % 256)
-    HIP_OK(h, hipMemsetAsync(am, 0, (size_t)8 * 256 * 4, s));
+    WS(am, unsigned, "sp.amax", (size_t)nslice * 8 * 256 * 4);          // one word per (slice, layer, image slot b % 256)
+    HIP_OK(h, hipMemsetAsync(am, 0, (size_t)nslice * 8 * 256 * 4, s));
     amax = am;
   }
   int layer = 0;
   auto conv = [&](const char* name, const ConvW& w, const float* in, float* out, int hh, int ww, bool pool, bool first, bool last = false) -> int {
-    ConvArgs a{};
     const int li = layer++;
+    const size_t in_img = (size_t)hh * ww * (first ? 1 : w.cin), out_img = (size_t)(pool ? hh / 2 : hh) * (pool ? ww / 2 : ww) * w.cout;
+    for (int sl = 0; sl < (amax ? nslice : 1); ++sl) {
+    ConvArgs a{};
+    const int b0 = amax ? sl * kSlice : 0, nb = amax ? std::min(kSlice, B - b0) : B;
     if (amax) {
-      a.amax_out = last ? nullptr : amax + (size_t)li * 256;
-      a.amax_in = li > 0 ? amax + (size_t)(li - 1) * 256 : nullptr;
+      unsigned* am = amax + (size_t)sl * 8 * 256;
+      a.amax_out = last ? nullptr : am + (size_t)li * 256;
+      a.amax_in = li > 0 ? am + (size_t)(li - 1) * 256 : nullptr;
       a.wuh = w.wuh; a.u_scale_inv = w.su_inv;
       a.c1a_l1 = h->c1a_l1; a.c1a_bmax = h->c1a_bmax;
     }
     a.in_blocked = (blocked && !first) ? 1 : 0;
     a.out_blocked = (blocked && !last) ? 1 : 0;
-    a.in = in; a.in2 = first ? img1 : nullptr; a.split = first ? split : 0;
-    a.w = w.w; a.wu24 = w.wu24; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out;
-    a.B = B; a.H = hh; a.W = ww; a.Cin = w.cin; a.Cout = w.cout; a.relu = 1; a.pool = pool ? 1 : 0; a.first = first ? 1 : 0;
+    if (first) {                       // images below `split` come from img0, the others from img1: the slice's view of that
+      if (b0 >= split) { a.in = img1 + (size_t)(b0 - split) * in_img; a.in2 = nullptr; a.split = nb; }
+      else { a.in = in + (size_t)b0 * in_img; a.in2 = img1; a.split = split - b0; }
+    } else {
+      a.in = in + (size_t)b0 * in_img; a.in2 = nullptr; a.split = 0;
+    }
+    a.w = w.w; a.wu24 = w.wu24; a.bias = w.b; a.w1 = h->w1; a.b1 = h->b1; a.out = out + (size_t)b0 * out_img;
+    a.B = nb; a.H = hh; a.W = ww; a.Cin = w.cin; a.Cout = w.cout; a.relu = 1; a.pool = pool ? 1 : 0; a.first = first ? 1 : 0;
     const bool fused1 = a.first && a.pool && !h->opt.conv_direct;
     const bool wino = !a.first && !h->opt.conv_direct && conv3x3_wino24_supported(a);
     const bool winoh = wino && amax && conv3x3_wino24h_supported(a);
@@ -675,6 +696,7 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
     const bool winop = winoh && h->opt.conv_f16 == 1 && conv3x3_wino24p_preferred(a);
     RUN(name, fused1h ? launch_conv1ab_wino24h(a, s) : fused1 ? launch_conv1ab_wino24(a, s) : winop ? launch_conv3x3_wino24p(a, s) : winoh ? launch_conv3x3_wino24h(a, s) :
               wino ? launch_conv3x3_wino24(a, s) : launch_conv3x3(a, s));
+    }
     return 0;
   };
   if (conv("conv1ab_pool", h->conv[0], img0, a1, H, W, true, true)) return -1;
@@ -875,7 +897,10 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     // "gnn_tail" = auto / fused: the same launch as three fp16 plane products (gnn_tail_h2.hip) where the two-plane attention runs (its
     // v maxima bound att) -- the maxima of x come from the previous layer's tail, for layer 0 from rows_amax
     bool tail_h2 = false;
-    if (tail && f16x2 && h->opt.gnn_tail != 2 && L.tail_stream_h2) {
+    // ("auto": only where the bounds that scale the operands are tight enough for both fp16 planes -- L.h2c.loose_*, computed from the
+    // weights at imx_finalize_weights; "fused" forces the fp16 form, "bf16x3" the other)
+    const bool h2_safe = L.h2c.loose_h <= kTailLooseMax && L.h2c.loose_x <= kTailLooseMax;
+    if (tail && f16x2 && h->opt.gnn_tail != 2 && L.tail_stream_h2 && (h2_safe || h->opt.gnn_tail == 1)) {
       ta.stream_h2 = L.tail_stream_h2;
       ta.w1_inv = L.h2c.w1_inv; ta.w2_inv = L.h2c.w2_inv; ta.w3_inv = L.h2c.w3_inv;
       ta.l1_1 = L.h2c.l1_1; ta.l1_2 = L.h2c.l1_2; ta.bmax_1 = L.bmax_1; ta.bmax_2 = L.bmax_2;
@@ -1456,7 +1481,19 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : o.conv_f16 == 2 ? "wino_h" : o.conv_f16 ? "wino" : "wino32";
     else if (k == "gnn_tail") h->opt_text = o.gnn_tail < 0 ? "auto" : o.gnn_tail == 2 ? "bf16x3" : o.gnn_tail ? "fused" : "unfused";
     else if (k == "attention") h->opt_text = o.attention < 0 ? "auto" : o.attention ? "f16x2" : "bf16x3";
-    else h->opt_text.clear();
+    else if (k == "arith_guard") {      // read-only: what the weights-derived guards decided (after imx_finalize_weights)
+      char buf[96];
+      float sp = 0.f;
+      for (int i = 1; i < 8; ++i) sp = std::max(sp, h->conv[i].u_spread);
+      snprintf(buf, sizeof buf, "conv: max spread 2^%.1f -> %s; gnn_tail bf16x3 layers:", std::log2(std::max(sp, 1.f)), sp <= kConvSpreadMax ? "f16x2" : "f32");
+      h->opt_text = buf;
+      for (size_t l = 0; l < h->layers.size(); ++l)
+        if (h->layers[l].tail_stream_h2 && !(h->layers[l].h2c.loose_h <= kTailLooseMax && h->layers[l].h2c.loose_x <= kTailLooseMax)) h->opt_text += " " + std::to_string(l);
+      float lx = 0.f;
+      for (const auto& L : h->layers) lx = std::max(lx, std::max(L.h2c.loose_h, L.h2c.loose_x));
+      snprintf(buf, sizeof buf, " (largest bound looseness 2^%.1f)", std::log2(std::max(lx, 1.f)));
+      h->opt_text += buf;
+    } else h->opt_text.clear();
     return h->opt_text.c_str();
   } catch (...) {
     return "";

@@ -1,5 +1,6 @@
 // wino24_pack.h -- host side of the Winograd F(2x4, 3x3) kernels: the transformed weights U = G2 g G4^T in the layouts the kernels read.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -82,9 +83,12 @@ inline float f16_to_f32(uint16_t h) {
 // conv3x3_wino24h.hip: U s_u as two fp16 planes (U s_u = h + m, round to nearest), s_u = the power of two that brings max |U| to
 // [2^13, 2^14); layout [Cout/64][Cin/32][position p = j*4 + i][plane][wave = co/16 % 4][lane = (ci%32 / 8)*16 + co%16][ci % 8].
 // w: [9][cin][cout].  Returns the bit patterns; *scale_inv = 1 / s_u.
-inline std::vector<uint16_t> wino24h_pack(const std::vector<float>& w, int cin, int cout, float* scale_inv) {
+// *spread (optional): max |U| over the median over the output channels of their own max |U| -- how far below the layer's one scale a
+// typical channel's weights sit (imx_api.cpp's guard: beyond 2^14 the scaled values of a typical channel lose their low plane)
+inline std::vector<uint16_t> wino24h_pack(const std::vector<float>& w, int cin, int cout, float* scale_inv, float* spread = nullptr) {
   const int nchunk = cin / 32;
   std::vector<double> U((size_t)cout * cin * 24);
+  std::vector<double> comax(cout, 0.0);
   double umax = 0.0;
   for (int co = 0; co < cout; ++co)
     for (int ci = 0; ci < cin; ++ci) {
@@ -96,8 +100,15 @@ inline std::vector<uint16_t> wino24h_pack(const std::vector<float>& w, int cin, 
           const double u = wino24_u(g, i, j);
           U[((size_t)co * cin + ci) * 24 + j * 4 + i] = u;
           if (std::fabs(u) > umax) umax = std::fabs(u);
+          if (std::fabs(u) > comax[co]) comax[co] = std::fabs(u);
         }
     }
+  if (spread) {
+    std::vector<double> m = comax;
+    std::nth_element(m.begin(), m.begin() + m.size() / 2, m.end());
+    const double med = m[m.size() / 2];
+    *spread = med > 0 ? (float)(umax / med) : (umax > 0 ? 3.0e38f : 1.f);
+  }
   int e = 0;
   if (umax > 0) std::frexp(umax, &e);                     // umax = f 2^e, f in [0.5, 1)
   const double su = std::ldexp(1.0, 14 - e);              // umax su in [2^13, 2^14)

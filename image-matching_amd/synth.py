@@ -247,12 +247,59 @@ def calibrated_stats(prefix):
             if k.startswith(prefix + "/") and not k.endswith("bin_score")}
 
 
-def make_superpoint_state_dict(descriptor_dim=128):
+def make_superpoint_state_dict(descriptor_dim=128, heavy=False):
     sd = synth_state_dict(superpoint_bn_shapes(descriptor_dim), SP_SEED)
-    return apply_bn_stats(sd, calibrated_stats(f"sp{descriptor_dim}"))
+    sd = apply_bn_stats(sd, calibrated_stats(f"sp{descriptor_dim}"))
+    return heavy_superpoint(sd) if heavy else sd
 
 
-def make_superglue_state_dict(descriptor_dim=128, keypoint_encoder=None, n_layers=18, variant="default"):
+# "Heavy" weight sets (round 5, VERDICT r4 item 3 / ADVICE r4): FUNCTION-PRESERVING re-parameterisations of the sets above by powers of
+# two.  A BatchNorm channel's gamma and beta times 2^k scales that channel's activation by 2^k (eval mode; ReLU and max-pooling commute
+# with a positive scale), and the next layer's weights of that input channel times 2^-k undo it: every product and every sum of the
+# reference's fp32 forward is scaled EXACTLY, so the reference's outputs are bit-identical to the base set's (tests/golden/make_golden.py
+# --heavy-check runs the reference on both and asserts it; tests/test_host.py does the same with the oracle) and every committed
+# golden vector stays valid -- while the FOLDED weights an implementation sees become heavy-tailed: one output channel 2^10 above
+# the rest (one column of a GNN layer's mlp.0' with a 2^10 times larger L1 norm: the bound that scales gnn_tail_h2's hidden
+# activations gets 2^10 looser), one 2^-10 below, per-image maxima dominated by one channel, a query / key channel pair at 2^7 / 2^-7.
+HEAVY_SP = (("down1.mpconv.1.conv", 0, 5, 10, "down1.mpconv.1.conv.3.weight"),       # conv2a channel 5 x 2^10, undone in conv2b
+            ("down2.mpconv.1.conv", 0, 7, -10, "down2.mpconv.1.conv.3.weight"),      # conv3a channel 7 x 2^-10, undone in conv3b
+            ("down3.mpconv.1.conv", 3, 11, 10, None))                                # conv4b channel 11 x 2^10, undone in convPa AND convDa
+HEAVY_SG_LAYERS = {3: (9, 10), 11: (200, 10), 14: (77, -10)}                         # layer -> (hidden channel of mlp.0, exponent)
+HEAVY_SG_QK = {5: (3, 7)}                                                            # layer -> (q/k channel, exponent): q x 2^k, k x 2^-k
+
+
+def heavy_superpoint(sd):
+    sd = OrderedDict((k, np.array(v, copy=True)) for k, v in sd.items())
+    for stem, idx, ch, e, nxt in HEAVY_SP:
+        f = np.float32(2.0 ** e)
+        sd[f"{stem}.{idx + 1}.weight"][ch] *= f
+        sd[f"{stem}.{idx + 1}.bias"][ch] *= f
+        for key in ([nxt] if nxt else ["convPa.weight", "convDa.weight"]):
+            sd[key][:, ch] *= np.float32(2.0 ** -e)
+    return sd
+
+
+def heavy_superglue(sd):
+    sd = OrderedDict((k, np.array(v, copy=True)) for k, v in sd.items())
+    for l, (ch, e) in HEAVY_SG_LAYERS.items():
+        f = np.float32(2.0 ** e)
+        sd[f"gnn.layers.{l}.mlp.1.weight"][ch] *= f
+        sd[f"gnn.layers.{l}.mlp.1.bias"][ch] *= f
+        sd[f"gnn.layers.{l}.mlp.3.weight"][:, ch] *= np.float32(2.0 ** -e)
+    for l, (ch, e) in HEAVY_SG_QK.items():
+        for k, ee in ((0, e), (1, -e)):
+            sd[f"gnn.layers.{l}.attn.proj.{k}.weight"][ch] *= np.float32(2.0 ** ee)
+            sd[f"gnn.layers.{l}.attn.proj.{k}.bias"][ch] *= np.float32(2.0 ** ee)
+    return sd
+
+
+def make_superglue_state_dict(descriptor_dim=128, keypoint_encoder=None, n_layers=18, variant="default", heavy=False):
+    if heavy:
+        return heavy_superglue(make_superglue_state_dict(descriptor_dim, keypoint_encoder, n_layers, variant))
+    return _make_superglue_state_dict(descriptor_dim, keypoint_encoder, n_layers, variant)
+
+
+def _make_superglue_state_dict(descriptor_dim=128, keypoint_encoder=None, n_layers=18, variant="default"):
     """variant "default": SG_GAINS (heavy-tailed scores, |S| up to several hundred); "t": SGT_GAINS (trained-model-like score
     statistics, see above).  Both carry BatchNorm running statistics calibrated with the reference's own modules."""
     kenc = list(keypoint_encoder) if keypoint_encoder is not None else SG_CONFIGS[descriptor_dim][0]

@@ -642,8 +642,54 @@ def strict_set():
             bin_score=np.float32(sd_t["bin_score"]), **{k: np.stack(v) for k, v in rows.items()})
 
 
+def heavy_check():
+    """Round 5: the "heavy" weight sets (synth.heavy_superpoint / heavy_superglue: channels of a few layers rescaled
+    by 2^+-10 and undone in the next layer, a query / key channel pair by 2^+-7) are function-preserving re-parameterisations by powers
+    of two, so the REFERENCE's fp32 forward must give bit-identical outputs on them.  Checked here with the reference's own modules on
+    strict seeds (C3 1000, 1001; C5 2000): Matching's ten outputs, SuperPoint's dense semi / desc, SuperGlue's dense gnn17 / scores_in
+    / Z.  Writes tests/golden/heavy_check.npz (what was compared, the largest difference = 0): every committed golden vector therefore
+    also pins the heavy sets, which is how tests/test_gpu_heavy.py uses them."""
+    rec = {"seeds": [], "max_abs_diff": [], "tensors": 0}
+    for H, W, d, K, seeds in ((480, 640, 128, 1024, (1000, 1001)), (960, 1280, 256, 2048, (2000,))):
+        kenc, iters, thr = synth.SG_CONFIGS[d]
+        cfg = {"superpoint": {"weights": None, "descriptor_dim": d, "nms_radius": 4, "keypoint_threshold": 0.005, "max_keypoints": K},
+               "superglue": {"weights": None, "descriptor_dim": d, "keypoint_encoder": kenc, "sinkhorn_iterations": iters, "match_threshold": thr}}
+        ms = []
+        for heavy in (False, True):
+            m = Matching(cfg).eval()
+            m.superpoint.load_state_dict(to_torch(synth.make_superpoint_state_dict(d, heavy=heavy)))
+            m.superglue.load_state_dict(to_torch(synth.make_superglue_state_dict(d, variant="t", heavy=heavy)))
+            ms.append(m)
+        for seed in seeds:
+            xa, xb_ = pair_tensor(seed, H, W)
+            outs = []
+            for m in ms:
+                pred = m({"image0": xa, "image1": xb_})
+                data = {"image0": xa, "image1": xb_, **{k: torch.stack(list(v)) for k, v in pred.items() if isinstance(v, (list, tuple))}}
+                dn = sg_dense(m.superglue, data)
+                sp = sp_dense(m.superpoint, xa)
+                flat = {k: (v[0] if isinstance(v, (list, tuple)) else v) for k, v in pred.items()}
+                flat.update({"dense_" + k: dn[k] for k in ("gnn0", "gnn1", "scores_in", "Z")})
+                flat.update({"sp_" + k: sp[k] for k in ("semi", "desc")})
+                outs.append(flat)
+            worst = 0.0
+            for k in outs[0]:
+                a, b = outs[0][k], outs[1][k]
+                assert torch.equal(a, b), f"{k} differs between the base and the heavy weight set (seed {seed}, d {d})"
+                worst = max(worst, float((a.double() - b.double()).abs().max()))
+                rec["tensors"] += 1
+            rec["seeds"].append(seed)
+            rec["max_abs_diff"].append(worst)
+            print(f"heavy check d={d} seed {seed}: {len(outs[0])} tensors bit-identical", flush=True)
+    npz("heavy_check.npz", seeds=np.array(rec["seeds"]), max_abs_diff=np.array(rec["max_abs_diff"], np.float64), tensors=np.int64(rec["tensors"]),
+        heavy_sp=np.array([[i, c, e] for _, i, c, e, _ in synth.HEAVY_SP]), heavy_sg_layers=np.array([[l, c, e] for l, (c, e) in synth.HEAVY_SG_LAYERS.items()]),
+        heavy_sg_qk=np.array([[l, c, e] for l, (c, e) in synth.HEAVY_SG_QK.items()]))
+
+
 if __name__ == "__main__":
-    if "--sweep-envelopes" in sys.argv:
+    if "--heavy-check" in sys.argv:
+        heavy_check()
+    elif "--sweep-envelopes" in sys.argv:
         sweep_envelopes()
     elif "--strict-set" in sys.argv:
         strict_set()

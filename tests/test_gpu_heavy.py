@@ -1,0 +1,138 @@
+"""Round 5: the fp16-plane forms on weights nobody chose.
+
+The "heavy" weight sets (image-matching_amd/synth.py: heavy_superpoint / heavy_superglue) are power-of-two re-parameterisations of the
+committed sets: the REFERENCE's outputs on them are bit-identical to its outputs on the base sets (tests/golden/make_golden.py
+--heavy-check, tests/golden/heavy_check.npz; tests/test_host.py repeats it for the oracle), so the strict fixtures pin them -- but the
+weights the library folds are heavy-tailed: BatchNorm scales 2^10 above / below their neighbours, a query / key channel pair at 2^+-7.
+What is held here, element-wise at 1e-4 + 1e-4|ref| and with equal match indices:
+  * SuperGlue on every form the weights-derived guard can pick -- "gnn_tail" = auto (gnn_tail_h2 where the bound that scales its
+    operands is tight, gnn_tail_x3 for the layers whose mlp.0' has a heavy column: asserted through imx_get_option("arith_guard") and
+    the timing forms), bf16x3, unfused -- and, reported, what FORCING the fp16 tail on those layers costs;
+  * SuperPoint's dense outputs and keypoints on the heavy convolution weights (per-image maxima dominated by one channel; one
+    output channel's transformed weights 2^10 above the layer's median: inside the guard, so the fp16-plane kernels run);
+  * the convolution guard itself: a variant with 2^20 pushes conv2a's spread past 2^14 and the chain must report the fp32 kernels.
+"""
+import numpy as np
+import pytest
+import torch
+
+from image_matching_amd import synth
+from tests import util
+from tests.test_gpu_strict import _pair_taps, _strict_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(d, K):
+    from image_matching_amd.engine import Engine
+    return Engine(util.sp_config(d, K), util.sg_config(d), "cuda")
+
+
+@pytest.mark.parametrize("tail", ["auto", "bf16x3", "unfused", "fused"])
+def test_heavy_superglue_weights_strict_on_every_form_the_guard_can_pick(tail):
+    from image_matching_amd import _lib as L
+    name = "strict_c3.npz"
+    g, per_seed = _strict_inputs(name)
+    H, W, d, K = (int(g[k]) for k in ("H", "W", "d", "K"))
+    eng = _engine(d, K)
+    sd = util.to_torch(synth.make_superglue_state_dict(d, variant="t", heavy=True))
+    eng.load_state_dict(L.NET_SUPERGLUE, sd)
+    eng.set_option("latency_forms", "off").set_option("gnn_tail", tail)
+    guard = eng.get_option("arith_guard")
+    heavy_layers = sorted(l for l, (c, e) in synth.HEAVY_SG_LAYERS.items() if e > 0)
+    assert guard.split("layers:")[1].split("(")[0].split() == [str(l) for l in heavy_layers], guard
+    eng.set_debug(True)
+    alpha, thr = float(sd["bin_score"]), float(util.sg_config(d)["match_threshold"])
+    worst = {"gnn17": 0.0, "scores_in": 0.0, "Z": 0.0}
+    bad = 0
+    for s in range(4):
+        data, ref = per_seed[s]
+        eng.timing_reset()
+        eng.set_timing(True)
+        out = eng.superglue(data["keypoints0"].cuda(), data["scores0"].cuda(), data["descriptors0"].cuda(), (1, 1, H, W),
+                            data["keypoints1"].cuda(), data["scores1"].cuda(), data["descriptors1"].cuda(), (1, 1, H, W))
+        torch.cuda.synchronize()
+        rows = eng.timing_report(forms=True)
+        eng.set_timing(False)
+        tails = sorted({r[3] for r in rows if r[0] == "gnn_tail"})
+        if tail == "auto":
+            assert tails == ["gnn_tail_h2:f16x2", "gnn_tail_x3:bf16x3"], tails      # the guard moved the heavy layers, and only those
+        elif tail == "bf16x3":
+            assert tails == ["gnn_tail_x3:bf16x3"], tails
+        elif tail == "fused":
+            assert tails == ["gnn_tail_h2:f16x2"], tails
+        m0, m1 = out[0].cpu().numpy(), out[1].cpu().numpy()
+        g0, g1 = _pair_taps(eng, K)
+        S = eng.fetch("scores_in")[0, :K, :K]
+        Z = util.transport_Z(S, eng.fetch("u")[0], eng.fetch("v")[0], K, K, alpha)
+        tag = f"heavy SuperGlue weights, seed {int(g['seeds'][s])} [gnn_tail={tail}]"
+        for key, mine, full in (("gnn17", np.stack([g0, g1]), np.stack([ref["gnn0"], ref["gnn1"]])), ("scores_in", S, ref["scores_in"]), ("Z", Z, ref["Z"])):
+            worst[key] = max(worst[key], util.tolerance_used(mine, full))
+            if tail != "fused":
+                util.assert_close(mine, full, f"{tag}: {key} vs the oracle, every element")
+        if tail != "fused":
+            for key, (mine, fx) in util.strict_samples(g, s, g0, g1, S, Z).items():
+                util.assert_close(mine, fx, f"{tag}: {key} vs the reference's sample")
+            util.strict_index_check(g, s, m0[0], m1[0], thr, tag)
+        else:
+            bad += int((m0[0] != g["matches0"][s]).sum())
+    print(f"[heavy] SuperGlue, gnn_tail={tail}: guard '{guard}'; worst fraction of the 1e-4+1e-4|ref| tolerance used over 4 strict seeds: "
+          + ", ".join(f"{k} {v:.3f}" for k, v in worst.items()) + (f"; match indices differing from the reference's: {bad} (FORCED fp16 tail on the heavy layers: reported, not asserted)" if tail == "fused" else ""))
+
+
+@pytest.mark.parametrize("conv", ["wino", "wino_h", "wino32"])
+def test_heavy_superpoint_weights_vs_reference_golden(conv):
+    from image_matching_amd import _lib as L
+    for name in ("sp_small.npz", "sp_ragged.npz"):
+        g = util.golden(name)
+        H, W, seed, K = int(g["H"]), int(g["W"]), int(g["seed"]), int(g["max_keypoints"])
+        eng = _engine(128, K)
+        eng.load_state_dict(L.NET_SUPERPOINT, util.to_torch(synth.make_superpoint_state_dict(128, heavy=True)))
+        eng.set_option("conv", conv)
+        guard = eng.get_option("arith_guard")
+        assert "-> f16x2" in guard, guard                       # spread 2^10: inside the guard, the fp16-plane kernels run
+        x = torch.cat(util.pair(seed, H, W))
+        eng.timing_reset()
+        eng.set_timing(True)
+        eng.set_debug(True)
+        kpts, _, _, n = eng.superpoint(x.cuda())
+        torch.cuda.synchronize()
+        forms = {r[0]: r[3] for r in eng.timing_report(forms=True)}
+        eng.set_timing(False)
+        assert forms["conv2b_pool"].startswith("conv3x3_wino24:f32" if conv == "wino32" else "conv3x3_wino24h:f16x2"), forms
+        x4 = eng.fetch("x4").copy(); semi = eng.fetch("semi")
+        x4[..., 11] *= np.float32(2.0 ** -10)            # the heavy set carries conv4b's channel 11 at 2^10 (undone in convPa / convDa): exact
+        nchw = lambda a: np.transpose(a, (0, 3, 1, 2))
+        util.assert_close(nchw(x4), g["x4"], f"{name}: x4 on the heavy convolution weights ({conv})")
+        util.assert_close(nchw(semi), g["semi"], f"{name}: semi on the heavy convolution weights ({conv})")
+        print(f"[heavy] SuperPoint {name} conv={conv}: x4 uses {util.tolerance_used(nchw(x4), g['x4']):.3f}, semi {util.tolerance_used(nchw(semi), g['semi']):.3f} of the tolerance; guard '{guard}'")
+        for side in (0, 1):
+            kp = kpts[side, :n[side]].cpu().numpy()
+            assert {tuple(p) for p in kp.astype(int)} == {tuple(p) for p in g[f"keypoints{side}"].astype(int)}, f"{name}: keypoint set, image {side}"
+
+
+def test_convolution_guard_moves_the_chain_to_the_fp32_kernels():
+    """One BatchNorm scale at 2^20: conv2a's transformed weights spread over more than 2^14, the typical channel would lose its low fp16
+    plane under the layer's one scale -- the guard must put the chain on the fp32-MFMA Winograd kernels (and say so), and the outputs
+    still sit inside the tolerance of the SAME golden vectors (the re-parameterisation is exact for the reference)."""
+    from image_matching_amd import _lib as L
+    sd = synth.make_superpoint_state_dict(128)
+    f = np.float32(2.0 ** 20)
+    sd["down1.mpconv.1.conv.1.weight"][5] *= f
+    sd["down1.mpconv.1.conv.1.bias"][5] *= f
+    sd["down1.mpconv.1.conv.3.weight"][:, 5] *= np.float32(2.0 ** -20)
+    g = util.golden("sp_small.npz")
+    H, W, seed, K = int(g["H"]), int(g["W"]), int(g["seed"]), int(g["max_keypoints"])
+    eng = _engine(128, K)
+    eng.load_state_dict(L.NET_SUPERPOINT, util.to_torch(sd))
+    guard = eng.get_option("arith_guard")
+    assert "-> f32" in guard, guard
+    eng.timing_reset()
+    eng.set_timing(True)
+    eng.set_debug(True)
+    eng.superpoint(torch.cat(util.pair(seed, H, W)).cuda())
+    torch.cuda.synchronize()
+    forms = {r[0]: r[3] for r in eng.timing_report(forms=True)}
+    eng.set_timing(False)
+    assert forms["conv2a"] == "conv3x3_wino24:f32" and forms["conv1ab_pool"] == "conv1ab_wino24:f32", forms
+    util.assert_close(np.transpose(eng.fetch("semi"), (0, 3, 1, 2)), g["semi"], "semi behind the convolution guard")

@@ -209,12 +209,14 @@ def test_every_conv_form_vs_reference_golden(monkeypatch, mode, form):
 
 
 def test_fp16_plane_convolutions_on_inputs_that_stress_their_scales():
-    """conv = wino (round 4): the Winograd products run on two fp16 planes per operand, scaled by powers of two taken from the tile's image
-    patch (first layer) and from the producing layer's per-image maximum (the others).  Inputs that stress exactly that: an all-black
-    image (maxima of zero / bias-only activations), images of very different magnitudes in ONE batch (x 255, x 1e-3: every image
-    carries its own scale), an image that is black except for one bright corner (tiles whose own maximum is zero next to one that is
-    not), and a batch of 260 images (the maxima live in 256 slots: images 256.. share slots with 0..).  Dense semi / descriptors against
-    the oracle, 1e-4 of each tensor's range."""
+    """conv = wino: the Winograd products run on two fp16 planes per operand, scaled by powers of two taken from the tile's image patch
+    (first layer) and from the producing layer's per-image maximum (the others).  Inputs that stress exactly that, each held ELEMENT-WISE
+    to 1e-4 + 1e-4|ref| against the oracle (round 5: no tolerance scaled by the tensor's range; the two tensors on which the fp32
+    reference arithmetic itself leaves that tolerance are float64-anchored, see below): an all-black image (maxima of zero /
+    bias-only activations); images of very different magnitudes in ONE batch (x 255, x 1e-3: every image carries its own scale); an
+    image that is black except for one bright corner; and large dynamic range INSIDE one image, which is the case a per-image scale can
+    hurt -- texture at x 1 next to a x 255 block, and a x 1e-3 image with a single saturated pixel (the dim texture sits 2^8 / 2^10
+    below the image's maximum)."""
     from oracle import superpoint_ref
     from image_matching_amd import _lib as L
     from image_matching_amd.engine import Engine
@@ -223,10 +225,15 @@ def test_fp16_plane_convolutions_on_inputs_that_stress_their_scales():
     sd = util.sp_sd(d)
     eng = Engine(cfg, util.sg_config(d), "cuda")
     eng.load_state_dict(L.NET_SUPERPOINT, sd)
-    base = [util.pair(900 + i, H, W)[i & 1] for i in range(6)]
+    base = [util.pair(900 + i, H, W)[i & 1] for i in range(8)]
     corner = torch.zeros(1, 1, H, W)
     corner[..., :9, :13] = base[4][..., :9, :13]
-    xs = torch.cat([torch.zeros(1, 1, H, W), base[0], base[1] * 255.0, base[2] * 1e-3, corner, base[3]])
+    block = base[5].clone()
+    block[..., 20:44, 30:70] *= 255.0
+    pixel = base[6] * 1e-3
+    pixel[..., 40, 50] = 1.0
+    xs = torch.cat([torch.zeros(1, 1, H, W), base[0], base[1] * 255.0, base[2] * 1e-3, corner, base[3], block, pixel])
+    what = ["black", "plain", "x255", "x1e-3", "black with one bright corner", "plain", "texture next to a x255 block", "x1e-3 with one saturated pixel"]
     eng.timing_reset()
     eng.set_timing(True)
     semi, desc = eng.superpoint_dense(xs.cuda())
@@ -234,19 +241,47 @@ def test_fp16_plane_convolutions_on_inputs_that_stress_their_scales():
     eng.set_timing(False)
     assert forms["conv1ab_pool"] == "conv1ab_wino24h:f16x2" and forms["conv4b"] == "conv3x3_wino24h:f16x2", forms
     ref = superpoint_ref.superpoint_forward(xs, sd, cfg, return_dense=True)
+    # the same oracle in float64: where the REFERENCE arithmetic itself (fp32) leaves the element-wise tolerance of its float64
+    # evaluation -- semi of the two images that hold x 255 values: its absolute error scales with the input, the 1e-4 does not -- no
+    # fp32 implementation can be held element-wise, and the HIP result must instead be as close to float64 as the fp32 oracle is
+    # (util.assert_fp64_anchored: rms within 2 x, maximum within 2.5 x); a property of the reference alone decides which rule applies
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    s64, d64 = superpoint_ref.heads_bn(superpoint_ref.encoder_bn(xs.double(), sd64), sd64)
+    f64 = {"semi": s64, "desc": d64}
+    used, anchored = [], []
     for b in range(xs.shape[0]):
-        for name, mine, want in (("semi", semi[b].cpu().numpy(), ref["semi"][b].numpy()), ("desc", desc[b].cpu().numpy(), ref["desc"][b].numpy())):
-            scale = max(1.0, float(np.abs(want).max()))
-            assert np.isfinite(mine).all(), f"image {b} {name}: non-finite values"
-            assert np.abs(mine - want).max() <= 1e-4 * scale, f"image {b} {name}: {np.abs(mine - want).max():.3e} vs range {scale:.3e}"
-    big = torch.cat([base[i % 6] * (1.0 + (i % 7)) for i in range(260)])
-    semi, desc = eng.superpoint_dense(big.cuda())
-    pick = [0, 5, 255, 256, 259]
-    ref = superpoint_ref.superpoint_forward(big[pick], sd, cfg, return_dense=True)
-    for k, b in enumerate(pick):
-        scale = max(1.0, float(ref["semi"][k].abs().max()))
-        assert np.abs(semi[b].cpu().numpy() - ref["semi"][k].numpy()).max() <= 1e-4 * scale, f"image {b} of 260: semi"
-        util.assert_close(desc[b].cpu().numpy(), ref["desc"][k].numpy(), f"image {b} of 260: descriptors")
+        for name, mine in (("semi", semi[b].cpu().numpy()), ("desc", desc[b].cpu().numpy())):
+            want, exact = ref[name][b].numpy(), f64[name][b].numpy()
+            assert np.isfinite(mine).all(), f"image {b} ({what[b]}) {name}: non-finite values"
+            if util.tolerance_used(want, exact) <= 1.0:
+                util.assert_close(mine, want, f"image {b} ({what[b]}): {name}, element-wise")
+                used.append(f"{what[b]} {name} {util.tolerance_used(mine, want):.3f}")
+            else:
+                util.assert_fp64_anchored(mine, want, exact, f"image {b} ({what[b]}): {name}")
+                anchored.append(f"{what[b]} {name} (the fp32 oracle itself uses {util.tolerance_used(want, exact):.1f} x the tolerance against float64)")
+    assert len(anchored) <= 2, anchored
+    print("[scales] fraction of the element-wise tolerance used: " + ", ".join(used) + "; float64-anchored instead: " + "; ".join(anchored))
+
+
+def test_an_image_of_a_260_image_batch_equals_the_same_image_alone():
+    """The per-image maxima behind the fp16 scales live in 256 slots per layer: a batch of more than 256 images runs its 3x3 layers in
+    slices of 256 images with separate tables (imx_api.cpp), so an image's scales never depend on which other images share the call --
+    image b of a 260-image batch is BIT-IDENTICAL to the same image in a call of its own (different kernels run: the batch takes the
+    tile-pair form, the single image the tile-per-workgroup form, which agree bit for bit)."""
+    from image_matching_amd import _lib as L
+    from image_matching_amd.engine import Engine
+    H, W, d = 72, 104, 128
+    eng = Engine(util.sp_config(d, 64), util.sg_config(d), "cuda")
+    eng.load_state_dict(L.NET_SUPERPOINT, util.sp_sd(d))
+    eng.set_option("latency_forms", "off")        # (the 1x1 heads of a single image would otherwise take their latency form: another summation order)
+    base = [util.pair(900 + i, H, W)[i & 1] for i in range(6)]
+    big = torch.cat([base[i % 6] * (1.0 + (i % 7)) for i in range(260)]).cuda()
+    semi, desc = eng.superpoint_dense(big)
+    semi, desc = semi.clone(), desc.clone()
+    for b in (0, 5, 255, 256, 259):
+        s1, d1 = eng.superpoint_dense(big[b:b + 1])
+        assert torch.equal(s1[0], semi[b]), f"image {b} of 260: semi differs from the same image alone"
+        assert torch.equal(d1[0], desc[b]), f"image {b} of 260: descriptors differ from the same image alone"
 
 
 @pytest.mark.parametrize("H,W,B", [(120, 160, 24), (80, 96, 35), (123, 165, 40)])
