@@ -284,7 +284,7 @@ def pcie_inclusive(matching, wl, B, steps=6, scale=0.5):
 
 class ClockSampler:
     """sclk (MHz) and socket power (W) of this process's GPU from sysfs (hwmon freq1_input / power1_input of the amdgpu card),
-    sampled by a thread every 20 ms while the timed region runs.  Reported, never used to scale `value`."""
+    sampled by a child process every 20 ms while the timed region runs.  Reported, never used to scale `value`."""
 
     def __init__(self, device):
         import glob
@@ -313,25 +313,34 @@ class ClockSampler:
         except (OSError, ValueError):
             return None
 
+    # (a CHILD process does the polling: a sampling thread in this process would compete for the GIL with the thread that
+    # launches the timed steps -- ADVICE r4)
+    _CHILD = ("import sys, time, json\n"
+              "f, p = sys.argv[1], sys.argv[2]\n"
+              "import select\n"
+              "out = []\n"
+              "while not select.select([sys.stdin], [], [], 0.02)[0]:\n"
+              "    try:\n"
+              "        out.append((int(open(f).read()) / 1e6, int(open(p).read()) / 1e6))\n"
+              "    except (OSError, ValueError):\n"
+              "        pass\n"
+              "print(json.dumps(out))\n")
+
     def start(self):
         if not self.files:
             return
-        import threading
-        self._stop, self.samples = False, []
-
-        def loop():
-            while not self._stop:
-                r = self._read()
-                if r:
-                    self.samples.append(r)
-                time.sleep(0.02)
-        self._thread = threading.Thread(target=loop, daemon=True)
-        self._thread.start()
+        import subprocess
+        self.samples = []
+        self._thread = subprocess.Popen([sys.executable, "-c", self._CHILD, self.files[1], self.files[2]], stdin=subprocess.PIPE,
+                                        stdout=subprocess.PIPE, text=True)
 
     def stop(self):
         if self._thread:
-            self._stop = True
-            self._thread.join()
+            try:
+                out, _ = self._thread.communicate("stop\n", timeout=5)
+                self.samples = [tuple(x) for x in json.loads(out)]
+            except Exception:       # noqa: BLE001 -- the sampler is a report, never a reason to fail the bench
+                self._thread.kill()
             self._thread = None
 
     def report(self):
@@ -410,7 +419,10 @@ def parity_in_run_strict(matching, wl, pair_ids, img0, img1, sd_sg_default):
     rep["weights"] = "SuperGlue set 't' (synth.SGT_GAINS): scores_in std ~5, bin_score = mean + 2 sigma; SuperPoint unchanged"
     rep["rule"] = ("keypoint sets identical; match indices identical except exact ties of the reference's own fp32 Z and rows whose reference score is within 1e-4 of "
                    "match_threshold (both counted); matching scores and the reference's samples of gnn17 / scores_in / Z: images in, so SuperPoint's within-tolerance "
-                   "differences are amplified by the GNN -- asserted at 10x, counted at 1x of 1e-4 + 1e-4|ref| (the SuperGlue stage alone is held to 1x in tests/test_gpu_strict.py)")
+                   "differences are amplified by the GNN -- scores_in / Z asserted against the fixture's float64 samples at 1e-4 + 1e-4|f64| + 2.5 x the reference's own "
+                   "fp32-vs-float64 envelope of that seed, gnn17 and the matching scores at 3x, all counted at 1x of 1e-4 + 1e-4|ref| with every outlier listed "
+                   "beside the reference's own distance from float64 at that element (the SuperGlue stage alone is held to 1x in tests/test_gpu_strict.py); "
+                   "a separate untimed pass with the 't' SuperGlue weights on the resident pairs, not the timed step itself")
     return rep
 
 
@@ -790,7 +802,8 @@ def main():
                    "c2": "images/sec (SuperPoint-only, 640x480, NMS + top-1024 kpts)"}[args.workload],
         "value": round(value, 3), "unit": "images/s" if sp_only else "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "compute_pipe": "fp32 products as exact-split plane products on the 16-bit matrix pipes (two fp16 planes x three products: convolutions, attention, GNN tails; three bf16 planes x six products: the other linear layers), fp32 accumulation",
+        "data": "synthetic",
         "config": {"workload": wl["name"], "pairs_per_gpu_per_step": B, "global_pairs_per_step": world * B,
                    "parallelism": f"pair-sharded x{world}" + ((" + RCCL gather of match records to rank 0" if backend == "nccl" else
                                                                 f" + {backend} (host-side bring-up hook, NOT RCCL) gather of match records to rank 0") if use_pg else ""),

@@ -634,13 +634,17 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   // Activations between the Winograd layers are channel-blocked (B, C/8, H, W, 8) -- dense patch loads for the next layer
   // (conv3x3_wino24.hip); the last 3x3 layer writes NHWC rows for the 1x1-conv GEMMs.  IMX_CONV=direct (or a layer the Winograd
   // kernels reject) keeps NHWC everywhere: the direct kernel reads nothing else.
-  bool blocked = !h->opt.conv_direct;
+  bool blocked = !h->opt.conv_direct, h_shapes = true;
   {
     const int hs[7] = {H2, H2, H4, H4, Hc, Hc, Hc}, ws_[7] = {W2, W2, W4, W4, Wc, Wc, Wc};
     for (int i = 1; i < 8 && blocked; ++i) {
       ConvArgs t{};
       t.H = hs[i - 1]; t.W = ws_[i - 1]; t.Cin = h->conv[i].cin; t.Cout = h->conv[i].cout; t.wu24 = h->conv[i].wu24;
       blocked = conv3x3_wino24_supported(t);
+      // the fp16-plane kernel's OWN predicate, in the same pre-pass (the chain used to be enabled on the fp32 kernel's
+      // predicate and a layer the fp16 kernel then rejected was a hard error; now the whole chain falls back to the fp32 kernels)
+      t.wuh = h->conv[i].wuh; t.u_scale_inv = h->conv[i].su_inv; t.amax_in = reinterpret_cast<const unsigned*>(h);      // (any non-null pointer: shape check only)
+      h_shapes = h_shapes && blocked && conv3x3_wino24h_supported(t);
     }
   }
   // "conv" = "wino": the layers after the first run their Winograd products on the fp16 matrix pipe (conv3x3_wino24h.hip).  Each needs an
@@ -657,7 +661,7 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   // images share the call (tests/test_gpu_superpoint.py: image b of a 260-image batch equals the same image alone).
   constexpr int kSlice = 256;
   const int nslice = (B + kSlice - 1) / kSlice;
-  if (blocked && all_h && h->opt.conv_f16 && !h->opt.mfma_f32) {
+  if (blocked && all_h && h_shapes && h->opt.conv_f16 && !h->opt.mfma_f32) {
     WS(am, unsigned, "sp.amax", (size_t)nslice * 8 * 256 * 4);          // one word per (slice, layer, image slot b % 256)
     HIP_OK(h, hipMemsetAsync(am, 0, (size_t)nslice * 8 * 256 * 4, s));
     amax = am;
@@ -973,6 +977,10 @@ int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
     if (v == "wino") { o.conv_direct = 0; o.conv_f16 = 1; }
     else if (v == "wino_h") { o.conv_direct = 0; o.conv_f16 = 2; }
     else if (v == "wino32") { o.conv_direct = 0; o.conv_f16 = 0; }
+    else if (v == "wx3") {             // round 3's bf16-plane experiment, deleted in round 4: its nearest living form
+      fprintf(stderr, "imx: conv = wx3 was removed (round 4); using wino32\n");
+      o.conv_direct = 0; o.conv_f16 = 0;
+    }
     else if (v == "direct") o.conv_direct = 1;
     else return -1;
   } else {

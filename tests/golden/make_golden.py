@@ -686,8 +686,43 @@ def heavy_check():
         heavy_sg_qk=np.array([[l, c, e] for l, (c, e) in synth.HEAVY_SG_QK.items()]))
 
 
+def strict_ties():
+    """the strict tests excuse rows / columns on an EXACT tie of the reference's own fp32 Z (top-1 minus top-2 == 0.0) --
+    but any index passed there.  This writes the tied PARTNERS (tests/golden/strict_ties.npz: per tie, the indices whose Z equals the
+    maximum, from the reference's own forward), so that the tests can require the reported index to be one of them (or -1)."""
+    out = []
+    for fi, name in enumerate(("strict_c3", "strict_c5")):
+        g = dict(np.load(os.path.join(OUT, name + ".npz")))
+        H, W, d, K = (int(g[k]) for k in ("H", "W", "d", "K"))
+        kenc, iters, thr = synth.SG_CONFIGS[d]
+        todo = [s for s in range(len(g["seeds"])) if (g["gap0"][s] == 0).any() or (g["gap1"][s] == 0).any()]
+        if not todo:
+            continue
+        cfg = {"superpoint": {"weights": None, "descriptor_dim": d, "nms_radius": 4, "keypoint_threshold": 0.005, "max_keypoints": K},
+               "superglue": {"weights": None, "descriptor_dim": d, "keypoint_encoder": kenc, "sinkhorn_iterations": iters, "match_threshold": thr}}
+        m = Matching(cfg).eval()
+        m.superpoint.load_state_dict(to_torch(synth.make_superpoint_state_dict(d)))
+        m.superglue.load_state_dict(to_torch(synth.make_superglue_state_dict(d, variant="t")))
+        for s in todo:
+            xa, xb_ = pair_tensor(int(g["seeds"][s]), H, W)
+            pred = m({"image0": xa, "image1": xb_})
+            assert np.array_equal(pred["matches0"][0].numpy(), g["matches0"][s])
+            data = {"image0": xa, "image1": xb_, **{k: torch.stack(list(v)) for k, v in pred.items() if isinstance(v, (list, tuple))}}
+            Z = sg_dense(m.superglue, data)["Z"][0, :-1, :-1]
+            for axis, gaps in ((0, g["gap0"][s]), (1, g["gap1"][s])):
+                for idx in np.nonzero(gaps == 0)[0]:
+                    line = Z[idx] if axis == 0 else Z[:, idx]
+                    partners = torch.nonzero(line == line.max())[:, 0].numpy()
+                    assert 2 <= len(partners) <= 8
+                    out.append([fi, s, axis, int(idx)] + list(map(int, partners)) + [-1] * (8 - len(partners)))
+                    print(f"{name} seed {int(g['seeds'][s])}: {'row' if axis == 0 else 'column'} {int(idx)} ties over {list(map(int, partners))}", flush=True)
+    npz("strict_ties.npz", ties=np.array(out, np.int32).reshape(-1, 12))
+
+
 if __name__ == "__main__":
-    if "--heavy-check" in sys.argv:
+    if "--strict-ties" in sys.argv:
+        strict_ties()
+    elif "--heavy-check" in sys.argv:
         heavy_check()
     elif "--sweep-envelopes" in sys.argv:
         sweep_envelopes()

@@ -28,26 +28,13 @@ def _strict_inputs(name):
     fixture's samples of the reference's tensors."""
     if name in _INPUTS:
         return _INPUTS[name]
-    from oracle import superglue_ref, superpoint_ref
+    from tests import oracle_jobs
     g = util.golden(name)
-    H, W, d, K = (int(g[k]) for k in ("H", "W", "d", "K"))
-    torch.set_num_threads(min(32, torch.get_num_threads()))
-    sd_sp, sd_sg = util.sp_sd(d), util.sg_sd(d, variant="t")
     per_seed = []
-    for s, seed in enumerate(g["seeds"]):
-        x0, x1 = util.pair(int(seed), H, W)
-        data = {"image0": x0, "image1": x1}
-        for side, x in (("0", x0), ("1", x1)):
-            dense = superpoint_ref.superpoint_forward(x, sd_sp, util.sp_config(d, K), return_dense=True)["desc"]
-            kp = torch.from_numpy(g["kpts" + side][s].astype(np.float32))[None]
-            data["keypoints" + side] = kp
-            data["scores" + side] = torch.from_numpy(g["scores" + side][s])[None]
-            data["descriptors" + side] = superpoint_ref.sample_descriptors(kp, dense, 8)
-        dn = superglue_ref.superglue_forward(data, sd_sg, util.sg_config(d), return_dense=True)["dense"]
-        ref = {"gnn0": dn["gnn0"][0].numpy(), "gnn1": dn["gnn1"][0].numpy(), "scores_in": dn["scores_in"][0].numpy(), "Z": dn["Z"][0].numpy()}
+    for s, (data, ref) in enumerate(oracle_jobs.pool_map(oracle_jobs.strict_inputs_job, [(name, s) for s in range(len(g["seeds"]))])):
         for key, (mine, fx) in util.strict_samples(g, s, ref["gnn0"], ref["gnn1"], ref["scores_in"], ref["Z"]).items():
-            util.assert_close(mine, fx, f"oracle vs the reference's {key} ({name} seed {seed})", atol=1e-5, rtol=1e-5)
-        per_seed.append(({k: data[k] for k in KEYS}, ref))
+            util.assert_close(mine, fx, f"oracle vs the reference's {key} ({name} seed {int(g['seeds'][s])})", atol=1e-5, rtol=1e-5)
+        per_seed.append(({k: torch.from_numpy(v) for k, v in data.items()}, ref))
     _INPUTS[name] = (g, per_seed)
     return _INPUTS[name]
 
@@ -106,6 +93,46 @@ def test_strict_bar_superglue_every_form(name, forms, mfma, attention):
           + ", ".join(f"{k} {v:.3f}" for k, v in worst.items()))
 
 
+def test_first_layers_with_undamped_gains_on_the_throughput_forms():
+    """the 't' weight set damps the residual branch (mlp.3 x 0.1, q / k x 0.5), so an error of the two-plane attention or
+    of the fused fp16 layer tail reaches gnn17 / scores_in / Z attenuated layer after layer -- the strict bar above is least sensitive
+    exactly where round 4's new kernels sit.  Here the DEFAULT gains (no damping: attention logits four times larger, the residual
+    branch at full size) on the same kernels (latency forms off: attention_h2, gnn_tail_h2) at C3 size, and the outputs of the first
+    two layers -- before any attenuation can accumulate -- element-wise at 1e-4 + 1e-4|ref| against the oracle; the keypoint encoder
+    too.  (After 18 undamped layers the reference's own fp32 result is 2e-4..2.6e-3 from float64: that end is float64-anchored in
+    tests/test_gpu_parity_r2.py.)"""
+    from oracle import superglue_ref
+    from image_matching_amd import _lib as L
+    from image_matching_amd.engine import Engine
+    g, per_seed = _strict_inputs("strict_c3.npz")
+    H, W, d, K = (int(g[k]) for k in ("H", "W", "d", "K"))
+    eng = Engine(util.sp_config(d, K), util.sg_config(d), "cuda")
+    sd = util.sg_sd(d)                                   # default gains
+    eng.load_state_dict(L.NET_SUPERGLUE, sd)
+    eng.set_option("latency_forms", "off")
+    eng.set_debug(True)
+    Kp = (K + 31) // 32 * 32
+    worst = {}
+    for s in range(2):
+        data, _ = per_seed[s]
+        eng.timing_reset()
+        eng.set_timing(True)
+        eng.superglue(data["keypoints0"].cuda(), data["scores0"].cuda(), data["descriptors0"].cuda(), (1, 1, H, W),
+                      data["keypoints1"].cuda(), data["scores1"].cuda(), data["descriptors1"].cuda(), (1, 1, H, W))
+        torch.cuda.synchronize()
+        forms = {r[0]: r[3] for r in eng.timing_report(forms=True)}
+        eng.set_timing(False)
+        assert forms["attention"] == "attention_h2:f16x2" and forms["gnn_tail"] == "gnn_tail_h2:f16x2", forms
+        full = dict(data, image_shape0=(1, 1, H, W), image_shape1=(1, 1, H, W))
+        dn = superglue_ref.superglue_forward(full, sd, util.sg_config(d), return_dense=True)["dense"]
+        for tap, (r0, r1) in (("kenc", (dn["kenc0"], dn["kenc1"])), ("gnn0", dn["gnn_taps"][0]), ("gnn1", dn["gnn_taps"][1])):
+            a = eng.fetch(tap)
+            for side, mine, ref in ((0, a[:K].T, r0[0].numpy()), (1, a[Kp:Kp + K].T, r1[0].numpy())):
+                util.assert_close(mine, ref, f"default gains, seed {int(g['seeds'][s])}: {tap} side {side}, every element")
+                worst[tap] = max(worst.get(tap, 0.0), util.tolerance_used(mine, ref))
+    print("[strict] undamped gains, throughput forms, first layers: worst fraction of the tolerance used: " + ", ".join(f"{k} {v:.3f}" for k, v in worst.items()))
+
+
 def _matching_t(d, K):
     from image_matching_amd.superglue.models.matching_test import Matching
     m = Matching({"superpoint": util.sp_config(d, K), "superglue": util.sg_config(d)}).eval().to("cuda")
@@ -121,7 +148,7 @@ def test_strict_bar_as_one_batched_call_from_images(name, B):
     the module docstring), matching scores at 1e-4 + 1e-4|ref|.  Dense tensors, two statements: (i) stage by stage at the north_star
     bar, every element -- the call's SuperPoint outputs against the oracle's SuperPoint, and the call's gnn17 / scores_in / Z against
     the oracle's SuperGlue run on those same SuperPoint outputs; (ii) images in, against the reference's samples: SuperPoint's
-    within-tolerance differences (descriptors ~4e-6) are amplified by the GNN, so this is held to 10x the tolerance and the number of
+    within-tolerance differences (descriptors ~4e-6) are amplified by the GNN, so scores_in / Z are anchored on the fixture's float64 samples (util.strict_compare_batch), gnn17 held to 3x, and the number of
     samples outside 1x is counted and printed (the reference's own fp32-vs-float64 chain from images sits at 1.2e-4 on Z)."""
     g = util.golden(name)
     H, W, d, K = (int(g[k]) for k in ("H", "W", "d", "K"))
@@ -145,32 +172,38 @@ def test_strict_bar_as_one_batched_call_from_images(name, B):
     # the SuperGlue STAGE inside this very call, at the north_star bar: the first pairs' taps against the oracle's SuperGlue run on the
     # library's OWN SuperPoint outputs of the call (identical inputs on both sides), every element; and those SuperPoint outputs
     # against the oracle's SuperPoint (keypoints matched by coordinate: near-tied scores swap neighbours in the top-k order)
-    from oracle import superglue_ref, superpoint_ref
+    from tests import oracle_jobs
     X, S, U, V = eng.fetch("x"), eng.fetch("scores_in"), eng.fetch("u"), eng.fetch("v")
     Kp = (K + 31) // 32 * 32
     worst = {"gnn17": 0.0, "scores_in": 0.0, "Z": 0.0, "sp_scores": 0.0, "sp_descriptors": 0.0}
-    n_stage = 4 if d == 128 else 2
+    n_stage = min(B, n)            # every distinct pair of the call (round 4 checked the first 4 / 2); the oracle runs in a process pool
+    owns = []
     for b in range(n_stage):
-        own = {"image_shape0": (1, 1, H, W), "image_shape1": (1, 1, H, W)}
-        for side, x in (("0", ims[b][0]), ("1", ims[b][1])):
+        own = {}
+        for side in ("0", "1"):
             kp, sc, ds = (out[k + side][b].cpu() for k in ("keypoints", "scores", "descriptors"))
-            own["keypoints" + side], own["scores" + side], own["descriptors" + side] = kp[None], sc[None], ds.t()[None]
-            o = superpoint_ref.superpoint_forward(x, util.sp_sd(d), util.sp_config(d, K))
-            pos = {tuple(p): i for i, p in enumerate(o["keypoints"][0].numpy().astype(int))}
-            perm = np.array([pos[tuple(p)] for p in kp.numpy().astype(int)])
-            util.assert_close(sc, o["scores"][0][perm], f"pair {b} side {side}: keypoint scores vs the oracle's SuperPoint")
-            util.assert_close(ds.t(), o["descriptors"][0][:, perm], f"pair {b} side {side}: descriptors vs the oracle's SuperPoint")
-            worst["sp_scores"] = max(worst["sp_scores"], util.tolerance_used(sc, o["scores"][0][perm]))
-            worst["sp_descriptors"] = max(worst["sp_descriptors"], util.tolerance_used(ds.t(), o["descriptors"][0][:, perm]))
-        dn = superglue_ref.superglue_forward(own, util.sg_sd(d, variant="t"), util.sg_config(d), return_dense=True)["dense"]
+            own["keypoints" + side], own["scores" + side], own["descriptors" + side] = kp.numpy(), sc.numpy(), np.ascontiguousarray(ds.t().numpy())
+        owns.append(own)
+    res = oracle_jobs.pool_map(oracle_jobs.stage_job, [(d, K, H, W, int(g["seeds"][b]), owns[b]) for b in range(n_stage)])
+    for b, (sp, dn) in enumerate(res):
+        for si, side in enumerate(("0", "1")):
+            o, kp = sp[si], owns[b]["keypoints" + side]
+            pos = {tuple(p): i for i, p in enumerate(o["keypoints"].astype(int))}
+            perm = np.array([pos[tuple(p)] for p in kp.astype(int)])
+            util.assert_close(owns[b]["scores" + side], o["scores"][perm], f"pair {b} side {side}: keypoint scores vs the oracle's SuperPoint")
+            util.assert_close(owns[b]["descriptors" + side], o["descriptors"][:, perm], f"pair {b} side {side}: descriptors vs the oracle's SuperPoint")
+            worst["sp_scores"] = max(worst["sp_scores"], util.tolerance_used(owns[b]["scores" + side], o["scores"][perm]))
+            worst["sp_descriptors"] = max(worst["sp_descriptors"], util.tolerance_used(owns[b]["descriptors" + side], o["descriptors"][:, perm]))
         g0, g1 = X[b * Kp:b * Kp + K].T, X[B * Kp + b * Kp:B * Kp + b * Kp + K].T
         Z = util.transport_Z(S[b], U[b], V[b], K, K, alpha)
-        for key, mine, ref in (("gnn17", np.stack([g0, g1]), np.stack([dn["gnn0"][0].numpy(), dn["gnn1"][0].numpy()])),
-                               ("scores_in", S[b, :K, :K], dn["scores_in"][0].numpy()), ("Z", Z, dn["Z"][0].numpy())):
+        for key, mine, ref in (("gnn17", np.stack([g0, g1]), np.stack([dn["gnn0"], dn["gnn1"]])), ("scores_in", S[b, :K, :K], dn["scores_in"]), ("Z", Z, dn["Z"])):
             util.assert_close(mine, ref, f"pair {b} of the {B}-pair call: {key} vs the oracle's SuperGlue on the same inputs, every element")
             worst[key] = max(worst[key], util.tolerance_used(mine, ref))
-    print(f"[strict e2e] {name}: per-stage parity inside the {B}-pair call (first {n_stage} pairs, every element), worst fraction of the tolerance used: "
+    print(f"[strict e2e] {name}: per-stage parity inside the {B}-pair call (all {n_stage} distinct pairs, every element), worst fraction of the tolerance used: "
           + ", ".join(f"{k} {v:.3f}" for k, v in worst.items()))
+    if summary.get("outliers"):
+        print(f"[strict e2e] {name}: samples outside 1x of the tolerance against the reference (images in), with the reference's own distance from float64 there: "
+              + "; ".join(f"pair {o['pair']} {o['tensor']} hip-ref {o['hip_vs_ref_in_tolerances']}x ref-f64 {o['ref_vs_f64_in_tolerances']}x hip-f64 {o['hip_vs_f64_in_tolerances']}x" for o in summary["outliers"][:16]))
     m0 = out["matches0"].cpu().numpy()
     for b in range(n, B):
         assert np.array_equal(m0[b], m0[b - n]), f"pair {b} differs from its copy at {b - n}"

@@ -286,8 +286,23 @@ def strict_index_check(g, s, mine0, mine1, thr, tag):
     # exact ties in the reference's OWN fp32 Z (top-1 minus top-2 == 0.0: two rows whose whole mass sits on one column converge to the
     # same transport entry, so the winner is decided by the last rounding -- the reference's float64 evaluation of itself picks the
     # other row on strict_c3 seed 1022): the reference reports the first index (Tensor.max), any evaluation may report either
-    tie0 = lambda i: g["gap0"][s][i] == 0.0 or g["gap1"][s][int(g["idx0"][s][i])] == 0.0
-    tie1 = lambda j: g["gap1"][s][j] == 0.0 or g["gap0"][s][int(g["idx1"][s][j])] == 0.0
+    # ... but not ANY index: the tied partners come from the reference's own forward (tests/golden/strict_ties.npz,
+    # make_golden.py --strict-ties), and on a tie the reported index must be one of them, or -1 (the mutual check can fail either way)
+    fi = 0 if int(g["d"]) == 128 else 1
+    parts = {(int(t[2]), int(t[3])): set(int(x) for x in t[4:] if x >= 0) for t in golden("strict_ties.npz")["ties"] if int(t[0]) == fi and int(t[1]) == s}
+
+    def allowed(axis, i, idx_mine, idx_ref):
+        """a differing entry of matches<axis> at index i is a tie if i's own line ties (then any tied partner, or -1) or if the line of
+        the index involved ties over i (then that index, or -1)"""
+        ok = set()
+        if (axis, i) in parts:
+            ok |= parts[(axis, i)] | {-1}
+        for other in (idx_mine, idx_ref):
+            if other >= 0 and i in parts.get((1 - axis, other), ()):
+                ok |= {other, -1}
+        return ok
+    tie0 = lambda i: int(mine0[i]) in allowed(0, int(i), int(mine0[i]), int(g["idx0"][s][i]))
+    tie1 = lambda j: int(mine1[j]) in allowed(1, int(j), int(mine1[j]), int(g["idx1"][s][j]))
     bad0 = [int(i) for i in d0 if not tie0(i) and not (int(i) in band0 and {int(mine0[i]), int(r0[i])} == {-1, int(g["idx0"][s][i])})]
     bad1 = [int(j) for j in d1 if not tie1(j) and not (int(j) in band1 and {int(mine1[j]), int(r1[j])} == {-1, int(g["idx1"][s][j])})]
     assert not bad0 and not bad1, f"{tag}: match indices differ from the reference's on rows {bad0[:6]} / columns {bad1[:6]} ({len(d0)}+{len(d1)} differ in all)"
@@ -365,10 +380,10 @@ def strict_compare_batch(g, out, eng, B, alpha, thr, dense=True, seed_idx=None):
         rs = g["mscores0"][s]
         # matching_scores0 = exp(Z[i, argmax]) where the argmaxes are mutual, else 0 (superglue_test.py:276-280).  Images in, a row's
         # mutual flag can flip where its reference argmax margin is below the amplified SuperPoint differences (score x vs 0 on a
-        # row that is unmatched on both sides): counted; everything else at 10x the tolerance, counted at 1x
+        # row that is unmatched on both sides): counted; everything else at 3x the tolerance (measured: 0.44x), counted at 1x
         both = (mine0 == r0) & ((sc > 0) == (rs > 0))
         summary["mutual_flag_flips_unmatched_rows"] += int(((mine0 == r0) & ((sc > 0) != (rs > 0))).sum())
-        assert_close(sc[both], rs[both], f"pair {b} (seed {seed}): matching_scores0", atol=10 * ATOL, rtol=10 * RTOL)
+        assert_close(sc[both], rs[both], f"pair {b} (seed {seed}): matching_scores0", atol=3 * ATOL, rtol=3 * RTOL)
         summary["mscores_outside_1e-4"] += int((np.abs(sc[both].astype(np.float64) - rs[both]) > ATOL + RTOL * np.abs(rs[both])).sum())
         summary["worst_tolerance_used"]["mscores"] = max(summary["worst_tolerance_used"]["mscores"], tolerance_used(sc[both], rs[both]))
         if dense:
@@ -380,9 +395,30 @@ def strict_compare_batch(g, out, eng, B, alpha, thr, dense=True, seed_idx=None):
             Z = Z[np.append(i0, K)][:, np.append(i1, K)]
             for key, (mine, fx) in strict_samples(g, s, g0, g1, S, Z).items():
                 # images in: the library's SuperGlue runs on the library's OWN SuperPoint outputs, whose (within-tolerance) differences
-                # from the reference's the 18-layer GNN amplifies -- held to 10x the north_star tolerance here, counted at 1x; the
-                # SuperGlue STAGE is held to 1x on identical inputs (test_gpu_strict.py)
-                assert_close(mine, fx, f"pair {b} (seed {seed}), images in: {key} vs the reference's sample", atol=10 * ATOL, rtol=10 * RTOL)
+                # from the reference's the 18-layer GNN amplifies; the SuperGlue STAGE is held to 1x on identical inputs
+                # (test_gpu_strict.py).  Round 5: no bare 10x any more.  scores_in and Z are anchored on the float64 evaluation the
+                # fixture carries for these very samples -- |hip - f64| <= 1e-4 + 1e-4|f64| + 2.5 x (the largest |ref32 - f64| of this
+                # seed's full tensor: the reference's own fp32 distance from its float64 self) -- and every sample outside 1x is listed
+                # with the reference's own distance AT THAT ELEMENT; gnn17 has no float64 samples in the fixture (its reference
+                # envelope is 5e-6) and is held to 3x, what the amplified SuperPoint differences were measured to need (1.2x)
+                fkey = {"scores_in": "scores_in_sub", "Z": "Z_sub"}.get(key)
+                m64, fx64 = mine.astype(np.float64), fx.astype(np.float64)
+                if fkey:
+                    f64 = fx64 + g[fkey + "_d64"][s].astype(np.float64)
+                    env = float(g["env_" + key][s][0])
+                    lim = ATOL + RTOL * np.abs(f64) + 2.5 * env
+                    bad = np.abs(m64 - f64) > lim
+                    assert not bad.any(), (f"pair {b} (seed {seed}), images in: {key}: {int(bad.sum())} samples further from the float64 evaluation than "
+                                           f"1e-4 + 1e-4|f64| + 2.5 x {env:.2e} (the reference's own fp32 envelope); worst {np.abs(m64 - f64).max():.3e}")
+                    out1 = np.abs(m64 - fx64) > ATOL + RTOL * np.abs(fx64)
+                    for idx in np.argwhere(out1)[:4]:
+                        t = tuple(idx)
+                        summary.setdefault("outliers", []).append(
+                            {"pair": b, "tensor": key, "hip_vs_ref_in_tolerances": round(float(abs(m64[t] - fx64[t]) / (ATOL + RTOL * abs(fx64[t]))), 2),
+                             "ref_vs_f64_in_tolerances": round(float(abs(fx64[t] - f64[t]) / (ATOL + RTOL * abs(f64[t]))), 2),
+                             "hip_vs_f64_in_tolerances": round(float(abs(m64[t] - f64[t]) / (ATOL + RTOL * abs(f64[t]))), 2)})
+                else:
+                    assert_close(mine, fx, f"pair {b} (seed {seed}), images in: {key} vs the reference's sample", atol=3 * ATOL, rtol=3 * RTOL)
                 w, o = summary["worst_tolerance_used"], summary["samples_outside_1e-4"]
                 w[key] = max(w.get(key, 0.0), tolerance_used(mine, fx))
                 o[key] = o.get(key, 0) + int((np.abs(mine.astype(np.float64) - fx) > ATOL + RTOL * np.abs(fx)).sum())
