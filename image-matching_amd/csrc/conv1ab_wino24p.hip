@@ -1,0 +1,421 @@
+// conv1ab_wino24p.hip -- conv1ab_wino24h.hip's fused first layer (conv1a + conv1b + folded BN + ReLU + MaxPool2d(2);
+// superpoint/models/unet_parts.py:10-48, superpoint_test.py:113-114) on PAIRS of tiles, conv1b's 24 Winograd positions split over two
+// waves -- conv3x3_wino24p.hip's structure (round 5): a transformed-weight fragment U of conv1b meets the B operands of two tiles, so
+// the layer pulls half the bytes through the L1 data path that the counters name as its busiest unit (profiles/r05_*_pmc_limiter.json:
+// 0.55 of the launch's cycles for conv1ab_wino24h, 121 GB per 128-image launch).
+//
+//   workgroup = 8 waves = two 8x16-pixel tiles x 64 channels, one workgroup per CU, a contiguous range of tile pairs.
+//   per pair: image patches (2 x 12x20) + their maxima | barrier | conv1a channels 0..31 of both patches on the fp32 matrix cores
+//   (four waves per tile, conv1ab_wino24h's GEMM: weights = A, im2col = B, the tile's power of two s_v riding in B) | barrier |
+//   input transform of chunk 0, split by (8-channel sub-patch, tile) | barrier | 72 MFMAs per wave (rows 2 ph, 2 ph + 1 of both
+//   tiles) with conv1a channels 32..63 in three pieces between them | barrier | transform 1 | barrier | MFMAs 1 | barrier | accumulator exchange | barrier | barrier |
+//   conv1ab_wino24h's epilogue (output transform, 2x2 max-pool, un-scale + bias, ReLU, store) by wave (cb, ph) for tile ph.
+// Every output sees conv1ab_wino24h's arithmetic in the same order: the two kernels agree bit for bit (tests/test_gpu_superpoint.py).
+// LDS: V 96 KB + conv1a half patches 2 x 26 KB + image patches + maxima table = 151 KB.
+#include "imx_kernels.h"
+#include "wino24_pk.h"
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+namespace imx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int OH = 8, OW = 16;                 // output pixels per tile (4 x 4 wtiles of 2 x 4)
+constexpr int RH = OH + 2, RW = OW + 2;        // conv1a patch (pad-1 halo)
+constexpr int IMG_H = RH + 2, IMG_W = RW + 2;  // image patch 12 x 20
+constexpr int IMG_N = IMG_H * IMG_W;           // 240
+constexpr int RSH = 34;                        // conv1a half patch: pixel stride (32 channels + 2), conv1ab_wino24h.hip
+constexpr int RAWSZ = 192 * RSH;               // floats per tile: 180 pixels + 12 pad
+constexpr int NPOS = 24, NLP = 12, NG = 2;
+constexpr int VPLANE = NPOS * 4 * 16 * 8;      // halves per plane of a tile
+constexpr int VGRP = 2 * VPLANE;               // halves per tile
+constexpr int UPOS = 2 * 4 * 64 * 8;           // halves of U per (chunk, position): [plane][channel block][lane][8]
+constexpr int RING = 6;
+constexpr int XCH = NLP * 64 * 16;             // bytes of one wave's accumulator exchange block
+constexpr int AMAX_SLOTS = 256;
+
+template <bool V>
+struct BoolC { static constexpr bool value = V; };
+
+__device__ __forceinline__ void split_h2(f32x2 x, f16x2& h, f16x2& m) {      // conv3x3_wino24h.hip
+  unsigned lo_u, hi_u;
+  asm("s_mov_b32 %0, 0x0000bc00" : "=s"(lo_u));
+  asm("s_mov_b32 %0, 0xbc000000" : "=s"(hi_u));
+  const f16x2 lo = __builtin_bit_cast(f16x2, lo_u), hi = __builtin_bit_cast(f16x2, hi_u);
+  h[0] = (_Float16)x[0]; h[1] = (_Float16)x[1];
+  const float r0 = __builtin_amdgcn_fdot2(h, lo, x[0], false);
+  const float r1 = __builtin_amdgcn_fdot2(h, hi, x[1], false);
+  m[0] = (_Float16)r0; m[1] = (_Float16)r1;
+}
+__device__ __forceinline__ int lane_now() {                                    // conv3x3_wino24p.hip
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+// the power of two that brings 32 x `bound` (>= 20 max|d| >= |V|) to 2^13 (conv1ab_wino24h.hip)
+__device__ __forceinline__ float v_scale_of_bound(float bound) {
+  unsigned e = (__builtin_bit_cast(unsigned, bound) >> 23) & 0xffu;
+  e = e < 60u ? 60u : e > 200u ? 200u : e;
+  return __builtin_bit_cast(float, (261u - e) << 23);
+}
+
+__global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, int tiles_y, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_1p[];
+  float* raw = reinterpret_cast<float*>(smem_1p + NG * VGRP * 2);               // [NG][192][RSH]: 32 channels of each conv1a patch
+  float* img = raw + NG * RAWSZ;                                                // [NG][12][20]
+  float* wmax = img + NG * IMG_N;                                               // [8]: the waves' maxima of |image patch|
+  unsigned* amax_tab = reinterpret_cast<unsigned*>(wmax + 8);                   // [AMAX_SLOTS]
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_1p;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = wave_s & 3, ph = wave_s >> 2;         // matrix role: channel block, position half
+  const int tq = wave_s & 3, tg = wave_s >> 2;         // transform role: 8-channel sub-patch, tile; conv1a / image / epilogue: tile tg (== ph), quarter tq
+  const int H = p.H, W = p.W, Cout = p.Cout;
+  const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.wuh, 0, 2 * NPOS * UPOS * 2, 0x00020000);
+  const int uoff_lane = (cb * 64 + lane) * 16 + ph * 2 * (UPOS * 2);
+  typedef const float __attribute__((address_space(4)))* cf32p;
+  const cf32p bias_c = (cf32p)(uintptr_t)p.bias;
+
+  // ---- per-lane constants of the conv1a GEMM (conv1ab_wino24h.hip): A = weights, 12 registers, loaded once per workgroup
+  const int n = lane & 15, kq = lane >> 4;
+  const float c2 = kq == 0 ? 1.f : 0.f, a2 = kq == 1 ? 1.f : 0.f;      // third k-step: tap 8 | the bias "tap" (input 1) | zero padding
+  float wa[4][3];
+  int toff[3];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    const int tap = 4 * ks + kq;
+    toff[ks] = tap < 9 ? (tap / 3) * IMG_W + tap % 3 : 0;
+#pragma unroll
+    for (int cbk = 0; cbk < 4; ++cbk) {
+      const float* src = tap < 9 ? p.w1 + tap * 64 + cbk * 16 + n : p.b1 + cbk * 16 + n;
+      const float v = *(tap <= 9 ? src : p.b1);
+      wa[cbk][ks] = tap <= 9 ? v : 0.f;
+    }
+  }
+  // ---- input transform: lane = (channel pair tk, wtile tw) of sub-patch tq of tile tg (conv3x3_wino24p.hip)
+  const int tk = lane & 3, tw = lane >> 2, twr = tw >> 2, twc = tw & 3;
+  const f32x2 m5 = {-5.f, -5.f}, one2 = {1.f, 1.f}, mone2 = {-1.f, -1.f};
+  const float* rp = raw + tg * RAWSZ + ((2 * twr) * RW + 4 * twc) * RSH + 8 * tq + 2 * tk;      // + (row * RW + column) * RSH
+  _Float16* const vwr = (_Float16*)((__attribute__((address_space(3))) unsigned char*)(uintptr_t)(lds0 + (unsigned)(tg * (VGRP * 2) + tq * 256 + lane * 4)));
+  const _Float16 *vrdK, *vrdS;
+  {
+    unsigned a = lds0 + (unsigned)(ph * (VGRP * 2) + ph * 2 * 1024 + lane * 16);
+    unsigned b = lds0 + (unsigned)((1 - ph) * (VGRP * 2) + ph * 2 * 1024 + lane * 16);
+    asm volatile("" : "+v"(a), "+v"(b));
+    vrdK = (const _Float16*)((__attribute__((address_space(3))) unsigned char*)(uintptr_t)a);
+    vrdS = (const _Float16*)((__attribute__((address_space(3))) unsigned char*)(uintptr_t)b);
+  }
+
+  // ---- persistent over a contiguous range of tile PAIRS; this wave's tile of pair q is 2 q + tg; the next pair's image patch element
+  // is fetched a whole pair ahead (thread t8 < 240 of the tile's 256 threads)
+  const int npairs = (ntiles + NG - 1) / NG;
+  const int per = (npairs + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int q_begin = (int)blockIdx.x * per, q_end = q_begin + per < npairs ? q_begin + per : npairs;
+  if (q_begin >= q_end) return;
+  int tx, ty, b, tlive;
+  {
+    const int t = NG * q_begin + tg;
+    tlive = t < ntiles;
+    const int tt = tlive ? t : 0;
+    tx = tt % tiles_x; ty = (tt / tiles_x) % tiles_y; b = tt / (tiles_x * tiles_y);
+  }
+  auto next_tile = [&]() __attribute__((always_inline)) {          // two tiles on
+    tx += NG;
+    while (tx >= tiles_x) { tx -= tiles_x; if (++ty == tiles_y) { ty = 0; ++b; } }
+    tlive = b < p.B;
+  };
+  const int t8 = tid & 255;
+  const int ipy = t8 / IMG_W - 2, ipx = t8 % IMG_W - 2;
+  auto fetch_px = [&](bool live) -> float {
+    const int gy = ty * OH + ipy, gx = tx * OW + ipx;
+    const bool ok = live && tlive && t8 < IMG_N && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const int fb = tlive ? b : 0;
+    const float* im = (fb < p.split) ? p.in + (size_t)fb * H * W : p.in2 + (size_t)(fb - p.split) * H * W;
+    const float* src = ok ? im + (size_t)gy * W + gx : p.in;
+    const float v = *src;
+    return ok ? v : 0.f;
+  };
+  float pre = fetch_px(true);
+  int gpy[3], gpx[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int pp = (3 * tq + j) * 16 + n;
+    const int pc = pp < RH * RW ? pp : RH * RW - 1;
+    gpy[j] = pc / RW;
+    gpx[j] = pc % RW;
+  }
+  u32x4v ub[RING][2];
+  auto u_load = [&](int slot, int chv, int lp) __attribute__((always_inline)) {
+    const int pos = (lp >> 1) * 4 + (lp & 1);
+    const int so = __builtin_amdgcn_readfirstlane((chv * NPOS + pos) * (UPOS * 2));
+    ub[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(ur, uoff_lane, so, 0);
+    ub[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(ur, uoff_lane, so + 4 * 64 * 16, 0);
+  };
+  for (int i = tid; i < AMAX_SLOTS; i += 512) amax_tab[i] = 0;
+#pragma unroll
+  for (int g = 0; g < RING; ++g) u_load(g, 0, g);
+
+  f32x4 accK[NLP], accS[NLP];
+  const f32x2 k8 = {8.f, 8.f};
+  const f32x4 zero4c = {0.f, 0.f, 0.f, 0.f};
+  float sv = 1.f;                // this wave's tile's power of two
+  float* const rawt = raw + tg * RAWSZ;
+  const float* const imgt = img + tg * IMG_N;
+
+  // conv1a + folded BN + ReLU for 32 channels (16-channel blocks 2 half, 2 half + 1) of this wave's share of its tile's 10x18 halo
+  // patch ON THE MATRIX CORES, scaled by sv, into raw (conv1ab_wino24h.hip)
+  auto conv1a_block = [&](int half, int j, int x0, int y0) __attribute__((always_inline)) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    {
+      const int pp = (3 * tq + j) * 16 + n;
+      const int py = gpy[j], px = gpx[j];
+      const int gy = y0 + py - 1, gx = x0 + px - 1;
+      const float m = (pp < RH * RW && gy >= 0 && gy < H && gx >= 0 && gx < W) ? sv : 0.f;
+      const float* ip = imgt + py * IMG_W + px;
+      float bv[3];
+      bv[0] = ip[toff[0]] * m;
+      bv[1] = ip[toff[1]] * m;
+      bv[2] = (ip[toff[2]] * c2 + a2) * m;
+#pragma unroll
+      for (int cl = 0; cl < 2; ++cl) {
+        f32x4 d = zero4;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x4f32(half ? wa[2 + cl][ks] : wa[cl][ks], bv[ks], d, 0, 0, 0);
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        d = __builtin_bit_cast(f32x4, __builtin_elementwise_max(__builtin_bit_cast(i32x4, d), (i32x4){0, 0, 0, 0}));      // ReLU on the bit pattern
+        float* o = rawt + pp * RSH + cl * 16 + 4 * kq;
+        *reinterpret_cast<f32x2*>(o) = (f32x2){d[0], d[1]};
+        *reinterpret_cast<f32x2*>(o + 2) = (f32x2){d[2], d[3]};
+      }
+    }
+  };
+  auto conv1a_half = [&](int half, int x0, int y0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) conv1a_block(half, j, x0, y0);
+  };
+  auto v_store2 = [&](int pos, f16x2 h, f16x2 m) __attribute__((always_inline)) {
+    *reinterpret_cast<f16x2*>(vwr + pos * 512) = h;
+    *reinterpret_cast<f16x2*>(vwr + VPLANE + pos * 512) = m;
+  };
+  auto transform = [&]() __attribute__((always_inline)) {
+    f32x2 r1[6], r2[6], rx[6];
+    auto row_load = [&](f32x2 (&d)[6], int row) __attribute__((always_inline)) {
+#pragma unroll
+      for (int bb = 0; bb < 6; ++bb) d[bb] = *reinterpret_cast<const f32x2*>(rp + (row * RW + bb) * RSH);
+    };
+    auto row_out = [&](int i, f32x2 sg2, const f32x2 (&bq)[6], const f32x2 (&aq)[6]) __attribute__((always_inline)) {
+      f32x2 o[6], T[6];
+#pragma unroll
+      for (int bb = 0; bb < 6; ++bb) o[bb] = pk_fma(sg2, bq[bb], aq[bb]);
+      const W24Half hb = w24_batch_a(o, m5);
+      w24_batch_b(o, hb, T);
+#pragma unroll
+      for (int jj = 0; jj < 6; ++jj) {
+        f16x2 h, m;
+        split_h2(T[jj], h, m);
+        v_store2(jj * 4 + i, h, m);
+      }
+    };
+    row_load(r1, 1);
+    row_load(r2, 2);
+    row_load(rx, 0);
+    row_out(1, one2, r2, r1);        // r1 + r2
+    row_out(2, mone2, r1, r2);       // r2 - r1
+    row_out(0, mone2, r2, rx);       // r0 - r2
+    row_load(rx, 3);
+    row_out(3, mone2, rx, r1);       // r1 - r3
+  };
+  // (chunk 0's phase carries conv1a's channels 32..63 in three pieces, after positions 1, 5 and 9: their fp32 MFMAs take their
+  // operands from LDS and registers, and fill matrix-pipe time in which the fp16 MFMAs wait for U on the L1 data path)
+  auto mfma_phase = [&](auto firstc, int c, int x0, int y0) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(firstc)::value;
+    f16x8 bq[2][4];              // [buffer][K h, K m, S h, S m]
+    auto b_load = [&](int buf, int lp) __attribute__((always_inline)) {
+      const int po = ((lp >> 1) * 4 + (lp & 1)) * 512;
+      bq[buf][0] = *reinterpret_cast<const f16x8*>(vrdK + po);
+      bq[buf][1] = *reinterpret_cast<const f16x8*>(vrdK + VPLANE + po);
+      bq[buf][2] = *reinterpret_cast<const f16x8*>(vrdS + po);
+      bq[buf][3] = *reinterpret_cast<const f16x8*>(vrdS + VPLANE + po);
+    };
+    b_load(0, 0);
+#pragma unroll
+    for (int lp = 0; lp < NLP; ++lp) {
+      const int buf = lp & 1;
+      if (lp + 1 < NLP) b_load(buf ^ 1, lp + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8 bKh = bq[buf][0], bKm = bq[buf][1], bSh = bq[buf][2], bSm = bq[buf][3];
+      const f16x8 ah = __builtin_bit_cast(f16x8, ub[lp % RING][0]), am = __builtin_bit_cast(f16x8, ub[lp % RING][1]);
+      accK[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bKm, FIRST ? zero4c : accK[lp], 0, 0, 0);
+      accS[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bSm, FIRST ? zero4c : accS[lp], 0, 0, 0);
+      accK[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bKh, accK[lp], 0, 0, 0);
+      accS[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bSh, accS[lp], 0, 0, 0);
+      accK[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bKh, accK[lp], 0, 0, 0);
+      accS[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bSh, accS[lp], 0, 0, 0);
+      {
+        const int np = lp + RING;                  // the other chunk follows (U is tile independent)
+        if (np < NLP) u_load(lp % RING, c, np);
+        else u_load(lp % RING, c ^ 1, np - NLP);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (FIRST && (lp & 3) == 1) {                // (5790 us against 5817 with the three pieces behind the phase)
+        conv1a_block(1, lp >> 2, x0, y0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  unsigned amax_run = 0;
+  const int Ho = H >> 1, Wo = W >> 1;
+  const bool outb = p.out_blocked != 0;
+  const int opx = outb ? 32 : Cout * 4;
+  __syncthreads();               // the maxima table is zeroed
+  for (int q = q_begin; q < q_end; ++q) {
+    const int x0 = tx * OW, y0 = ty * OH, bcur = tlive ? b : 0, lcur = tlive;
+    if (t8 < IMG_N) img[tg * IMG_N + t8] = pre;
+    {                                           // the patch's largest |value|: wave maxima -> LDS
+      float mx = fabsf(pre);
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      if (lane == 0) wmax[wave_s] = mx;
+    }
+    next_tile();
+    pre = fetch_px(q + 1 < q_end);
+    __syncthreads();             // image patches and maxima visible (and every wave is past the previous pair's epilogue reads)
+    {
+      const float* wm = wmax + 4 * tg;
+      const float imax = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+      sv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v_scale_of_bound(fmaf(imax, p.c1a_l1, p.c1a_bmax)))));
+    }
+    conv1a_half(0, x0, y0);
+    __syncthreads();             // channels 0..31 of both patches complete
+    transform();
+    __syncthreads();             // V complete; raw free
+    mfma_phase(BoolC<true>{}, 0, x0, y0);      // (+ conv1a channels 32..63)
+    __syncthreads();             // channels 32..63 complete; V free
+    transform();
+    __syncthreads();             // V complete
+    mfma_phase(BoolC<false>{}, 1, x0, y0);
+    __syncthreads();             // every wave is past its B-operand reads: the V region takes the exchange
+
+    // ---- the accumulators of the partner's tile go to LDS, the partner's of THIS wave's tile come back (conv3x3_wino24p.hip)
+    typedef __attribute__((address_space(3))) f32x4* lds4p;
+    const int lq = lane_now();
+    const unsigned xw = lds0 + (unsigned)(wave_s * XCH + lq * 16), xr = lds0 + (unsigned)((wave_s ^ 4) * XCH + lq * 16);
+    f32x4 bs4;
+    {
+      const int bo = __builtin_amdgcn_readfirstlane(cb * 16);
+      typedef const f32x4 __attribute__((address_space(4)))* cf4p;
+      const cf4p b4 = (cf4p)(bias_c + bo);
+      const f32x4 b0 = b4[0], b1 = b4[1], b2 = b4[2], b3 = b4[3];
+      const int kq2 = lq >> 4;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) bs4[qq] = kq2 == 0 ? b0[qq] : kq2 == 1 ? b1[qq] : kq2 == 2 ? b2[qq] : b3[qq];
+    }
+#pragma unroll
+    for (int lp = 0; lp < NLP; ++lp) *(lds4p)(uintptr_t)(xw + lp * 1024) = accS[lp];
+    __syncthreads();
+    f32x4 got[NLP];
+#pragma unroll
+    for (int lp = 0; lp < NLP; ++lp) got[lp] = *(lds4p)(uintptr_t)(xr + lp * 1024);
+    __syncthreads();             // (the next pair's transform overwrites the region)
+
+    // ---- output transform, 2x2 max-pool (commutes with the positive scale), un-scale + bias, ReLU, stores (conv1ab_wino24h.hip)
+    f32x4 y[2][4];
+    {
+      f32x4 m[NPOS];
+      if (ph == 0) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { m[j * 4 + 0] = accK[j * 2]; m[j * 4 + 1] = accK[j * 2 + 1]; m[j * 4 + 2] = got[j * 2]; m[j * 4 + 3] = got[j * 2 + 1]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { m[j * 4 + 0] = got[j * 2]; m[j * 4 + 1] = got[j * 2 + 1]; m[j * 4 + 2] = accK[j * 2]; m[j * 4 + 3] = accK[j * 2 + 1]; }
+      }
+      w24_output_transform(m, k8, y);
+    }
+    {
+      const float inv = p.u_scale_inv / sv;
+      const f32x4 inv4 = {inv, inv, inv, inv};
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      const int wr = (lq & 15) >> 2, wc = lq & 3;
+      const int bu = __builtin_amdgcn_readfirstlane(bcur), lv = __builtin_amdgcn_readfirstlane(lcur);
+      const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)bu * Ho * Wo * Cout), 0, lv ? Ho * Wo * Cout * 4 : 0, 0x00020000);
+      const int choff = outb ? (cb * 2 + (lq >> 5)) * (Ho * Wo * 32) + ((lq >> 4) & 1) * 16 : (cb * 16 + 4 * (lq >> 4)) * 4;
+      typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+      const int oy = (y0 >> 1) + wr;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const f32x4 mx4 = __builtin_elementwise_max(__builtin_elementwise_max(y[0][2 * hh], y[0][2 * hh + 1]), __builtin_elementwise_max(y[1][2 * hh], y[1][2 * hh + 1]));
+        const f32x4 v = __builtin_elementwise_max(__builtin_elementwise_fma(mx4, inv4, bs4), zero4);
+        const int ox = (x0 >> 1) + 2 * wc + hh;
+        const unsigned off = (oy < Ho && ox < Wo) ? (unsigned)((oy * Wo + ox) * opx + choff) : 0x7ffffff0u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (int)off, 0, 0);
+        amax_run = max(amax_run, __builtin_bit_cast(unsigned, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]))));
+      }
+      if (p.amax_out) {          // wave maximum by DPP, into the workgroup's LDS table (conv3x3_wino24p.hip)
+        unsigned mb = amax_run;
+        mb = max(mb, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xb1, 0xf, 0xf, true));
+        mb = max(mb, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0x4e, 0xf, 0xf, true));
+        mb = max(mb, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0x141, 0xf, 0xf, true));
+        mb = max(mb, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0x140, 0xf, 0xf, true));
+        const unsigned m01 = max((unsigned)__builtin_amdgcn_readlane((int)mb, 0), (unsigned)__builtin_amdgcn_readlane((int)mb, 16));
+        const unsigned m23 = max((unsigned)__builtin_amdgcn_readlane((int)mb, 32), (unsigned)__builtin_amdgcn_readlane((int)mb, 48));
+        const unsigned mw = max(m01, m23);
+        if (lv && mw && lq == 0) atomicMax(amax_tab + (bu & (AMAX_SLOTS - 1)), mw);
+        amax_run = 0;
+      }
+    }
+  }
+  if (p.amax_out) {
+    __syncthreads();
+    for (int i = tid; i < AMAX_SLOTS; i += 512)
+      if (amax_tab[i]) atomicMax(p.amax_out + i, amax_tab[i]);
+  }
+}
+}  // namespace
+
+bool conv1ab_wino24p_supported(const ConvArgs& a) { return conv1ab_wino24h_supported(a); }
+
+// at least one tile pair per CU (below that conv1ab_wino24h, with twice the workgroups, fills more of the chip)
+bool conv1ab_wino24p_preferred(const ConvArgs& a) {
+  if (!conv1ab_wino24p_supported(a)) return false;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    ncu = prop.multiProcessorCount;
+  }
+  const long long tiles = (long long)((a.W + OW - 1) / OW) * ((a.H + OH - 1) / OH) * a.B;
+  return (tiles + NG - 1) / NG >= 2LL * ncu;
+}
+
+hipError_t launch_conv1ab_wino24p(const ConvArgs& a, hipStream_t s) {
+  if (!conv1ab_wino24p_supported(a)) return hipErrorInvalidValue;
+  const int tiles_x = (a.W + OW - 1) / OW, tiles_y = (a.H + OH - 1) / OH, ntiles = tiles_x * tiles_y * a.B;
+  const int npairs = (ntiles + NG - 1) / NG;
+  const size_t lds = (size_t)NG * VGRP * 2 + (size_t)(NG * RAWSZ + NG * IMG_N + 8) * sizeof(float) + AMAX_SLOTS * sizeof(unsigned);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    ncu = prop.multiProcessorCount;
+  }
+  static unsigned long long attr = 0;
+  raise_lds_limit(reinterpret_cast<const void*>(conv1ab_wino24p), (int)lds, attr);
+  const dim3 grid((unsigned)(npairs < ncu ? npairs : ncu));     // persistent: one workgroup per CU
+  last_form = "conv1ab_wino24p:f16x2";
+  hipLaunchKernelGGL(conv1ab_wino24p, grid, dim3(512), lds, s, a, tiles_x, tiles_y, ntiles);
+  return hipGetLastError();
+}
+
+}  // namespace imx

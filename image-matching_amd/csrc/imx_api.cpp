@@ -698,7 +698,8 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
     // the fp16-plane layers: tile pairs with the positions split over two waves where that fills the chip (conv3x3_wino24p.hip: a U
     // fragment serves two tiles), one tile per workgroup otherwise ("conv" = "wino_h": always) -- the same arithmetic, bit for bit
     const bool winop = winoh && h->opt.conv_f16 == 1 && conv3x3_wino24p_preferred(a);
-    RUN(name, fused1h ? launch_conv1ab_wino24h(a, s) : fused1 ? launch_conv1ab_wino24(a, s) : winop ? launch_conv3x3_wino24p(a, s) : winoh ? launch_conv3x3_wino24h(a, s) :
+    const bool fused1p = fused1h && h->opt.conv_f16 == 1 && conv1ab_wino24p_preferred(a);
+    RUN(name, fused1p ? launch_conv1ab_wino24p(a, s) : fused1h ? launch_conv1ab_wino24h(a, s) : fused1 ? launch_conv1ab_wino24(a, s) : winop ? launch_conv3x3_wino24p(a, s) : winoh ? launch_conv3x3_wino24h(a, s) :
               wino ? launch_conv3x3_wino24(a, s) : launch_conv3x3(a, s));
     }
     return 0;

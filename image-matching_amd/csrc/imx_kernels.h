@@ -78,6 +78,9 @@ hipError_t launch_conv3x3(const ConvArgs& a, hipStream_t s);       // direct for
 hipError_t launch_conv1ab_wino24(const ConvArgs& a, hipStream_t s); // fused conv1a + conv1b (Winograd F(2x4,3x3)) + pool
 bool conv1ab_wino24h_supported(const ConvArgs& a);                   // + wuh, c1a_l1
 hipError_t launch_conv1ab_wino24h(const ConvArgs& a, hipStream_t s); // the same with conv1b's products on the fp16 matrix pipe
+bool conv1ab_wino24p_supported(const ConvArgs& a);                   // = conv1ab_wino24h_supported
+bool conv1ab_wino24p_preferred(const ConvArgs& a);                   // supported and at least two tile pairs per CU
+hipError_t launch_conv1ab_wino24p(const ConvArgs& a, hipStream_t s); // conv1ab_wino24h's arithmetic on tile pairs, positions split over two waves (8 waves per CU)
 // Cin % 64 == 0, Cout % 64 == 0, not first.
 bool conv3x3_wino24_supported(const ConvArgs& a);                   // false (e.g. an image of >= 2 GB per layer): callers fall back to the direct form
 hipError_t launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s); // Winograd F(2x4,3x3), persistent, in-stream transform

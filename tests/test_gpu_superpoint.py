@@ -310,7 +310,8 @@ def test_tile_pair_winograd_form_is_bit_identical_to_the_tile_per_workgroup_form
         eng.set_timing(False)
     fh, fp = got["wino_h"][2], got["wino"][2]
     layers = ("conv2a", "conv2b_pool", "conv3a", "conv3b_pool", "conv4a", "conv4b", "convPaDa")
-    assert all(fh[k] == "conv3x3_wino24h:f16x2" for k in layers), fh
+    assert all(fh[k] == "conv3x3_wino24h:f16x2" for k in layers) and fh["conv1ab_pool"] == "conv1ab_wino24h:f16x2", fh
+    assert fp["conv1ab_pool"] == "conv1ab_wino24p:f16x2", fp            # (the fused first layer has a pair form too: conv1ab_wino24p.hip)
     assert fp["conv2a"] == "conv3x3_wino24p:f16x2" and fp["convPaDa"] == "conv3x3_wino24p:f16x2", fp
     assert all(fp[k] in ("conv3x3_wino24p:f16x2", "conv3x3_wino24h:f16x2") for k in layers), fp
     assert torch.equal(got["wino"][0], got["wino_h"][0]), "semi differs between the pair form and the tile-per-workgroup form"

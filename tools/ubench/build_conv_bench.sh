@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 C=image-matching_amd/csrc; O=/tmp/conv_h_bench_obj; mkdir -p $O
 F="-O3 -std=c++17 --offload-arch=gfx950 -Iinclude"
 EXTRA="$@"
-for f in conv3x3_wino24 conv3x3_wino24h conv1ab_wino24 conv1ab_wino24h; do
+for f in conv3x3_wino24 conv3x3_wino24h conv1ab_wino24 conv1ab_wino24h conv1ab_wino24p; do
   /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 $EXTRA -c $C/$f.hip -o $O/$f.o &
 done
 /opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 $EXTRA -c $C/conv3x3_wino24p.hip -o $O/conv3x3_wino24p.o &

@@ -199,22 +199,24 @@ static int run_first(int B, int H, int W, float mag) {
   a.in = dim_; a.in2 = dim_; a.split = B; a.wu24 = dw32; a.bias = db; a.w1 = dw1; a.b1 = db1; a.B = B; a.H = H; a.W = W; a.Cin = 64; a.Cout = 64;
   a.relu = 1; a.pool = 1; a.first = 1; a.out_blocked = 1; a.wuh = duh; a.u_scale_inv = su_inv; a.c1a_l1 = l1; a.c1a_bmax = bmax; a.amax_out = damax_out;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  float ms[2] = {0, 0};
-  std::vector<unsigned> am[2];
-  for (int form = 0; form < 2; ++form) {
-    a.out = form ? douth : dout32;
+  float ms[3] = {0, 0, 0};
+  std::vector<unsigned> am[3];
+  float* doutp; hipMalloc(&doutp, (size_t)B * Ho * Wo * C * 4); hipMemset(doutp, 0xff, (size_t)B * Ho * Wo * C * 4);
+  for (int form = 0; form < 3; ++form) {
+    a.out = form == 2 ? doutp : form ? douth : dout32;
     hipMemset(damax_out, 0, 1024);
-    auto go = [&]() { return form ? launch_conv1ab_wino24h(a, 0) : launch_conv1ab_wino24(a, 0); };
+    auto go = [&]() { return form == 2 ? launch_conv1ab_wino24p(a, 0) : form ? launch_conv1ab_wino24h(a, 0) : launch_conv1ab_wino24(a, 0); };
     hipError_t err = go();
     hipDeviceSynchronize();
     if (err != hipSuccess || hipGetLastError() != hipSuccess) { printf("launch failed (first, form %d): %s\n", form, hipGetErrorString(err)); return 1; }
     am[form].resize(256); hipMemcpy(am[form].data(), damax_out, 1024, hipMemcpyDeviceToHost);
+    const int iters = getenv("ITERS") ? atoi(getenv("ITERS")) : 5;      // (ITERS=60: sustained clocks, as inside the step)
     for (int i = 0; i < 2; ++i) go();
     hipEventRecord(e0, 0);
-    for (int i = 0; i < 5; ++i) go();
+    for (int i = 0; i < iters; ++i) go();
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms[form], e0, e1);
-    ms[form] /= 5;
+    ms[form] /= iters;
   }
   std::vector<float> o32((size_t)B * Ho * Wo * C), oh(o32.size());
   hipMemcpy(o32.data(), dout32, o32.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(oh.data(), douth, oh.size() * 4, hipMemcpyDeviceToHost);
@@ -225,8 +227,15 @@ static int run_first(int B, int H, int W, float mag) {
   }
   int bad = 0;
   for (int b = 0; b < B && b < 256; ++b) if (am[0][b] != am[1][b]) { float x, y; memcpy(&x, &am[0][b], 4); memcpy(&y, &am[1][b], 4); if (fabsf(x - y) > 1e-4f * fabsf(x)) ++bad; }
-  printf("first layer %dx%d B=%d | fp32 wino %8.1f us  f16x2 wino %8.1f us (x%.2f) | max |h - f32| %.2e of %.2e%s | per-image maxima differing by > 1e-4: %d\n",
-         H, W, B, ms[0] * 1e3, ms[1] * 1e3, ms[0] / ms[1], dmax, omax, nan ? " NaN!" : "", bad);
+  size_t pdiff = 0;
+  {
+    std::vector<float> op(oh.size());
+    hipMemcpy(op.data(), doutp, op.size() * 4, hipMemcpyDeviceToHost);
+    for (size_t i = 0; i < oh.size(); ++i) pdiff += memcmp(&op[i], &oh[i], 4) != 0;
+    for (int b = 0; b < B && b < 256; ++b) pdiff += am[2][b] != am[1][b];
+  }
+  printf("first layer %dx%d B=%d | pair %8.1f us (x%.2f vs h; %zu words differ) | fp32 wino %8.1f us  f16x2 wino %8.1f us (x%.2f) | max |h - f32| %.2e of %.2e%s | per-image maxima differing by > 1e-4: %d\n",
+         H, W, B, ms[2] * 1e3, ms[1] / ms[2], pdiff, ms[0] * 1e3, ms[1] * 1e3, ms[0] / ms[1], dmax, omax, nan ? " NaN!" : "", bad);
   return 0;
 }
 
