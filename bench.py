@@ -517,8 +517,8 @@ def roofline_block(rows, wl, B, steps, dt, lib_build, workload):
     if bound == "mfma" and pipe_of[name] == "f16x2" and name.startswith("conv"):
         rf["frac_note"] = ("round 4 moved this kernel's products from the fp32 MFMA (157.3 TFLOP/s) to three fp16 plane products on the 16-bit pipe "
                            "(2500 TFLOP/s): `achieved` counts the executed plane products against THAT peak, so `frac` fell while the launch got shorter "
-                           "(r04_v9: 10.4 ms at 0.647 of the fp32 peak); the kernel is now bound by the L2 -> register stream of the transformed weights "
-                           "and by VALU issue (transform + split), DESIGN.md section 5h")
+                           "(r04_v9: 10.4 ms at 0.647 of the fp32 peak); what the launch's cycles go to is `limiter` (counters), and why the pair form "
+                           "is DESIGN.md section 4")
     # what limits the dominant kernel, FROM COUNTERS: tools/gpu_pmc_limiter.sh -> profiles/r*_pmc_limiter.json, taken on
     # this build (same rule as `traffic`); rounds 1-4 computed this figure from a byte count (tiles x 393216 B of transformed weights)
     try:

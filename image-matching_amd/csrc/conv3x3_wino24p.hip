@@ -2,7 +2,7 @@
 // products on v_mfma_f32_16x16x32_f16; superpoint/models/unet_parts.py:10-48, superpoint_test.py:113-123) with every U fragment used
 // for TWO tiles and the 24 positions SPLIT over two waves (round 5).
 //
-// Why.  The phase clocks of conv3x3_wino24h (tools/ubench/conv_h_bench.cpp -DH_TRACE; DESIGN section 5i) say its 72-MFMA phase takes
+// Why.  The phase clocks of conv3x3_wino24h (tools/ubench/conv_h_bench.cpp -DH_TRACE; DESIGN.md section 4) say its 72-MFMA phase takes
 // ~4 k cycles per chunk against 1.2 k of MFMA issue, and 5.6 k with a ring of four positions instead of six: the phase is paced by
 // the L2 latency of the wave's own U stream -- 24 positions x ~1 k cycles / ring depth -- and the ring cannot grow (96 accumulators +
 // 48 ring registers + the patch in flight + the transform = 242 of the 256 registers two waves per SIMD leave each).  A first
@@ -22,8 +22,8 @@
 //     positions: every output sees the arithmetic of conv3x3_wino24h in the same order -- the two kernels agree bit for bit
 //     (tests/test_gpu_superpoint.py), so every parity statement made for that kernel holds for this one;
 //   * the per-image maxima and the bias come through the scalar cache (uniform addresses; as vector loads they were waited for with
-//     vmcnt(0) behind the U refills and the patch loads just issued), and the V stores are ds_write_addtid_b32 (a wave's store is
-//     256 contiguous bytes in lane order: no address register, twice ds_write_b32's rate).
+//     vmcnt(0) behind the U refills and the patch loads just issued); the V stores are plain ds_write2st64_b32 (ds_write_addtid_b32
+//     was tried: twice the rate, four instructions per store with its m0 write and wait state, no gain).
 // U layout, scales (ConvArgs::amax_in / amax_out, u_scale_inv) and the blocked / NHWC activation layouts are conv3x3_wino24h's.
 //
 // LDS: V 2 tiles x 48 KB + raw patches 2 x 30 KB + 1 KB of maxima = 157 KB, one workgroup per CU.

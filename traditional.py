@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """BASELINE.json configs[0]: SIFT/ORB + FLANN registration of one pair directory on the CPU (reference traditional.py:8-57).
-Plumbing only: the arithmetic is OpenCV's (third-party), there is no GPU path here and no parity claim (DESIGN.md §7).  The
+Plumbing only: the arithmetic is OpenCV's (third-party), there is no GPU path here and no parity claim (DESIGN.md §8).  The
 reference's flags, directory convention (<img_dir>/source1/*, <img_dir>/template1/<one>) and outputs
 (<Result_dir>/<Method>/Transform1/trans_*, .../Match1/match_*) are kept.  Without OpenCV -- the case in this image, where
 `pip download opencv-contrib-python` finds no index (tools/try_opencv.sh) -- it prints one skip line and exits 0."""
