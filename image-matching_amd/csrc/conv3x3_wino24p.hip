@@ -167,15 +167,16 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
   // the host makes grid a multiple of ncob whenever a workgroup has more than one item, so the output block is fixed (vb % ncob) and
   // the tile advances by dt = NG grid / ncob per item -- stepped with carries (three divisions per item and wave, plus the loader's
   // three, were a tenth of the epilogue's instructions)
-  const int cob = vb % ncob;
-  const int dt = NG * (grid / ncob), dtx = dt % tiles_x, dty = (dt / tiles_x) % tiles_y, dtb = dt / (tiles_x * tiles_y);
+  const int cob = __builtin_amdgcn_readfirstlane(vb % ncob);       // (a division leaves its uniform result in a vector register)
+  const int dt = NG * (grid / ncob), dtx = __builtin_amdgcn_readfirstlane(dt % tiles_x), dty = __builtin_amdgcn_readfirstlane((dt / tiles_x) % tiles_y),
+            dtb = __builtin_amdgcn_readfirstlane(dt / (tiles_x * tiles_y));
   Tile cur, nxt;                 // cur: the item whose chunks are multiplied; nxt: the one after it = the loader's, once it has wrapped
   {
     const int t = NG * (vb / ncob) + tg;
     cur.live = t < ntiles;
-    cur.x0 = t % tiles_x;        // (tile coordinates; pixels = * OW, * OH)
-    cur.y0 = (t / tiles_x) % tiles_y;
-    cur.b = t / (tiles_x * tiles_y);
+    cur.x0 = __builtin_amdgcn_readfirstlane(t % tiles_x);        // (tile coordinates; pixels = * OW, * OH)
+    cur.y0 = __builtin_amdgcn_readfirstlane((t / tiles_x) % tiles_y);
+    cur.b = __builtin_amdgcn_readfirstlane(t / (tiles_x * tiles_y));
   }
   auto step_tile = [&](const Tile& t) __attribute__((always_inline)) -> Tile {
     Tile r;
@@ -321,8 +322,13 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
   // place with the wave's position lp + RING (of this chunk, or of the next chunk / the next item's block)
   auto mfma_phase = [&](auto firstc, int c) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(firstc)::value;
-    const bool lastc = c + 1 == nchunk;
-    const int nch = lastc ? 0 : c + 1;
+    // (c through an opaque scalar: for an item's first chunk, c == 0, hipcc hoisted (cob nchunk + nch) out of the item loop as a VECTOR
+    // value, spilled it, and reloaded it in the middle of this phase -- a scratch reload is a vector-memory operation that is waited
+    // for with vmcnt(0), i.e. behind the six U refills just issued)
+    int cs = c;
+    asm volatile("" : "+s"(cs));
+    const bool lastc = cs + 1 == nchunk;
+    const int nch = lastc ? 0 : cs + 1;
     // the B operands of position lp + 1 are requested beneath the MFMAs of position lp (without this the phase waits for the LDS
     // once per position -- ~270 cycles per position and wave against 96 of MFMAs: the trace of the first build)
     f16x8 bq[2][4];              // [buffer][K h, K m, S h, S m]
@@ -413,6 +419,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
 #pragma unroll
     for (int lp = 0; lp < NLP; ++lp) got[lp] = *(lds4p)(uintptr_t)(xr + lp * 1024);
     __syncthreads();               // (the next transform overwrites the region)
+    P_STAMP(6)
 
     // ---- output transform, un-scale + bias, ReLU, (2x2 max-pool), stores straight from registers (conv3x3_wino24h.hip); position
     // j*4 + i: rows 2 ph, 2 ph + 1 are this wave's, the other two the partner's
@@ -428,6 +435,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
       }
       w24_output_transform(m, k8, y);
     }
+    P_STAMP(7)
     {
       const int lwr = (lq & 15) >> 2, lwc = lq & 3;
       const int chl = outb ? (cb * 2 + (lq >> 5)) * (Ho_k * Wo_k * 8 * 4) + ((lq >> 4) & 1) * 16 : (cb * 16 + 4 * (lq >> 4)) * 4;
@@ -472,6 +480,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(su32x4, v), ors, (int)off, 0, 0);
           }
       }
+      P_STAMP(13)
       // the image's output maximum for the NEXT layer's s_v: into this workgroup's LDS table, flushed once at the end of the kernel
       // (conv3x3_wino24h.hip).  Wave maximum by DPP (row butterflies, then the four rows' lane 0 through SGPRs): a shuffle
       // reduction keeps six bpermute addresses alive across the main loop, and an atomic from every lane is turned by hipcc's atomic
@@ -488,6 +497,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
         if (tl.live && mw && lq == 0) atomicMax(amax_tab + (tl.b & (AMAX_SLOTS - 1)), mw);
         amax_run = 0;
       }
+      P_STAMP(14)
     }
     item_c += grid;
     if (item_c >= nitems) break;

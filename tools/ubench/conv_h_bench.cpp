@@ -81,11 +81,14 @@ static int run(int B, int H, int W, int Cin, int Cout, int pool, int blocked, fl
     const double items = (double)(((W + 15) / 16) * ((H + 7) / 8) * B / 2) * (Cout / 64) / 256.0, chunks = items * (Cin / 32);
     if (getenv("TRACE_WAVES"))
       for (int g = 0; g < 8; ++g)
+{
         printf("    wave %d: transform tail %.0f | barrier %.0f | MFMA %.0f | raw store %.0f | barrier %.0f | epilogue/item %.0f | bookkeeping + loads %.0f | row 1 %.0f | row 2 %.0f | row 0 %.0f | row 3 %.0f\n", g, tr[g * 16] / chunks, tr[g * 16 + 1] / chunks,
                tr[g * 16 + 2] / chunks, tr[g * 16 + 3] / chunks, tr[g * 16 + 4] / chunks, tr[g * 16 + 5] / items, tr[g * 16 + 8] / chunks, tr[g * 16 + 9] / chunks, tr[g * 16 + 10] / chunks, tr[g * 16 + 11] / chunks, tr[g * 16 + 12] / chunks);
+        printf("            per item: exchange %.0f | output transform %.0f | stores %.0f | maxima %.0f | to the next chunk step %.0f\n", tr[g * 16 + 6] / items, tr[g * 16 + 7] / items, tr[g * 16 + 13] / items, tr[g * 16 + 14] / items, tr[g * 16 + 5] / items);
+      }
     printf("  P trace (wave 0 of %d workgroups; cycles per chunk of a tile PAIR): loads + transform %.0f | barrier %.0f | MFMA phase %.0f | raw store %.0f | barrier %.0f | epilogue per item %.0f | total per chunk %.0f\n",
            n, s[0] / n / chunks, s[1] / n / chunks, s[2] / n / chunks, s[3] / n / chunks, s[4] / n / chunks, s[5] / n / items,
-           (s[0] + s[1] + s[2] + s[3] + s[4] + s[5] + s[8] + s[9] + s[10] + s[11] + s[12]) / n / chunks);
+           (s[0] + s[1] + s[2] + s[3] + s[4] + s[5] + s[6] + s[7] + s[13] + s[14] + s[8] + s[9] + s[10] + s[11] + s[12]) / n / chunks);
   }
 #endif
 #ifdef H_TRACE
