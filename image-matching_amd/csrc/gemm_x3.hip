@@ -152,6 +152,30 @@ __global__ __launch_bounds__(256, 2) void gemm_x3(GemmArgs p, const __bf16* __re
         }
       }
     }
+    // the q|k|v projection: the maxima the two-plane fp16 attention scales its operands by, from the registers (a tile's 128 rows
+    // belong to one (side, pair): aN0p, aN1p % 128 == 0; a wave's 32 columns to one of q | k | v)
+    if (p.amax) {
+      const int side = cu.r0 >= p.aB * p.aN0p ? 1 : 0;
+      const int rel = cu.r0 - side * p.aB * p.aN0p, Np = side ? p.aN1p : p.aN0p;
+      const int b = rel / Np;
+      const int n = side ? (p.an1 ? p.an1[b] : p.aN1) : (p.an0 ? p.an0[b] : p.aN0);
+      const int left = n - (rel - b * Np) - (wr * WROWS + 4 * kb);        // rows (local index ro) below this are valid
+      unsigned mx = 0;
+      if (col < p.N) {
+        const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ro = rb * 32 + (r & 3) + 8 * (r >> 2);
+            const unsigned bits = __builtin_bit_cast(unsigned, acc[rb][r] + bias) & 0x7fffffffu;
+            mx = ro < left ? max(mx, bits) : mx;
+          }
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+      if (lane == 0 && mx) atomicMax(p.amax + (side * p.aB + b) * 4 + (cu.n0 + wc * 32) / (p.N / 3), mx);
+    }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -207,8 +231,14 @@ bool gemm_x3_supported(const GemmArgs& a) {
   return true;
 }
 
+bool gemm_x3_amax_supported(const GemmArgs& a) {
+  return gemm_x3_supported(a) && !a.res && !a.relu && a.N % 3 == 0 && (a.N / 3) % 32 == 0 && a.aB > 0 && a.aN0p % BM == 0 && a.aN1p % BM == 0 &&
+         a.M == a.aB * (a.aN0p + a.aN1p);
+}
+
 hipError_t launch_gemm_x3(const GemmArgs& a, const void* wx3, hipStream_t s) {
   if (!gemm_x3_supported(a) || !wx3) return hipErrorInvalidValue;
+  if (a.amax && !gemm_x3_amax_supported(a)) return hipErrorInvalidValue;
   const __bf16* wx = static_cast<const __bf16*>(wx3);
   const bool wide = a.Npad % 128 == 0;
   const int nct = a.Npad / (wide ? 128 : 64), ntiles = ((a.M + BM - 1) / BM) * nct;

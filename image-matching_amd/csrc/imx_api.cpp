@@ -592,10 +592,14 @@ constexpr float kConvSpreadMax = 16384.f, kTailLooseMax = 65536.f;
 hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 int pad32(int n) { return ((n + 31) / 32) * 32; }
 
+// `am` (optional; the q|k|v projection): where the maxima of the output's thirds over the valid rows go if the throughput form can
+// write them from its epilogue; am->done says whether it did (else the caller runs launch_qkv_amax)
+struct GemmAmax { unsigned* amax; const int* n0; const int* n1; int B, N0p, N1p, N0, N1; bool done; };
 int gemm(imx_handle_t h, hipStream_t s, const char* name, const GemmW& W, const float* a0, int lda0, int K0, const float* a1,
-         int lda1, int K1, const float* res, int ldr, float* out, int ldo, int M, bool relu) {
+         int lda1, int K1, const float* res, int ldr, float* out, int ldo, int M, bool relu, GemmAmax* am = nullptr) {
   if (K0 + K1 != W.K) return fail(h, "internal: gemm '%s' K mismatch (%d+%d vs %d)", name, K0, K1, W.K);
   GemmArgs g{a0, lda0, K0, a1, lda1, K1, W.w, W.b, res, ldr, out, ldo, M, W.N, W.Npad, relu ? 1 : 0};
+  if (am) am->done = false;
   // Three forms, each with its reason:
   //   gemm_small  M <= 4096 rows (one or two pairs): the latency form ("latency_forms": auto / off / on);
   //   gemm_x3     the throughput form: fp32 products as six bf16 term products on the bf16 matrix pipe;
@@ -605,6 +609,11 @@ int gemm(imx_handle_t h, hipStream_t s, const char* name, const GemmW& W, const 
   const Options& o = h->opt;
   const bool small = gemm_small_supported(g) && (o.latency_forms >= 0 ? o.latency_forms != 0 : M <= 4096);
   const bool x3 = !small && !o.mfma_f32 && W.wx3 && gemm_x3_supported(g);
+  if (am && am->amax && x3) {
+    GemmArgs ga = g;
+    ga.amax = am->amax; ga.an0 = am->n0; ga.an1 = am->n1; ga.aB = am->B; ga.aN0p = am->N0p; ga.aN1p = am->N1p; ga.aN0 = am->N0; ga.aN1 = am->N1;
+    if (gemm_x3_amax_supported(ga)) { g = ga; am->done = true; }
+  }
   RUN(name, small ? launch_gemm_small(g, s) : x3 ? launch_gemm_x3(g, W.wx3, s) : launch_gemm(g, s));
   return 0;
 }
@@ -871,9 +880,18 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     amax_x = am + nl * 2 * B * 4;
   }
   bool have_amax_x = false;
+  // (IMX_QKV_AMAX=kernel: the maxima of a projected q|k|v by the separate pass even where the projection's epilogue can write them --
+  // the A/B switch of tests/test_gpu_superglue.py; the two must agree bit for bit)
+  const char* amax_env = getenv("IMX_QKV_AMAX");
+  const bool amax_by_kernel = amax_env && !strcmp(amax_env, "kernel");
   for (size_t l = 0; l < h->layers.size(); ++l) {
     const GnnLayer& L = h->layers[l];
-    if (!have_next && gemm(h, s, "qkv_proj", L.qkv, x, d, d, nullptr, 0, 0, nullptr, 0, qkv, 3 * d, R, false)) return -1;
+    if (!have_next) {
+      // (the maxima of this q|k|v, if the two-plane attention will want them, out of the projection's epilogue where it can)
+      GemmAmax gam{amax && !amax_by_kernel ? amax + 8 * B * l : nullptr, sd[0].n, sd[1].n, B, N0p, N1p, N0, N1, false};
+      if (gemm(h, s, "qkv_proj", L.qkv, x, d, d, nullptr, 0, 0, nullptr, 0, qkv, 3 * d, R, false, &gam)) return -1;
+      have_amax = gam.done;
+    }
     have_next = false;
     AttnArgs a{};
     a.qkv = qkv; a.out = att; a.B = B; a.N0p = N0p; a.N1p = N1p; a.d = d; a.heads = HEADS;

@@ -102,7 +102,15 @@ struct GemmArgs {
   float* out; int ldo;
   int M, N, Npad;
   int relu;
+  // optional (gemm_x3 only; the q|k|v projection): max |out| over the VALID rows of every (side, pair), by column third (q | k | v),
+  // as bit patterns through atomicMax into amax[(side B + pair) 4 + third] -- what launch_qkv_amax computes from the stored rows, out
+  // of the epilogue's registers.  Rows = [side 0: aB pairs x aN0p][side 1: aB x aN1p], counts an0 / an1 (null: aN0 / aN1);
+  // aN0p, aN1p % 128 == 0 and N == 3 d with d % 32 == 0 (gemm_x3_amax_supported)
+  unsigned* amax;
+  const int* an0; const int* an1;
+  int aB, aN0p, aN1p, aN0, aN1;
 };
+bool gemm_x3_amax_supported(const GemmArgs& a);
 // (K0, K1) % 32 == 0.
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 // The tail of one GNN layer for small row counts, fused (gnn_small.hip): hidden = relu([x | att] w1 + b1); x += hidden w2 + b2;

@@ -22,8 +22,7 @@ __global__ __launch_bounds__(512) void burst(float* out, long long* cyc, int pat
   f32x4 v = {(float)lane, 1.f, 2.f, 3.f};
   long long worst = 0, sum = 0;
   for (int it = 0; it < iters; ++it) {
-    __syncthreads();
-    const long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned offs[NST];            // (addresses first: the timed region is the stores alone)
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
       unsigned off;
@@ -41,12 +40,26 @@ __global__ __launch_bounds__(512) void burst(float* out, long long* cyc, int pat
         else if (pattern == 4) {   // x <-> (half, plane) by v_permlane16/32_swap: lane bits 4-5 = x, registers = (r, half, plane)
           const unsigned xl = lane >> 4, hf = k & 1, p2 = (wave & 3) * 2 + ((k >> 1) & 1);
           off = p2 * PLANE + ((ty * 8 + 2 * lwr + r) * WP + tx * 16 + 4 * lwc + xl) * 32u + hf * 16u;
+        } else if (pattern == 6) { // as 5, every wave in the same two planes (waves -> different tile rows)
+          const unsigned xl = (lane >> 2) & 3, wr = k & 3, tyw = (ty + 3 * wave) % 30u;
+          off = (lane >> 5) * PLANE + ((tyw * 8 + 2 * wr + r) * WP + tx * 16 + 4 * lwc + xl) * 32u + half * 16u;
+        } else if (pattern == 7) { // as 5 with ONE plane per instruction: lanes = 32 pixels x half (1 KB contiguous), registers = (r, wtile row, plane)
+          const unsigned px = lane >> 1, hf = lane & 1, wr = k & 3;
+          off = ((wave & 3) * 2 + (wave >> 2)) * PLANE + ((ty * 8 + 2 * wr + r) * WP + (tx & ~1u) * 16 + px) * 32u + hf * 16u;
         } else {                   // x <-> wtile row (a 4 x 4 transpose by DPP): lanes = (wtile column, x, half, plane), registers = (r, wtile row)
           const unsigned xl = (lane >> 2) & 3, wr = k & 3;
           off = pl * PLANE + ((ty * 8 + 2 * wr + r) * WP + tx * 16 + 4 * lwc + xl) * 32u + half * 16u;
         }
       }
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(su32x4, v), rs, (int)off, 0, 0);
+      offs[k] = off;
+    }
+#pragma unroll
+    for (int k = 0; k < NST; ++k) asm volatile("" : "+v"(offs[k]));
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(su32x4, v), rs, (int)offs[k], 0, 0);
       v[1] += 1.f;
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
@@ -63,10 +76,9 @@ int main(int argc, char** argv) {
   float* out; long long* cyc;
   hipMalloc(&out, 256 * wg_bytes); hipMalloc(&cyc, 256 * 8 * 2 * sizeof(long long));
   struct Geo { unsigned wp, plane; };
-  const Geo geos[] = {{320, 2457600}, {320, 2457600 + 256}, {320, 2457600 + 4096}, {324, 240 * 324 * 32}, {328, 240 * 328 * 32}, {336, 240 * 336 * 32}, {328, 240 * 328 * 32 + 256}, {352, 240 * 352 * 32}};
-  for (int pattern : {0, 3, 5})
+  const Geo geos[] = {{320, 2457600}, {320, 81920}};
+  for (int pattern : {0, 3, 5, 6, 7})
     for (const Geo& ge : geos) {
-      if (pattern == 0 && ge.wp != 320) continue;
       for (int grid : {1, 256}) {
         hipMemset(cyc, 0, 256 * 8 * 2 * sizeof(long long));
         hipLaunchKernelGGL(burst<8>, dim3(grid), dim3(512), 0, 0, out, cyc, pattern, iters, idle, wg_bytes, ge.wp, ge.plane);
