@@ -5,10 +5,11 @@
 // 0.55 of the launch's cycles for conv1ab_wino24h, 121 GB per 128-image launch).
 //
 //   workgroup = 8 waves = two 8x16-pixel tiles x 64 channels, one workgroup per CU, a contiguous range of tile pairs.
-//   per pair: image patches (2 x 12x20) + their maxima | barrier | conv1a channels 0..31 of both patches on the fp32 matrix cores
-//   (four waves per tile, conv1ab_wino24h's GEMM: weights = A, im2col = B, the tile's power of two s_v riding in B) | barrier |
-//   input transform of chunk 0, split by (8-channel sub-patch, tile) | barrier | 72 MFMAs per wave (rows 2 ph, 2 ph + 1 of both
-//   tiles) with conv1a channels 32..63 in three pieces between them | barrier | transform 1 | barrier | MFMAs 1 | barrier | accumulator exchange | barrier | barrier |
+//   per pair: input transform of chunk 0, split by (8-channel sub-patch, tile) | barrier | 72 MFMAs per wave (rows 2 ph, 2 ph + 1 of
+//   both tiles) with conv1a channels 32..63 in three pieces between them | barrier | the NEXT pair's image patches (2 x 12x20) and
+//   their maxima to LDS, transform 1 | barrier | MFMAs 1 with the next pair's conv1a channels 0..31 between them (conv1a on the fp32
+//   matrix cores, four waves per tile, conv1ab_wino24h's GEMM: weights = A, im2col = B, the tile's power of two s_v riding in B) |
+//   barrier | accumulator exchange (write | barrier | read | barrier) |
 //   conv1ab_wino24h's epilogue (output transform, 2x2 max-pool, un-scale + bias, ReLU, store) by wave (cb, ph) for tile ph.
 // Every output sees conv1ab_wino24h's arithmetic in the same order: the two kernels agree bit for bit (tests/test_gpu_superpoint.py).
 // LDS: V 96 KB + conv1a half patches 2 x 26 KB + image patches + maxima table = 151 KB.
@@ -134,8 +135,11 @@ __global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, 
     tlive = b < p.B;
   };
   const int t8 = tid & 255;
-  const int ipy = t8 / IMG_W - 2, ipx = t8 % IMG_W - 2;
-  auto fetch_px = [&](bool live) -> float {
+  auto fetch_px = [&](bool live) __attribute__((always_inline)) -> float {
+    // (the element's patch coordinates from the lane index, recomputed here: kept across the loop they are spilled, and a scratch
+    // reload is waited for with vmcnt(0) -- behind the U refills the matrix phase has just requested)
+    const int t8n = (wave_s & 3) * 64 + lane_now();
+    const int ipy = t8n / IMG_W - 2, ipx = t8n % IMG_W - 2;
     const int gy = ty * OH + ipy, gx = tx * OW + ipx;
     const bool ok = live && tlive && t8 < IMG_N && gy >= 0 && gy < H && gx >= 0 && gx < W;
     const int fb = tlive ? b : 0;
@@ -173,13 +177,13 @@ __global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, 
 
   // conv1a + folded BN + ReLU for 32 channels (16-channel blocks 2 half, 2 half + 1) of this wave's share of its tile's 10x18 halo
   // patch ON THE MATRIX CORES, scaled by sv, into raw (conv1ab_wino24h.hip)
-  auto conv1a_block = [&](int half, int j, int x0, int y0) __attribute__((always_inline)) {
+  auto conv1a_block = [&](int half, int j, int x0, int y0, float svb) __attribute__((always_inline)) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     {
       const int pp = (3 * tq + j) * 16 + n;
       const int py = gpy[j], px = gpx[j];
       const int gy = y0 + py - 1, gx = x0 + px - 1;
-      const float m = (pp < RH * RW && gy >= 0 && gy < H && gx >= 0 && gx < W) ? sv : 0.f;
+      const float m = (pp < RH * RW && gy >= 0 && gy < H && gx >= 0 && gx < W) ? svb : 0.f;
       const float* ip = imgt + py * IMG_W + px;
       float bv[3];
       bv[0] = ip[toff[0]] * m;
@@ -198,9 +202,9 @@ __global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, 
       }
     }
   };
-  auto conv1a_half = [&](int half, int x0, int y0) __attribute__((always_inline)) {
+  auto conv1a_half = [&](int half, int x0, int y0, float svb) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) conv1a_block(half, j, x0, y0);
+    for (int j = 0; j < 3; ++j) conv1a_block(half, j, x0, y0, svb);
   };
   auto v_store2 = [&](int pos, f16x2 h, f16x2 m) __attribute__((always_inline)) {
     *reinterpret_cast<f16x2*>(vwr + pos * 512) = h;
@@ -234,9 +238,10 @@ __global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, 
     row_load(rx, 3);
     row_out(3, mone2, rx, r1);       // r1 - r3
   };
-  // (chunk 0's phase carries conv1a's channels 32..63 in three pieces, after positions 1, 5 and 9: their fp32 MFMAs take their
-  // operands from LDS and registers, and fill matrix-pipe time in which the fp16 MFMAs wait for U on the L1 data path)
-  auto mfma_phase = [&](auto firstc, int c, int x0, int y0) __attribute__((always_inline)) {
+  // (each phase carries half a conv1a in three pieces, after positions 1, 5 and 9 -- chunk 0's this pair's channels 32..63, chunk
+  // 1's the NEXT pair's channels 0..31 (`half` = 0, the next pair's coordinates and scale): their fp32 MFMAs take their operands from
+  // LDS and registers, and fill matrix-pipe time in which the fp16 MFMAs wait for U on the L1 data path)
+  auto mfma_phase = [&](auto firstc, int c, int x0, int y0, float svb) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(firstc)::value;
     f16x8 bq[2][4];              // [buffer][K h, K m, S h, S m]
     auto b_load = [&](int buf, int lp) __attribute__((always_inline)) {
@@ -266,8 +271,8 @@ __global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, 
         else u_load(lp % RING, c ^ 1, np - NLP);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (FIRST && (lp & 3) == 1) {                // (5790 us against 5817 with the three pieces behind the phase)
-        conv1a_block(1, lp >> 2, x0, y0);
+      if ((lp & 3) == 1) {                         // (5790 us against 5817 with the three pieces behind the phase)
+        conv1a_block(FIRST ? 1 : 0, lp >> 2, x0, y0, svb);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -278,33 +283,51 @@ __global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, 
   const bool outb = p.out_blocked != 0;
   const int opx = outb ? 32 : Cout * 4;
   __syncthreads();               // the maxima table is zeroed
+  // Software pipeline over pairs (round 5, second form): the image patch of pair q + 1 goes to LDS and its conv1a channels 0..31 are
+  // computed INSIDE pair q's second matrix phase (raw is free there: transform 1 has consumed channels 32..63), so a pair costs six
+  // barriers instead of nine and no conv1a phase of its own.  x0 / y0 / bcur / lcur / sv: the pair being multiplied; tx / ty / b /
+  // tlive: the tile whose image element `pre` holds (one pair ahead of the image in LDS until it is stored).
+  auto image_to_lds = [&]() __attribute__((always_inline)) {
+    // (addresses from the lane index recomputed here, the wave maximum by DPP: a kept LDS address or a shuffle's bpermute address is
+    // spilled across the loop, and its scratch reload is waited for with vmcnt(0) behind the U refills just requested)
+    const int ln = lane_now(), t8n = (wave_s & 3) * 64 + ln;
+    if (t8n < IMG_N) img[tg * IMG_N + t8n] = pre;
+    unsigned mb = __builtin_bit_cast(unsigned, fabsf(pre));       // the patch's largest |value| (bit patterns of non-negative floats order as integers)
+    mb = max(mb, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xb1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    mb = max(mb, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0x4e, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    mb = max(mb, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0x141, 0xf, 0xf, true));   // row_half_mirror
+    mb = max(mb, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0x140, 0xf, 0xf, true));   // row_mirror
+    const unsigned m01 = max((unsigned)__builtin_amdgcn_readlane((int)mb, 0), (unsigned)__builtin_amdgcn_readlane((int)mb, 16));
+    const unsigned m23 = max((unsigned)__builtin_amdgcn_readlane((int)mb, 32), (unsigned)__builtin_amdgcn_readlane((int)mb, 48));
+    if (ln == 0) wmax[wave_s] = __builtin_bit_cast(float, max(m01, m23));
+  };
+  auto scale_from_lds = [&]() __attribute__((always_inline)) -> float {
+    const float* wm = wmax + 4 * tg;
+    const float imax = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v_scale_of_bound(fmaf(imax, p.c1a_l1, p.c1a_bmax)))));
+  };
+  int x0 = tx * OW, y0 = ty * OH, bcur = tlive ? b : 0, lcur = tlive;
+  image_to_lds();
+  next_tile();
+  pre = fetch_px(q_begin + 1 < q_end);
+  __syncthreads();               // image patches and maxima visible
+  sv = scale_from_lds();
+  conv1a_half(0, x0, y0, sv);
+  __syncthreads();               // channels 0..31 of both patches complete
   for (int q = q_begin; q < q_end; ++q) {
-    const int x0 = tx * OW, y0 = ty * OH, bcur = tlive ? b : 0, lcur = tlive;
-    if (t8 < IMG_N) img[tg * IMG_N + t8] = pre;
-    {                                           // the patch's largest |value|: wave maxima -> LDS
-      float mx = fabsf(pre);
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-      if (lane == 0) wmax[wave_s] = mx;
-    }
-    next_tile();
-    pre = fetch_px(q + 1 < q_end);
-    __syncthreads();             // image patches and maxima visible (and every wave is past the previous pair's epilogue reads)
-    {
-      const float* wm = wmax + 4 * tg;
-      const float imax = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-      sv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v_scale_of_bound(fmaf(imax, p.c1a_l1, p.c1a_bmax)))));
-    }
-    conv1a_half(0, x0, y0);
-    __syncthreads();             // channels 0..31 of both patches complete
     transform();
     __syncthreads();             // V complete; raw free
-    mfma_phase(BoolC<true>{}, 0, x0, y0);      // (+ conv1a channels 32..63)
-    __syncthreads();             // channels 32..63 complete; V free
+    mfma_phase(BoolC<true>{}, 0, x0, y0, sv);  // (+ conv1a channels 32..63)
+    __syncthreads();             // channels 32..63 complete; V free; the image patches have been read for the last time
+    const int x0n = tx * OW, y0n = ty * OH, bn = tlive ? b : 0, ln = tlive;     // the pair after this one (dead past the range: zeros)
+    image_to_lds();
+    next_tile();
+    pre = fetch_px(q + 2 < q_end);
     transform();
-    __syncthreads();             // V complete
-    mfma_phase(BoolC<false>{}, 1, x0, y0);
-    __syncthreads();             // every wave is past its B-operand reads: the V region takes the exchange
+    __syncthreads();             // V complete; raw free; the next pair's image patches and maxima visible
+    const float svn = scale_from_lds();
+    mfma_phase(BoolC<false>{}, 1, x0n, y0n, svn);     // (+ the next pair's conv1a channels 0..31)
+    __syncthreads();             // every wave is past its B-operand reads: the V region takes the exchange; raw holds the next pair's channels 0..31
 
     // ---- the accumulators of the partner's tile go to LDS, the partner's of THIS wave's tile come back (conv3x3_wino24p.hip)
     typedef __attribute__((address_space(3))) f32x4* lds4p;
@@ -373,6 +396,7 @@ __global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, 
         amax_run = 0;
       }
     }
+    x0 = x0n; y0 = y0n; bcur = bn; lcur = ln; sv = svn;
   }
   if (p.amax_out) {
     __syncthreads();
