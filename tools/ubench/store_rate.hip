@@ -17,7 +17,7 @@ typedef unsigned su32x4 __attribute__((__vector_size__(16)));
 template <int NST>
 __global__ __launch_bounds__(512) void burst(float* out, long long* cyc, int pattern, int iters, int idle, size_t wg_bytes, unsigned WP, unsigned PLANE) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const __amdgpu_buffer_rsrc_t rs = pattern >= 3 ? __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, 8 * PLANE, 0x00020000)
+  const __amdgpu_buffer_rsrc_t rs = pattern >= 3 ? __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, 0x7ffffff0, 0x00020000)
                                                       : __builtin_amdgcn_make_buffer_rsrc((void*)((char*)out + (size_t)blockIdx.x * wg_bytes), 0, (int)wg_bytes, 0x00020000);
   f32x4 v = {(float)lane, 1.f, 2.f, 3.f};
   long long worst = 0, sum = 0;
@@ -46,6 +46,11 @@ __global__ __launch_bounds__(512) void burst(float* out, long long* cyc, int pat
         } else if (pattern == 7) { // as 5 with ONE plane per instruction: lanes = 32 pixels x half (1 KB contiguous), registers = (r, wtile row, plane)
           const unsigned px = lane >> 1, hf = lane & 1, wr = k & 3;
           off = ((wave & 3) * 2 + (wave >> 2)) * PLANE + ((ty * 8 + 2 * wr + r) * WP + (tx & ~1u) * 16 + px) * 32u + hf * 16u;
+        } else if (pattern == 8) { // the staged blocked form: lanes in address order, two rows of 16 pixels x 32 bytes (2 x 512 contiguous bytes)
+          const unsigned row = 2 * (k & 3) + (lane >> 5), px = (lane >> 1) & 15, hf = lane & 1;
+          off = ((wave & 3) * 2 + (k >> 2)) * PLANE + ((ty * 8 + row) * WP + tx * 16 + px) * 32u + hf * 16u;
+        } else if (pattern == 9) { // the staged NHWC form: 16 pixels x 64 bytes, a quad of lanes per pixel, pixels 2 KB apart (512 channels)
+          off = ((ty * 8 + k) * WP + tx * 16 + (lane >> 2)) * 2048u + (wave & 3) * 64u + (lane & 3) * 16u;
         } else {                   // x <-> wtile row (a 4 x 4 transpose by DPP): lanes = (wtile column, x, half, plane), registers = (r, wtile row)
           const unsigned xl = (lane >> 2) & 3, wr = k & 3;
           off = pl * PLANE + ((ty * 8 + 2 * wr + r) * WP + tx * 16 + 4 * lwc + xl) * 32u + half * 16u;
@@ -73,11 +78,14 @@ __global__ __launch_bounds__(512) void burst(float* out, long long* cyc, int pat
 int main(int argc, char** argv) {
   const int iters = 32, idle = argc > 1 ? atoi(argv[1]) : 20;
   const size_t wg_bytes = 8 * 8 * 8 * 4096;      // (pattern 3 addresses one 19.7-MB image from every workgroup: descriptor below)      // 8 generations x 8 waves x 8 stores x (1 KB footprint up to 4 KB)
-  float* out; long long* cyc;
-  hipMalloc(&out, 256 * wg_bytes); hipMalloc(&cyc, 256 * 8 * 2 * sizeof(long long));
+  float* out = nullptr; long long* cyc = nullptr;
+  if (hipMalloc(&out, (size_t)2200 << 20) != hipSuccess || hipMalloc(&cyc, 256 * 8 * 2 * sizeof(long long)) != hipSuccess || !out || !cyc) {   // (pattern 9 spans 157 MB per image; the descriptor covers 2 GB)
+    printf("allocation failed\n");
+    return 1;
+  }
   struct Geo { unsigned wp, plane; };
-  const Geo geos[] = {{320, 2457600}, {320, 81920}};
-  for (int pattern : {0, 3, 5, 6, 7})
+  const Geo geos[] = {{320, 2457600}};
+  for (int pattern : {0, 3, 7, 8, 9})
     for (const Geo& ge : geos) {
       for (int grid : {1, 256}) {
         hipMemset(cyc, 0, 256 * 8 * 2 * sizeof(long long));
