@@ -170,21 +170,34 @@ __global__ __launch_bounds__(1024) void sinkhorn_cols(SinkhornArgs a) {
 // the per-slab partials into v.  Slab `m / R` also owns the dustbin row i = m.
 // NW = waves per workgroup: 16 (a row split over 16/R waves) or, when a row fits one wave's batch (N1p <= 1024), 8 -- twice
 // as many workgroups resident per CU to cover each other's load latency and barriers.
-template <int R, int NW>
-__global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* __restrict__ part, int nslab_max) {
+// Round 5: a workgroup walks G consecutive slabs and merges their column partials in registers before writing them: the partials
+// were 2 x 68 MB of an iteration's traffic at C3 (written here, read by sinkhorn_vmerge) beside the 268 MB of S.
+template <int R, int NW, int G>
+__global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* __restrict__ part, int ngroup_max) {   // (eight waves per SIMD: <= 64 registers)
   extern __shared__ float sm[];
   float* tile = sm;                       // [R][N1p]
   float* vs = tile + R * a.N1p;           // [N1p + 1]
   __shared__ float uu[R];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.y, slab = blockIdx.x, i0 = slab * R;
+  const int b = blockIdx.y, grp = blockIdx.x;
   int m, n;
   counts(a, b, m, n);
-  if (m == 0 || n == 0 || i0 > m) return;
+  if (m == 0 || n == 0 || grp * G * R > m) return;
   const float* v = a.v + (size_t)b * (a.N1p + 1);
   for (int j = tid; j <= n; j += 64 * NW) vs[j] = v[j];
   __syncthreads();
   const float norm = -logf((float)(m + n));
+  constexpr int MAXC = R == 4 ? 4 : 2;    // real columns per thread: N1p / (64 NW) -- N1p <= 1024 with 8 waves, <= 2048 with 16 (R >= 8), <= 4096 with 16 (R = 4)
+  LSE cacc[MAXC], cdust{-INFINITY, 0.f};  // (the dustbin column j = n: thread 0's)
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) cacc[c] = LSE{-INFINITY, 0.f};
+  // (G is a template parameter and the loop fully unrolled: as a run-time loop hipcc keeps 40 more vector and 50 more scalar registers
+  // across the slabs -- 81 / 105 against 43 / 58 -- and the kernel falls off its eight waves per SIMD)
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+  const int slab = grp * G + g, i0 = slab * R;
+  if (i0 > m) break;                      // (block-uniform)
+  if (g) __syncthreads();                 // the previous slab's column pass has read tile / uu
   // Row pass: all 16 waves work whatever R is -- a row is split over W = 16/R waves (segments of N1p/W <= 1024
   // columns, one batch of four float4 loads per lane); their partial (max, sum) pairs are merged through LDS.
   constexpr int W = NW / R;
@@ -288,66 +301,92 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
   }
   __syncthreads();
   const int rows = min(R, m + 1 - i0);      // rows of this slab, the last may be the dustbin row
-  float2* pb = reinterpret_cast<float2*>(part + ((size_t)b * nslab_max + slab) * (a.N1p + 1) * 2);
   // all R rows REAL (i0 + R <= m): `rows == R` alone also admits a slab whose last row is the dustbin row i == m
   // (m % R == R-1), and that row of `tile` is never written by the row pass
   const bool fastcol = i0 + R <= m && n == a.N1p;
-  if (fastcol) {
-    // Fast path (uniform): a full slab of real rows, every column real -- no masks; the dustbin column (j = n) is left to
-    // the generic loop below, which then runs for one thread only
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    static_assert(R % 4 == 0, "slab rows in groups of four");
-    const int ld = a.N1p;
-    for (int j = tid; j < n; j += 64 * NW) {
-      f32x4 t4[R / 4];
-      float mx = -INFINITY;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  static_assert(R % 4 == 0, "slab rows in groups of four");
+  const int ld = a.N1p;
+  // the generic column: masks for the rows past m, the dustbin row and the dustbin column (alpha)
+  auto generic_col = [&](int j) __attribute__((always_inline)) -> LSE {
+    float tt[R];
 #pragma unroll
-      for (int q = 0; q < R / 4; ++q) {
-        t4[q] = (f32x4){tile[(4 * q + 0) * ld + j], tile[(4 * q + 1) * ld + j], tile[(4 * q + 2) * ld + j], tile[(4 * q + 3) * ld + j]} +
-                (f32x4){uu[4 * q + 0], uu[4 * q + 1], uu[4 * q + 2], uu[4 * q + 3]};
-        mx = fmaxf(fmaxf(mx, fmaxf(t4[q][0], t4[q][1])), fmaxf(t4[q][2], t4[q][3]));
-      }
-      const float ml = -mx * LOG2E;
-      const f32x4 l2e = {LOG2E, LOG2E, LOG2E, LOG2E}, ml4 = {ml, ml, ml, ml};
-      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < R / 4; ++q) {
-        const f32x4 a4 = __builtin_elementwise_fma(t4[q], l2e, ml4);
-        s4 += (f32x4){__builtin_amdgcn_exp2f(a4[0]), __builtin_amdgcn_exp2f(a4[1]), __builtin_amdgcn_exp2f(a4[2]), __builtin_amdgcn_exp2f(a4[3])};
-      }
-      pb[j] = make_float2(mx, lse_unbias((s4[0] + s4[1]) + (s4[2] + s4[3]), mx, ml));
-    }
-  }
-  for (int j = fastcol ? n + tid : tid; j <= n; j += 64 * NW) {
-    float t[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) t[r] = tile[r * a.N1p + j];          // rows beyond `rows` hold stale data, masked below
+    for (int r = 0; r < R; ++r) tt[r] = j < n ? tile[r * a.N1p + j] : 0.f;     // rows beyond `rows` hold stale data, masked below
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const bool real = (i0 + r < m) && (j < n);
-      t[r] = r < rows ? (real ? t[r] : a.alpha) + uu[r] : -INFINITY;
-      mx = fmaxf(mx, t[r]);
+      tt[r] = r < rows ? (real ? tt[r] : a.alpha) + uu[r] : -INFINITY;
+      mx = fmaxf(mx, tt[r]);
     }
-    const float ml = -mx * LOG2E;                                     // rows >= 1: mx is finite
-    float sum = 0.f;
+    float sum = 0.f;                                                  // rows >= 1: mx is finite
 #pragma unroll
-    for (int r = 0; r < R; ++r) sum += __builtin_amdgcn_exp2f((t[r] - mx) * LOG2E);
-    (void)ml;
-    pb[j] = make_float2(mx, sum);
+    for (int r = 0; r < R; ++r) sum += __builtin_amdgcn_exp2f((tt[r] - mx) * LOG2E);
+    return LSE{mx, sum};
+  };
+  if (fastcol) {
+    // Fast path (uniform): a full slab of real rows, every column real -- no masks
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      __builtin_amdgcn_sched_barrier(0);       // (one column at a time: interleaved, the unrolled bodies cost 40 registers and the eighth wave per SIMD)
+      const int j = tid + c * 64 * NW;
+      if (j < n) {
+        f32x4 t4[R / 4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < R / 4; ++q) {
+          t4[q] = (f32x4){tile[(4 * q + 0) * ld + j], tile[(4 * q + 1) * ld + j], tile[(4 * q + 2) * ld + j], tile[(4 * q + 3) * ld + j]} +
+                  (f32x4){uu[4 * q + 0], uu[4 * q + 1], uu[4 * q + 2], uu[4 * q + 3]};
+          mx = fmaxf(fmaxf(mx, fmaxf(t4[q][0], t4[q][1])), fmaxf(t4[q][2], t4[q][3]));
+        }
+        const float ml = -mx * LOG2E;
+        const f32x4 l2e = {LOG2E, LOG2E, LOG2E, LOG2E}, ml4 = {ml, ml, ml, ml};
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < R / 4; ++q) {
+          const f32x4 a4 = __builtin_elementwise_fma(t4[q], l2e, ml4);
+          s4 += (f32x4){__builtin_amdgcn_exp2f(a4[0]), __builtin_amdgcn_exp2f(a4[1]), __builtin_amdgcn_exp2f(a4[2]), __builtin_amdgcn_exp2f(a4[3])};
+        }
+        const LSE t{mx, lse_unbias((s4[0] + s4[1]) + (s4[2] + s4[3]), mx, ml)};
+        cacc[c] = lse_merge(cacc[c], t);                              // (the first slab: exp(0) = 1 and an empty accumulator's 0 -- the pair as computed)
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int j = tid + c * 64 * NW;
+      if (j < n) {
+        const LSE t = generic_col(j);
+        cacc[c] = lse_merge(cacc[c], t);
+      }
+    }
   }
+  __builtin_amdgcn_sched_barrier(0);
+  if (tid == 0) {
+    const LSE t = generic_col(n);
+    cdust = lse_merge(cdust, t);
+  }
+  }  // slabs of the group
+  float2* pb = reinterpret_cast<float2*>(part + ((size_t)b * ngroup_max + grp) * (a.N1p + 1) * 2);
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int j = tid + c * 64 * NW;
+    if (j < n) pb[j] = make_float2(cacc[c].m, cacc[c].s);
+  }
+  if (tid == 0) pb[n] = make_float2(cdust.m, cdust.s);
 }
 
 // v[j] = log_nu[j] - logsumexp over the slabs' partial (max, sum) pairs.  64 columns x 16 slab groups per
 // workgroup; each thread loads its (up to 4 at a time) partials before merging them, so the loads overlap.
-__global__ __launch_bounds__(1024) void sinkhorn_vmerge(SinkhornArgs a, const float* __restrict__ part, int nslab_max, int R) {
+__global__ __launch_bounds__(1024) void sinkhorn_vmerge(SinkhornArgs a, const float* __restrict__ part, int nslab_max, int R, int G) {
   __shared__ float pm[16][64], ps[16][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int b = blockIdx.y, j = blockIdx.x * 64 + c;
   int m, n;
   counts(a, b, m, n);
   if (m == 0 || n == 0) return;
-  const int nslab = m / R + 1;
+  const int nslab = (m / R + 1 + G - 1) / G;        // groups of G slabs, merged by sinkhorn_slab (nslab_max = groups per pair)
   // two-pass merges: the maximum of the (max, sum) pairs first, then ONE exp per pair -- a chain of pairwise lse_merge()
   // spends two exps (quarter-rate instructions) and two selects per pair
   LSE t{-INFINITY, 0.f};
@@ -529,23 +568,29 @@ hipError_t launch_gather_desc(const float* src, int64_t sb, int64_t sc, int64_t 
   return hipGetLastError();
 }
 
-template <int R, int NW>
-static void launch_slab_k(const SinkhornArgs& a, int nslab_max, hipStream_t s) {
+template <int R, int NW, int G>
+static void launch_slab_g(const SinkhornArgs& a, int nslab_max, hipStream_t s) {
   const size_t lds = ((size_t)R * a.N1p + a.N1p + 1) * sizeof(float);
   static unsigned long long attr = 0;
-  raise_lds_limit(reinterpret_cast<const void*>(sinkhorn_slab<R, NW>), 96 * 1024, attr);
-  hipLaunchKernelGGL((sinkhorn_slab<R, NW>), dim3((unsigned)nslab_max, (unsigned)a.B), dim3(64 * NW), lds, s, a, a.part, nslab_max);
+  raise_lds_limit(reinterpret_cast<const void*>(sinkhorn_slab<R, NW, G>), 96 * 1024, attr);
+  hipLaunchKernelGGL((sinkhorn_slab<R, NW, G>), dim3((unsigned)nslab_max, (unsigned)a.B), dim3(64 * NW), lds, s, a, a.part, nslab_max);
+}
+template <int R, int NW>
+static void launch_slab_k(const SinkhornArgs& a, int nslab_max, int G, hipStream_t s) {
+  if (G == 4) launch_slab_g<R, NW, 4>(a, nslab_max, s);
+  else if (G == 2) launch_slab_g<R, NW, 2>(a, nslab_max, s);
+  else launch_slab_g<R, NW, 1>(a, nslab_max, s);
 }
 
 template <int R>
-static void launch_slab_iter(const SinkhornArgs& a, int nslab_max, hipStream_t s) {
+static void launch_slab_iter(const SinkhornArgs& a, int nslab_max, int G, hipStream_t s) {
   if constexpr (R == 8) {
-    if (a.N1p <= 1024) launch_slab_k<8, 8>(a, nslab_max, s);     // a row fits one wave's batch: 8-wave workgroups, four per CU
-    else launch_slab_k<8, 16>(a, nslab_max, s);
+    if (a.N1p <= 1024) launch_slab_k<8, 8>(a, nslab_max, G, s);  // a row fits one wave's batch: 8-wave workgroups, four per CU
+    else launch_slab_k<8, 16>(a, nslab_max, G, s);
   } else {
-    launch_slab_k<R, 16>(a, nslab_max, s);
+    launch_slab_k<R, 16>(a, nslab_max, G, s);
   }
-  hipLaunchKernelGGL(sinkhorn_vmerge, dim3((unsigned)((a.N1p + 1 + 63) / 64), (unsigned)a.B), dim3(1024), 0, s, a, a.part, nslab_max, R);
+  hipLaunchKernelGGL(sinkhorn_vmerge, dim3((unsigned)((a.N1p + 1 + 63) / 64), (unsigned)a.B), dim3(1024), 0, s, a, a.part, nslab_max, R, G);
 }
 
 hipError_t launch_sinkhorn(const SinkhornArgs& a, hipStream_t s) {
@@ -563,15 +608,21 @@ hipError_t launch_sinkhorn(const SinkhornArgs& a, hipStream_t s) {
   }
   const int R = sinkhorn_slab_rows(a.N1p);
   if (R > 0 && a.part) {
-    const int nslab_max = a.N0p / R + 1;
+    // G slabs per workgroup (their column partials merged in registers): where a pair has enough slabs to fill its share of the
+    // chip anyway (IMX_SINKHORN_GROUP overrides: the A/B switch of the parity tests; 1 = a partial per slab, as before round 5)
+    // (measured, tools/sinkhorn_time.py: C3, 129 slabs of 1024 columns x 64 pairs: 2.28 / 2.02 / 2.03 ms per 30 iterations with 1 / 2 / 4
+    // slabs per workgroup; C5, 257 slabs of 2048 columns x 8 pairs: 4.49 / 4.63 / 4.18 per 100)
+    int G = a.N0p / R + 1 < 64 ? 1 : a.N1p <= 1024 ? 2 : 4;
+    if (const char* e = getenv("IMX_SINKHORN_GROUP")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) G = v; }
+    const int nslab_max = (a.N0p / R + 1 + G - 1) / G;           // groups per pair = the partial buffer's rows per pair (<= N0p / R + 1: a.part's size)
     // (Round 5: walking the batch in groups whose score matrices fit the 256-MB Infinity Cache -- all iterations of a group back to
     // back -- was measured and is SLOWER: 2.22 ms for the 64 C3 pairs in one group, 2.58 / 2.88 / 3.16 / 4.25 ms with groups of 150 /
     // 112 / 72 / 40 MB.  An iteration of 64 pairs is 73 us over two launches: the loop is paced by launches and their tails, not by
     // the 268 MB an iteration reads, and smaller groups only multiply the launches.)
     for (int it = 0; it < a.iters; ++it) {
-      if (R == 16) launch_slab_iter<16>(a, nslab_max, s);
-      else if (R == 8) launch_slab_iter<8>(a, nslab_max, s);
-      else launch_slab_iter<4>(a, nslab_max, s);
+      if (R == 16) launch_slab_iter<16>(a, nslab_max, G, s);
+      else if (R == 8) launch_slab_iter<8>(a, nslab_max, G, s);
+      else launch_slab_iter<4>(a, nslab_max, G, s);
     }
     return hipGetLastError();
   }

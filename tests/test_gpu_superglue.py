@@ -393,3 +393,26 @@ def test_qkv_maxima_from_the_projection_epilogue_equal_the_separate_pass(tail, m
         assert np.array_equal(res["epilogue"][0][i], res["kernel"][0][i]) and np.array_equal(res["epilogue"][2][i], res["kernel"][2][i]), i
     assert np.array_equal(res["epilogue"][1], res["kernel"][1]) and np.array_equal(res["epilogue"][3], res["kernel"][3])
     assert np.array_equal(res["epilogue"][0][0], g["matches0"])
+
+
+@pytest.mark.parametrize("name", ["c3_pair_s59.npz", "c5_pair_s19.npz"])
+def test_sinkhorn_grouped_slabs_equal_a_partial_per_slab(name, monkeypatch):
+    """Round 5: a Sinkhorn workgroup walks two consecutive 8-row slabs and merges their column partials in registers (half the
+    partial traffic).  The merge is the same log-sum-exp with one more pairwise step: potentials equal to 2e-6, match indices equal,
+    against the one-partial-per-slab form (IMX_SINKHORN_GROUP=1) and against a group of four."""
+    g = util.golden(name)
+    H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
+    data = {k: v.cuda() for k, v in _oracle_pair_inputs(seed, H, W, d, K).items()}
+    eng, L = _engine(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(d))
+    eng.set_debug(True)
+    res = {}
+    for G in ("1", "2", "4"):
+        monkeypatch.setenv("IMX_SINKHORN_GROUP", G)
+        out = _run(eng, data, (1, 1, H, W))
+        res[G] = (out, eng.fetch("u").copy(), eng.fetch("v").copy())
+    for G in ("2", "4"):
+        assert np.array_equal(res[G][0][0], res["1"][0][0]) and np.array_equal(res[G][0][1], res["1"][0][1]), G
+        assert np.abs(res[G][1] - res["1"][1]).max() <= 2e-6 * max(1.0, np.abs(res["1"][1]).max()), (G, np.abs(res[G][1] - res["1"][1]).max())
+        assert np.abs(res[G][2] - res["1"][2]).max() <= 2e-6 * max(1.0, np.abs(res["1"][2]).max()), (G, np.abs(res[G][2] - res["1"][2]).max())
+    assert np.array_equal(res["2"][0][0], g["matches0"])
