@@ -5,11 +5,11 @@
 // 0.55 of the launch's cycles for conv1ab_wino24h, 121 GB per 128-image launch).
 //
 //   workgroup = 8 waves = two 8x16-pixel tiles x 64 channels, one workgroup per CU, a contiguous range of tile pairs.
-//   per pair: input transform of chunk 0, split by (8-channel sub-patch, tile) | barrier | 72 MFMAs per wave (rows 2 ph, 2 ph + 1 of
+//   per pair: input transform of chunk 0, split by (8-channel sub-patch, tile) | barrier | 72 MFMAs per wave (transformed columns 3 ph .. 3 ph + 2 of
 //   both tiles) with conv1a channels 32..63 in three pieces between them | barrier | the NEXT pair's image patches (2 x 12x20) and
 //   their maxima to LDS, transform 1 | barrier | MFMAs 1 with the next pair's conv1a channels 0..31 between them (conv1a on the fp32
 //   matrix cores, four waves per tile, conv1ab_wino24h's GEMM: weights = A, im2col = B, the tile's power of two s_v riding in B) |
-//   barrier | accumulator exchange (write | barrier | read | barrier) |
+//   barrier | output transform's row stage, exchange of its six results (write | barrier | read | barrier) |
 //   conv1ab_wino24h's epilogue (output transform, 2x2 max-pool, un-scale + bias, ReLU, store) by wave (cb, ph) for tile ph.
 // Every output sees conv1ab_wino24h's arithmetic in the same order: the two kernels agree bit for bit (tests/test_gpu_superpoint.py).
 // LDS: V 96 KB + conv1a half patches 2 x 26 KB + image patches + maxima table = 151 KB.
@@ -40,7 +40,7 @@ constexpr int VPLANE = NPOS * 4 * 16 * 8;      // halves per plane of a tile
 constexpr int VGRP = 2 * VPLANE;               // halves per tile
 constexpr int UPOS = 2 * 4 * 64 * 8;           // halves of U per (chunk, position): [plane][channel block][lane][8]
 constexpr int RING = 6;
-constexpr int XCH = NLP * 64 * 16;             // bytes of one wave's accumulator exchange block
+constexpr int XCH = 6 * 64 * 16;               // bytes of one wave's exchange block: the row stage's six results for the partner's tile (conv3x3_wino24p.hip)
 constexpr int AMAX_SLOTS = 256;
 
 template <bool V>
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, 
   const int tq = wave_s & 3, tg = wave_s >> 2;         // transform role: 8-channel sub-patch, tile; conv1a / image / epilogue: tile tg (== ph), quarter tq
   const int H = p.H, W = p.W, Cout = p.Cout;
   const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.wuh, 0, 2 * NPOS * UPOS * 2, 0x00020000);
-  const int uoff_lane = (cb * 64 + lane) * 16 + ph * 2 * (UPOS * 2);
+  const int uoff_lane = (cb * 64 + lane) * 16 + ph * NLP * (UPOS * 2);         // the wave's positions: transformed columns 3 ph .. 3 ph + 2 = positions 12 ph + lp (conv3x3_wino24p.hip)
   typedef const float __attribute__((address_space(4)))* cf32p;
   const cf32p bias_c = (cf32p)(uintptr_t)p.bias;
 
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, 
   _Float16* const vwr = (_Float16*)((__attribute__((address_space(3))) unsigned char*)(uintptr_t)(lds0 + (unsigned)(tg * (VGRP * 2) + tq * 256 + lane * 4)));
   const _Float16 *vrdK, *vrdS;
   {
-    unsigned a = lds0 + (unsigned)(ph * (VGRP * 2) + ph * 2 * 1024 + lane * 16);
-    unsigned b = lds0 + (unsigned)((1 - ph) * (VGRP * 2) + ph * 2 * 1024 + lane * 16);
+    unsigned a = lds0 + (unsigned)(ph * (VGRP * 2) + ph * NLP * 1024 + lane * 16);
+    unsigned b = lds0 + (unsigned)((1 - ph) * (VGRP * 2) + ph * NLP * 1024 + lane * 16);
     asm volatile("" : "+v"(a), "+v"(b));
     vrdK = (const _Float16*)((__attribute__((address_space(3))) unsigned char*)(uintptr_t)a);
     vrdS = (const _Float16*)((__attribute__((address_space(3))) unsigned char*)(uintptr_t)b);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, 
   }
   u32x4v ub[RING][2];
   auto u_load = [&](int slot, int chv, int lp) __attribute__((always_inline)) {
-    const int pos = (lp >> 1) * 4 + (lp & 1);
+    const int pos = lp;
     const int so = __builtin_amdgcn_readfirstlane((chv * NPOS + pos) * (UPOS * 2));
     ub[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(ur, uoff_lane, so, 0);
     ub[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(ur, uoff_lane, so + 4 * 64 * 16, 0);
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, 
     constexpr bool FIRST = decltype(firstc)::value;
     f16x8 bq[2][4];              // [buffer][K h, K m, S h, S m]
     auto b_load = [&](int buf, int lp) __attribute__((always_inline)) {
-      const int po = ((lp >> 1) * 4 + (lp & 1)) * 512;
+      const int po = lp * 512;
       bq[buf][0] = *reinterpret_cast<const f16x8*>(vrdK + po);
       bq[buf][1] = *reinterpret_cast<const f16x8*>(vrdK + VPLANE + po);
       bq[buf][2] = *reinterpret_cast<const f16x8*>(vrdS + po);
@@ -343,26 +343,41 @@ __global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, 
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) bs4[qq] = kq2 == 0 ? b0[qq] : kq2 == 1 ? b1[qq] : kq2 == 2 ? b2[qq] : b3[qq];
     }
+    // the output transform's row stage on this wave's three columns of both tiles; the six results for the partner's tile through
+    // LDS, the partner's for this wave's tile back; then the column stage (conv3x3_wino24p.hip)
+    f32x4 sK0[3], sK1[3];
+    {
+      f32x4 sS0[3], sS1[3];
 #pragma unroll
-    for (int lp = 0; lp < NLP; ++lp) *(lds4p)(uintptr_t)(xw + lp * 1024) = accS[lp];
+      for (int jj = 0; jj < 3; ++jj) {
+        w24_out_rows(accS[jj * 4 + 0], accS[jj * 4 + 1], accS[jj * 4 + 2], accS[jj * 4 + 3], sS0[jj], sS1[jj]);
+        *(lds4p)(uintptr_t)(xw + (2 * jj) * 1024) = sS0[jj];
+        *(lds4p)(uintptr_t)(xw + (2 * jj + 1) * 1024) = sS1[jj];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) w24_out_rows(accK[jj * 4 + 0], accK[jj * 4 + 1], accK[jj * 4 + 2], accK[jj * 4 + 3], sK0[jj], sK1[jj]);
+    }
     __syncthreads();
-    f32x4 got[NLP];
+    f32x4 gs0[3], gs1[3];
 #pragma unroll
-    for (int lp = 0; lp < NLP; ++lp) got[lp] = *(lds4p)(uintptr_t)(xr + lp * 1024);
+    for (int jj = 0; jj < 3; ++jj) {
+      gs0[jj] = *(lds4p)(uintptr_t)(xr + (2 * jj) * 1024);
+      gs1[jj] = *(lds4p)(uintptr_t)(xr + (2 * jj + 1) * 1024);
+    }
     __syncthreads();             // (the next pair's transform overwrites the region)
 
-    // ---- output transform, 2x2 max-pool (commutes with the positive scale), un-scale + bias, ReLU, stores (conv1ab_wino24h.hip)
+    // ---- column stage, 2x2 max-pool (commutes with the positive scale), un-scale + bias, ReLU, stores (conv1ab_wino24h.hip)
     f32x4 y[2][4];
     {
-      f32x4 m[NPOS];
+      f32x4 s0[6], s1[6];
       if (ph == 0) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { m[j * 4 + 0] = accK[j * 2]; m[j * 4 + 1] = accK[j * 2 + 1]; m[j * 4 + 2] = got[j * 2]; m[j * 4 + 3] = got[j * 2 + 1]; }
+        for (int jj = 0; jj < 3; ++jj) { s0[jj] = sK0[jj]; s1[jj] = sK1[jj]; s0[3 + jj] = gs0[jj]; s1[3 + jj] = gs1[jj]; }
       } else {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { m[j * 4 + 0] = got[j * 2]; m[j * 4 + 1] = got[j * 2 + 1]; m[j * 4 + 2] = accK[j * 2]; m[j * 4 + 3] = accK[j * 2 + 1]; }
+        for (int jj = 0; jj < 3; ++jj) { s0[jj] = gs0[jj]; s1[jj] = gs1[jj]; s0[3 + jj] = sK0[jj]; s1[3 + jj] = sK1[jj]; }
       }
-      w24_output_transform(m, k8, y);
+      w24_out_cols(s0, s1, k8, y);
     }
     {
       const float inv = p.u_scale_inv / sv;

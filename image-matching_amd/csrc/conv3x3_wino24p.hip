@@ -11,16 +11,17 @@
 // instruction -- scalar address arithmetic and waits included -- costs its 4-5 issue cycles, and the transform and the epilogue are
 // 1.9 k and 2.3 k instructions per tile pair.  This kernel keeps two waves per SIMD AND the reuse:
 //   * workgroup = 8 waves = one PAIR of 8x16-pixel tiles x 64 output channels, one workgroup per CU; wave (cb, ph) owns channel
-//     block cb and the positions of transformed rows 2 ph, 2 ph + 1 (twelve of the 24) of BOTH tiles: 96 accumulators as before;
+//     block cb and the positions of transformed COLUMNS 3 ph .. 3 ph + 2 (twelve of the 24) of BOTH tiles: 96 accumulators as before;
 //   * its U fragment of a position meets the B operands of both tiles: 24 U loads per chunk and wave for 72 MFMAs (48 before), and a
 //     ring of six positions is now half of the wave's positions -- a refill has ~1.2 k cycles (six positions x six MFMAs x two
 //     waves) to arrive;
 //   * the input transform is split by (8-channel sub-patch, tile) over the eight waves: a wave reads each row of its sub-patch
 //     ONCE and produces all four transformed rows (the row-per-wave split of conv3x3_wino24h reads every row twice);
-//   * at the end of an item the two waves of a channel block exchange the accumulators of the tile they do not finish through LDS
-//     (12 KB each way, in the V region, which is free then) and each runs conv3x3_wino24h's epilogue on ITS tile with all 24
-//     positions: every output sees the arithmetic of conv3x3_wino24h in the same order -- the two kernels agree bit for bit
-//     (tests/test_gpu_superpoint.py), so every parity statement made for that kernel holds for this one;
+//   * at the end of an item each wave runs the ROW stage of the output transform on its three columns of both tiles, the two waves
+//     of a channel block exchange the six results of the tile they do not finish through LDS (6 KB each way, in the V region, which
+//     is free then; the first form exchanged the twelve accumulators) and each runs the column stage and the rest of
+//     conv3x3_wino24h's epilogue on ITS tile: every output sees the arithmetic of conv3x3_wino24h in the same order -- the two
+//     kernels agree bit for bit (tests/test_gpu_superpoint.py), so every parity statement made for that kernel holds for this one;
 //   * the per-image maxima and the bias come through the scalar cache (uniform addresses; as vector loads they were waited for with
 //     vmcnt(0) behind the U refills and the patch loads just issued); the V stores are plain ds_write2st64_b32 (ds_write_addtid_b32
 //     was tried: twice the rate, four instructions per store with its m0 write and wait state, no gain).
@@ -50,13 +51,13 @@ constexpr int RAWC = 192 * RSC;                // 180 pixels + pad, floats per 8
 constexpr int NSUB = 4;                        // 8-channel sub-patches per chunk
 constexpr int NG = 2;                          // tiles per workgroup
 constexpr int CKH = 32, NT = 64, NPOS = 24;
-constexpr int NLP = 12;                        // positions per wave: (j, e) -> position j*4 + 2 ph + e, local index j*2 + e
+constexpr int NLP = 12;                        // positions per wave: transformed COLUMNS 3 ph .. 3 ph + 2, all four rows = positions 12 ph + lp, lp = jj*4 + i
 constexpr int VPLANE = NPOS * 4 * 16 * 8;      // halves per plane of a tile (24576 bytes)
 constexpr int VGRP = 2 * VPLANE;               // halves per tile
 constexpr int UPOS = 2 * 4 * 64 * 8;           // halves of U per (item block, chunk, position): [plane][channel block][lane][8]
 constexpr int AMAX_SLOTS = 256;                // image b -> slot b % 256 (conv3x3_wino24h.hip)
 constexpr int RING = 6;                        // of the wave's twelve positions, in flight (NLP % RING == 0)
-constexpr int XCH = NLP * 64 * 16;             // bytes of one wave's accumulator exchange block
+constexpr int XCH = 6 * 64 * 16;               // bytes of one wave's exchange block: the row stage's six results for the partner's tile
 constexpr unsigned OOB = 0x7ffffff0u;          // byte offset beyond any image: buffer loads return 0
 #ifdef P_TRACE
 // phase clocks (tools/ubench/conv_h_bench.cpp, -DP_TRACE): cycles of wave 0 of every 16th workgroup in each phase of chunk_step
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cb = wave_s & 3, ph = wave_s >> 2;         // matrix role: channel block, position half (transformed rows 2 ph, 2 ph + 1)
+  const int cb = wave_s & 3, ph = wave_s >> 2;         // matrix role: channel block, position half (transformed columns 3 ph .. 3 ph + 2)
   const int tq = wave_s & 3, tg = wave_s >> 2;         // transform / loader / epilogue role: 8-channel sub-patch, tile (tg == ph)
   const int H = p.H, W = p.W, Cin = p.Cin, Cout = p.Cout;
   const int nchunk = Cin / CKH, ncob = Cout / NT;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
   if (ph == P_PRIO - 1) __builtin_amdgcn_s_setprio(2);      // experiment: the issue arbiter favours the older four waves
 #endif
   const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)p.wuh, 0, ncob * nchunk * NPOS * UPOS * 2, 0x00020000);
-  const int uoff_lane = (cb * 64 + lane) * 16 + ph * 2 * (UPOS * 2);           // bytes: plane 0 of position 2 ph of a (block, chunk)
+  const int uoff_lane = (cb * 64 + lane) * 16 + ph * NLP * (UPOS * 2);         // bytes: plane 0 of position 12 ph of a (block, chunk)
   const int img_bytes = H * W * Cin * 4;
   typedef const unsigned __attribute__((address_space(4)))* cu32p;
   typedef const float __attribute__((address_space(4)))* cf32p;
@@ -139,12 +140,12 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
 
   // B-operand reads: lane = (wtile n = lane & 15, group kg = lane >> 4) -> 16 bytes at position * 1024 + lane * 16 of a plane.  One
   // opaque base per tile (the second tile's planes lie beyond the 64 KB an LDS offset field reaches from the first tile's base:
-  // hipcc would materialise an address register per position), the wave's 2 ph folded in; K = the tile this wave finishes (tile
+  // hipcc would materialise an address register per position), the wave's 12 ph folded in; K = the tile this wave finishes (tile
   // ph), S = the tile whose accumulators it sends to its partner
   const _Float16 *vrdK, *vrdS;
   {
-    unsigned a = lds0 + (unsigned)(ph * (VGRP * 2) + ph * 2 * 1024 + lane * 16);
-    unsigned b = lds0 + (unsigned)((1 - ph) * (VGRP * 2) + ph * 2 * 1024 + lane * 16);
+    unsigned a = lds0 + (unsigned)(ph * (VGRP * 2) + ph * NLP * 1024 + lane * 16);
+    unsigned b = lds0 + (unsigned)((1 - ph) * (VGRP * 2) + ph * NLP * 1024 + lane * 16);
     asm volatile("" : "+v"(a), "+v"(b));
     vrdK = (const _Float16*)((__attribute__((address_space(3))) unsigned char*)(uintptr_t)a);
     vrdS = (const _Float16*)((__attribute__((address_space(3))) unsigned char*)(uintptr_t)b);
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
   // ---- U ring: slot lp % RING holds local position lp's two planes (eight halves each per lane)
   u32x4 ub[RING][2];
   auto u_load = [&](int slot, int cobv, int chv, int lp) __attribute__((always_inline)) {
-    const int pos = (lp >> 1) * 4 + (lp & 1);                                      // (+ 2 ph: in uoff_lane)
+    const int pos = lp;                                                            // (+ 12 ph: in uoff_lane)
     const int so = __builtin_amdgcn_readfirstlane(((cobv * nchunk + chv) * NPOS + pos) * (UPOS * 2));
     ub[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(ur, uoff_lane, so, 0);
     ub[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(ur, uoff_lane, so + 4 * 64 * 16, 0);
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
     // once per position -- ~270 cycles per position and wave against 96 of MFMAs: the trace of the first build)
     f16x8 bq[2][4];              // [buffer][K h, K m, S h, S m]
     auto b_load = [&](int buf, int lp) __attribute__((always_inline)) {
-      const int po = ((lp >> 1) * 4 + (lp & 1)) * 512;       // halves (the wave's 2 ph sits in the bases)
+      const int po = lp * 512;                               // halves (the wave's 12 ph sits in the bases)
       bq[buf][0] = *reinterpret_cast<const f16x8*>(vrdK + po);
       bq[buf][1] = *reinterpret_cast<const f16x8*>(vrdK + VPLANE + po);
       bq[buf][2] = *reinterpret_cast<const f16x8*>(vrdS + po);
@@ -411,29 +412,47 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
     const float inv = p.u_scale_inv * v_scale_inv(amax_c[tl.b & (AMAX_SLOTS - 1)]);
 
 
+    // The output transform's ROW stage (s0[j] = m0j + m1j + m2j, s1[j] = m1j - m2j - m3j: down the four rows of a transformed column)
+    // needs one column's four accumulators -- which one wave holds, for both tiles.  It runs here, before the exchange, on this
+    // wave's three columns of both tiles; the six results for the PARTNER's tile go through LDS (half of the twelve accumulators that
+    // went before round 5's second form), the partner's six for this wave's tile come back, and the column stage runs on all six
+    // columns: the instructions of conv3x3_wino24h's output transform on the same values -- bit-identical.
     const unsigned xw = lds0 + (unsigned)(wave_s * XCH + lq * 16), xr = lds0 + (unsigned)((wave_s ^ 4) * XCH + lq * 16);
+    f32x4 sK0[3], sK1[3];
+    {
+      f32x4 sS0[3], sS1[3];
 #pragma unroll
-    for (int lp = 0; lp < NLP; ++lp) *(lds4p)(uintptr_t)(xw + lp * 1024) = accS[lp];
+      for (int jj = 0; jj < 3; ++jj) {
+        w24_out_rows(accS[jj * 4 + 0], accS[jj * 4 + 1], accS[jj * 4 + 2], accS[jj * 4 + 3], sS0[jj], sS1[jj]);
+        *(lds4p)(uintptr_t)(xw + (2 * jj) * 1024) = sS0[jj];
+        *(lds4p)(uintptr_t)(xw + (2 * jj + 1) * 1024) = sS1[jj];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) w24_out_rows(accK[jj * 4 + 0], accK[jj * 4 + 1], accK[jj * 4 + 2], accK[jj * 4 + 3], sK0[jj], sK1[jj]);
+    }
     __syncthreads();
-    f32x4 got[NLP];
+    f32x4 gs0[3], gs1[3];
 #pragma unroll
-    for (int lp = 0; lp < NLP; ++lp) got[lp] = *(lds4p)(uintptr_t)(xr + lp * 1024);
+    for (int jj = 0; jj < 3; ++jj) {
+      gs0[jj] = *(lds4p)(uintptr_t)(xr + (2 * jj) * 1024);
+      gs1[jj] = *(lds4p)(uintptr_t)(xr + (2 * jj + 1) * 1024);
+    }
     __syncthreads();               // (the next transform overwrites the region)
     P_STAMP(6)
 
-    // ---- output transform, un-scale + bias, ReLU, (2x2 max-pool), stores straight from registers (conv3x3_wino24h.hip); position
-    // j*4 + i: rows 2 ph, 2 ph + 1 are this wave's, the other two the partner's
+    // ---- column stage, un-scale + bias, ReLU, (2x2 max-pool), stores straight from registers (conv3x3_wino24h.hip); columns
+    // 3 ph .. 3 ph + 2 are this wave's, the other three the partner's
     f32x4 y[2][4];
     {
-      f32x4 m[NPOS];
+      f32x4 s0[6], s1[6];
       if (ph == 0) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { m[j * 4 + 0] = accK[j * 2]; m[j * 4 + 1] = accK[j * 2 + 1]; m[j * 4 + 2] = got[j * 2]; m[j * 4 + 3] = got[j * 2 + 1]; }
+        for (int jj = 0; jj < 3; ++jj) { s0[jj] = sK0[jj]; s1[jj] = sK1[jj]; s0[3 + jj] = gs0[jj]; s1[3 + jj] = gs1[jj]; }
       } else {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { m[j * 4 + 0] = got[j * 2]; m[j * 4 + 1] = got[j * 2 + 1]; m[j * 4 + 2] = accK[j * 2]; m[j * 4 + 3] = accK[j * 2 + 1]; }
+        for (int jj = 0; jj < 3; ++jj) { s0[jj] = gs0[jj]; s1[jj] = gs1[jj]; s0[3 + jj] = sK0[jj]; s1[3 + jj] = sK1[jj]; }
       }
-      w24_output_transform(m, k8, y);
+      w24_out_cols(s0, s1, k8, y);
     }
     P_STAMP(7)
     {

@@ -48,32 +48,39 @@ __device__ __forceinline__ w24_f32x2 w24_hi(w24_f32x4 v) { return __builtin_shuf
 //   along the columns y[r][0] = s0 + (s1+s2) + (s3+s4)      y[r][1] = (s1-s2) + 2 (s3-s4)
 //                     y[r][2] = (s1+s2) + 4 (s3+s4)         y[r][3] = (s1-s2) + 8 (s3-s4) + s5
 // 2 x (24 + 20) = 88 packed instructions for the 8 x 4 outputs of the lane.
-__device__ __forceinline__ void w24_output_transform(const w24_f32x4 (&m)[24], w24_f32x2 k8, w24_f32x4 (&y)[2][4]) {
+// (in two stages, so that the pair kernels can run the row stage where the accumulators are and exchange its results -- half the
+// registers -- between the two waves that share a tile: the same instructions on the same values either way)
+__device__ __forceinline__ void w24_out_rows(const w24_f32x4& m0, const w24_f32x4& m1, const w24_f32x4& m2, const w24_f32x4& m3, w24_f32x4& s0, w24_f32x4& s1) {
+  const w24_f32x2 s0l = pk_add(pk_add(w24_lo(m0), w24_lo(m1)), w24_lo(m2)), s1l = pk_sub(pk_sub(w24_lo(m1), w24_lo(m2)), w24_lo(m3));
+  const w24_f32x2 s0h = pk_add(pk_add(w24_hi(m0), w24_hi(m1)), w24_hi(m2)), s1h = pk_sub(pk_sub(w24_hi(m1), w24_hi(m2)), w24_hi(m3));
+  s0 = __builtin_shufflevector(s0l, s0h, 0, 1, 2, 3);
+  s1 = __builtin_shufflevector(s1l, s1h, 0, 1, 2, 3);
+}
+__device__ __forceinline__ void w24_out_cols(const w24_f32x4 (&s0)[6], const w24_f32x4 (&s1)[6], w24_f32x2 k8, w24_f32x4 (&y)[2][4]) {
   w24_f32x2 out[2][4][2];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {                  // channel pair: registers 0-1 / 2-3 of every accumulator
-    w24_f32x2 s0[6], s1[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const w24_f32x2 a0 = h ? w24_hi(m[j * 4 + 0]) : w24_lo(m[j * 4 + 0]), a1 = h ? w24_hi(m[j * 4 + 1]) : w24_lo(m[j * 4 + 1]);
-      const w24_f32x2 a2 = h ? w24_hi(m[j * 4 + 2]) : w24_lo(m[j * 4 + 2]), a3 = h ? w24_hi(m[j * 4 + 3]) : w24_lo(m[j * 4 + 3]);
-      s0[j] = pk_add(pk_add(a0, a1), a2);
-      s1[j] = pk_sub(pk_sub(a1, a2), a3);
-    }
+  for (int h = 0; h < 2; ++h)                    // channel pair: registers 0-1 / 2-3
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const w24_f32x2* s = r ? s1 : s0;
+      w24_f32x2 s[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) s[j] = h ? w24_hi(r ? s1[j] : s0[j]) : w24_lo(r ? s1[j] : s0[j]);
       const w24_f32x2 a12 = pk_add(s[1], s[2]), b12 = pk_sub(s[1], s[2]), c34 = pk_add(s[3], s[4]), d34 = pk_sub(s[3], s[4]);
       out[r][0][h] = pk_add(pk_add(s[0], a12), c34);
       out[r][1][h] = pk_fma_p2(d34, b12);
       out[r][2][h] = pk_fma_p4(c34, a12);
       out[r][3][h] = pk_add(pk_fma(d34, k8, b12), s[5]);
     }
-  }
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
     for (int x = 0; x < 4; ++x) y[r][x] = __builtin_shufflevector(out[r][x][0], out[r][x][1], 0, 1, 2, 3);
+}
+__device__ __forceinline__ void w24_output_transform(const w24_f32x4 (&m)[24], w24_f32x2 k8, w24_f32x4 (&y)[2][4]) {
+  w24_f32x4 s0[6], s1[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) w24_out_rows(m[j * 4 + 0], m[j * 4 + 1], m[j * 4 + 2], m[j * 4 + 3], s0[j], s1[j]);
+  w24_out_cols(s0, s1, k8, y);
 }
 
 // B4^T of F(4,3) on six values o[0..5] (one transformed row of the patch), in two batches of six instructions:
