@@ -105,7 +105,7 @@ __device__ __forceinline__ float v_scale_inv(unsigned amax_bits) {
   return __builtin_bit_cast(float, (e - 8u) << 23);
 }
 
-template <bool POOL, bool RELU, bool FASTW>
+template <bool POOL, bool RELU, bool FASTW, bool INZ>
 __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, int tiles_y, int ntiles, int nitems) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
   float* raw = reinterpret_cast<float*>(smem_p + NG * VGRP * 2);               // [NG][NSUB][RAWC]   (V [NG][2][VPLANE] halves sits at 0)
@@ -161,9 +161,33 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
     px_ = px % RW - 1;
     return px * RSC + half * 4;
   };
-  int ldst[2];
+  // Tile-swizzled input (in_blocked == 2; round 5): the producer (this kernel, out_blocked == 2) wrote the tensor as
+  // [image][tile row][tile column][16-channel block][r][x][channel quarter][wtile][4] -- its accumulators' own lane order, 1 KB per store
+  // instruction -- so a tile's 32 channels of a chunk are 16 KB contiguous: thread t takes the float4 t, t + 256, t + 512, t + 768 of
+  // them (pixel (2 wr + r, 4 wc + x): x = t >> 6, r = k & 1, block k >> 1) and up to two of the 52 x 8 float4 of the one-pixel halo
+  // from the neighbouring tiles.
+  constexpr bool inz = INZ;                  // (a template parameter: with both loaders in one kernel their state cost 16 spilled registers)
+  auto halo_slot = [&](int t, int j, int& py, int& px_, int& piece) __attribute__((always_inline)) -> bool {
+    const int hh = t + 256 * j, hp = hh >> 3;
+    piece = hh & 7;
+    py = hp < 18 ? 0 : hp < 36 ? RH - 1 : hp < 44 ? hp - 35 : hp - 43;
+    px_ = hp < 18 ? hp : hp < 36 ? hp - 18 : hp < 44 ? 0 : RW - 1;
+    return hh < 52 * 8;
+  };
+  int ldst[2], ldmain = 0;
+  if constexpr (inz) {
+    const int t = tid & 255, n = t & 15, kq = (t >> 4) & 3, x = t >> 6;
+    ldmain = tg * NSUB * RAWC + (kq >> 1) * RAWC + ((1 + 2 * (n >> 2)) * RW + 1 + 4 * (n & 3) + x) * RSC + (kq & 1) * 4;
 #pragma unroll
-  for (int k = 0; k < 2; ++k) { int a, b, c; ldst[k] = tg * NSUB * RAWC + loader_slot(tid & 255, k, a, b, c); }
+    for (int j = 0; j < 2; ++j) {
+      int py, px, piece;
+      halo_slot(t, j, py, px, piece);
+      ldst[j] = tg * NSUB * RAWC + ((piece >> 2) * 2 + ((piece & 3) >> 1)) * RAWC + (py * RW + px) * RSC + (piece & 1) * 4;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { int a, b, c; ldst[k] = tg * NSUB * RAWC + loader_slot(tid & 255, k, a, b, c); }
+  }
   // an item = (pair of consecutive tiles, 64-channel output block); a wave only ever needs ITS tile of the pair.  Items vb + k grid:
   // the host makes grid a multiple of ncob whenever a workgroup has more than one item, so the output block is fixed (vb % ncob) and
   // the tile advances by dt = NG grid / ncob per item -- stepped with carries (three divisions per item and wave, plus the loader's
@@ -190,8 +214,10 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
   };
   int item_c = vb, lchunk = 0;
   __amdgpu_buffer_rsrc_t lrs;
-  unsigned goff[2];
+  unsigned goff[2], gmain = 0, mmask = 0xfu;                      // (swizzled input: the halo slots, the tile's own block, its rows' validity)
   float lsv;                                                      // s_v of the loader's tile
+  const int nblk_in = Cin / 16;                                   // swizzled input: 16-channel blocks of 8 KB per tile
+  const int zimg = tiles_x * tiles_y * nblk_in * 8192;            // bytes per image
   const bool inb = p.in_blocked != 0;
   const int pxb = inb ? 8 * 4 : Cin * 4;                          // bytes from one pixel to the next
   const int sub_step = inb ? H * W * 8 * 4 : 8 * 4;               // bytes from one 8-channel group to the next
@@ -202,8 +228,27 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
     for (int k = 0; k < 2; ++k) loader_slot(t8, k, lpy[k], lpx[k], lhalf[k]);
     const bool lv = t.live != 0;
     const int b = __builtin_amdgcn_readfirstlane(lv ? t.b : 0);
-    lrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)b * H * W * Cin), 0, lv ? img_bytes : 0, 0x00020000);
     lsv = v_scale(amax_c[b & (AMAX_SLOTS - 1)]);
+    if constexpr (inz) {
+      lrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)b * (zimg >> 2)), 0, lv ? zimg : 0, 0x00020000);
+      const int n = t8 & 15, x = t8 >> 6;
+      gmain = (unsigned)((t.y0 * tiles_x + t.x0) * nblk_in * 8192 + t8 * 16);
+      const bool xin = t.x0 * OW + 4 * (n & 3) + x < W;
+      const int gy0 = t.y0 * OH + 2 * (n >> 2);
+      mmask = ((xin && gy0 < H) ? 5u : 0u) | ((xin && gy0 + 1 < H) ? 10u : 0u);        // bit k: slot k (row r = k & 1) lies inside the image
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int py, px, piece;
+        const bool used = halo_slot(t8, j, py, px, piece);
+        const int gy = t.y0 * OH - 1 + py, gx = t.x0 * OW - 1 + px;
+        const bool in = (int)used & (int)lv & (int)((unsigned)gy < (unsigned)H) & (int)((unsigned)gx < (unsigned)W);
+        goff[j] = in ? (unsigned)((((gy >> 3) * tiles_x + (gx >> 4)) * nblk_in + (piece >> 2)) * 8192 + ((gy & 1) * 4 + (gx & 3)) * 1024 + (piece & 3) * 256 +
+                                  (((gy & 7) >> 1) * 4 + ((gx & 15) >> 2)) * 16)
+                     : OOB;
+      }
+      return;
+    }
+    lrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)b * H * W * Cin), 0, lv ? img_bytes : 0, 0x00020000);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int gy = t.y0 * OH + lpy[k], gx = t.x0 * OW + lpx[k];
@@ -213,7 +258,18 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
   };
   f32x4 rr[NSUB][2];
   float rr_sv = 1.f;                                              // the scale that goes with the registers' chunk
+  unsigned rr_mask = 0xfu;                                        // (swizzled input: the validity bits that go with it)
   auto issue_load = [&]() __attribute__((always_inline)) {
+    if constexpr (inz) {                                          // rr[k][0]: the tile's own block, slot k; rr[j][1]: the halo slots
+      const int so = __builtin_amdgcn_readfirstlane(lchunk * 2 * 8192);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rr[k][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)gmain, so + k * 4096, 0));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) rr[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)goff[j], so, 0));
+      rr_sv = lsv;
+      rr_mask = mmask;
+      return;
+    }
     const int so = __builtin_amdgcn_readfirstlane(lchunk * NSUB * sub_step);
 #pragma unroll
     for (int q = 0; q < NSUB; ++q) {
@@ -234,6 +290,26 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
   };
   auto store_raw = [&]() __attribute__((always_inline)) {
     const f32x4 s4 = {rr_sv, rr_sv, rr_sv, rr_sv};
+    if constexpr (inz) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {                               // (pixels of the padded tile outside the image hold the producer's values: zero here)
+        const float mk = (rr_mask >> k) & 1u ? 1.f : 0.f;
+        const f32x4 v = rr[k][0] * s4 * (f32x4){mk, mk, mk, mk};
+        float* d = raw + ldmain + (k & 1) * (RW * RSC) + (k >> 1) * (2 * RAWC);
+        *reinterpret_cast<f32x2*>(d) = (f32x2){v[0], v[1]};
+        *reinterpret_cast<f32x2*>(d + 2) = (f32x2){v[2], v[3]};
+      }
+      const int t8 = (wave_s & 3) * 64 + lane_now();
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (t8 + 256 * j < 52 * 8) {
+          const f32x4 v = rr[j][1] * s4;
+          float* d = raw + ldst[j];
+          *reinterpret_cast<f32x2*>(d) = (f32x2){v[0], v[1]};
+          *reinterpret_cast<f32x2*>(d + 2) = (f32x2){v[2], v[3]};
+        }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < NSUB; ++q)
 #pragma unroll
@@ -466,8 +542,17 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
                                                        (outb ? cob * (NT / 8) * (Ho * Wo * 8 * 4) : cob * NT * 4));
       const int fbase = fastw ? ibase : 0;
       // a dead tile (the odd tile out at the end of the grid) stores through an empty descriptor
-      const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)tl.b * Ho * Wo * Cout + (fbase >> 2)), 0,
-                                                                           tl.live ? Ho * Wo * Cout * 4 - fbase : 0, 0x00020000);
+      // Tile-swizzled output (out_blocked == 2, layers without a pool whose consumer is this kernel too; round 5): the accumulators'
+      // own lane order -- [image][tile][16-channel block][r][x][channel quarter = lane >> 4][wtile = lane & 15][4] -- so that a store
+      // instruction's 64 lanes write 1 KB contiguous: 16 cycles of the CU's store unit instead of the 56 it takes for 64 separate
+      // 16-byte pieces (tools/ubench/store_rate.hip; with a pixel-major layout the pieces are four pixels apart).  Whole padded tiles
+      // are written: the consumer's loader zeroes what lies outside the image.
+      const bool outz = !POOL && p.out_blocked == 2;
+      const int zbase = outz ? __builtin_amdgcn_readfirstlane((((tl.y0 / OH) * tiles_x + tl.x0 / OW) * (Cout / 16) + cob * 4 + cb) * 8192) : 0;
+      const size_t zimg_out = (size_t)tiles_x * tiles_y * (Cout / 16) * 2048;        // floats per image
+      const __amdgpu_buffer_rsrc_t ors =
+          outz ? __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)tl.b * zimg_out + (zbase >> 2)), 0, tl.live ? 8192 : 0, 0x00020000)
+               : __builtin_amdgcn_make_buffer_rsrc((void*)(p.out + (size_t)tl.b * Ho * Wo * Cout + (fbase >> 2)), 0, tl.live ? Ho * Wo * Cout * 4 - fbase : 0, 0x00020000);
       auto note = [&](const f32x4& v) __attribute__((always_inline)) {
         const float mm = RELU ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) : fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
         amax_run = max(amax_run, __builtin_bit_cast(unsigned, mm));
@@ -495,7 +580,7 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
             note(v);
             const int oy = tl.y0 + 2 * lwr + r, ox = tl.x0 + 4 * lwc + x;
             const int so_ = ((2 * lwr + r) * Wo + 4 * lwc + x) * opx + chl;
-            const unsigned off = fastw ? (unsigned)so_ : (oy < Ho && ox < Wo) ? (unsigned)(so_ + ibase) : OOB;
+            const unsigned off = outz ? (unsigned)((r * 4 + x) * 1024 + lq * 16) : fastw ? (unsigned)so_ : (oy < Ho && ox < Wo) ? (unsigned)(so_ + ibase) : OOB;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(su32x4, v), ors, (int)off, 0, 0);
           }
       }
@@ -538,8 +623,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
 #endif
 }
 
-template <bool POOL, bool RELU, bool FASTW>
-hipError_t launch_p(const ConvArgs& a, hipStream_t s) {
+template <bool POOL, bool RELU, bool FASTW, bool INZ>
+hipError_t launch_p2(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = (a.W + OW - 1) / OW, tiles_y = (a.H + OH - 1) / OH;
   const int ntiles = tiles_x * tiles_y * a.B;
   const int nitems = ((ntiles + NG - 1) / NG) * (a.Cout / NT);
@@ -551,7 +636,7 @@ hipError_t launch_p(const ConvArgs& a, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
     ncu = prop.multiProcessorCount;
   }
-  auto k = conv3x3_wino24p<POOL, RELU, FASTW>;
+  auto k = conv3x3_wino24p<POOL, RELU, FASTW, INZ>;
   static unsigned long long attr = 0;
   raise_lds_limit(reinterpret_cast<const void*>(k), (int)lds, attr);
   const int ncob = a.Cout / NT;
@@ -560,6 +645,10 @@ hipError_t launch_p(const ConvArgs& a, hipStream_t s) {
   last_form = "conv3x3_wino24p:f16x2";
   hipLaunchKernelGGL(k, grid, dim3(512), lds, s, a, tiles_x, tiles_y, ntiles, nitems);
   return hipGetLastError();
+}
+template <bool POOL, bool RELU, bool FASTW>
+hipError_t launch_p(const ConvArgs& a, hipStream_t s) {
+  return a.in_blocked == 2 ? launch_p2<POOL, RELU, FASTW, true>(a, s) : launch_p2<POOL, RELU, FASTW, false>(a, s);
 }
 }  // namespace
 

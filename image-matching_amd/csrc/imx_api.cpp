@@ -628,11 +628,13 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   const int d = c.descriptor_dim;
   const size_t f = sizeof(float);
   WS(a1, float, "sp.a1", (size_t)B * H2 * W2 * 64 * f);
-  WS(a2a, float, "sp.a2a", (size_t)B * H2 * W2 * 64 * f);
+  // (a2a / a3a / a4a may be written tile-swizzled -- whole 8 x 16-pixel tiles, conv3x3_wino24p.hip: sized for the padded tile grid)
+  auto padded = [](int hh, int ww) { return (size_t)((hh + 7) / 8 * 8) * ((ww + 15) / 16 * 16); };
+  WS(a2a, float, "sp.a2a", (size_t)B * padded(H2, W2) * 64 * f);
   WS(a2, float, "sp.a2", (size_t)B * H4 * W4 * 64 * f);
-  WS(a3a, float, "sp.a3a", (size_t)B * H4 * W4 * 128 * f);
+  WS(a3a, float, "sp.a3a", (size_t)B * padded(H4, W4) * 128 * f);
   WS(a3, float, "sp.a3", (size_t)B * Hc * Wc * 128 * f);
-  WS(a4a, float, "sp.a4a", (size_t)B * Hc * Wc * 128 * f);
+  WS(a4a, float, "sp.a4a", (size_t)B * padded(Hc, Wc) * 128 * f);
   WS(x4, float, "sp.x4", (size_t)B * Hc * Wc * 128 * f);
   WS(hd, float, "sp.heads", (size_t)B * Hc * Wc * 512 * f);
   WS(semi, float, "sp.semi", (size_t)B * Hc * Wc * 65 * f);
@@ -676,12 +678,31 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
     amax = am;
   }
   int layer = 0;
+  // conv2a -> conv2b, conv3a -> conv3b, conv4a -> conv4b: the tensor between them is tile-swizzled (ConvArgs::out_blocked / in_blocked
+  // = 2) when BOTH layers run the pair kernel on this slice -- its stores are then 1 KB contiguous per instruction
+  // (conv3x3_wino24p.hip).  IMX_CONV_SWZ=0: never (the A/B switch of tools and tests; the results are bit-identical either way).
+  const char* swz_env = getenv("IMX_CONV_SWZ");
+  const bool swz_on = !(swz_env && swz_env[0] == '0');
+  auto swz_pair = [&](int li_prod, int hh, int ww, int nb) -> bool {
+    if (!amax || !swz_on || h->opt.conv_f16 != 1 || (li_prod != 1 && li_prod != 3 && li_prod != 5)) return false;
+    for (int k = 0; k < 2; ++k) {
+      const ConvW& cw = h->conv[li_prod + k];
+      ConvArgs t{};
+      t.B = nb; t.H = hh; t.W = ww; t.Cin = cw.cin; t.Cout = cw.cout; t.pool = (k == 1 && li_prod != 5) ? 1 : 0; t.relu = 1;
+      t.wu24 = cw.wu24; t.wuh = cw.wuh; t.u_scale_inv = cw.su_inv; t.amax_in = amax;
+      if (!conv3x3_wino24p_preferred(t)) return false;
+    }
+    return true;
+  };
   auto conv = [&](const char* name, const ConvW& w, const float* in, float* out, int hh, int ww, bool pool, bool first, bool last = false) -> int {
     const int li = layer++;
-    const size_t in_img = (size_t)hh * ww * (first ? 1 : w.cin), out_img = (size_t)(pool ? hh / 2 : hh) * (pool ? ww / 2 : ww) * w.cout;
     for (int sl = 0; sl < (amax ? nslice : 1); ++sl) {
     ConvArgs a{};
     const int b0 = amax ? sl * kSlice : 0, nb = amax ? std::min(kSlice, B - b0) : B;
+    const bool in_z = !first && swz_pair(li - 1, hh, ww, nb), out_z = !first && !pool && !last && swz_pair(li, hh, ww, nb);
+    const size_t ztile = (size_t)((hh + 7) / 8) * ((ww + 15) / 16) * 2048;       // floats per image and 16-channel block of a swizzled tensor
+    const size_t in_img = in_z ? ztile * (w.cin / 16) : (size_t)hh * ww * (first ? 1 : w.cin);
+    const size_t out_img = out_z ? ztile * (w.cout / 16) : (size_t)(pool ? hh / 2 : hh) * (pool ? ww / 2 : ww) * w.cout;
     if (amax) {
       unsigned* am = amax + (size_t)sl * 8 * 256;
       a.amax_out = last ? nullptr : am + (size_t)li * 256;
@@ -689,8 +710,8 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
       a.wuh = w.wuh; a.u_scale_inv = w.su_inv;
       a.c1a_l1 = h->c1a_l1; a.c1a_bmax = h->c1a_bmax;
     }
-    a.in_blocked = (blocked && !first) ? 1 : 0;
-    a.out_blocked = (blocked && !last) ? 1 : 0;
+    a.in_blocked = in_z ? 2 : (blocked && !first) ? 1 : 0;
+    a.out_blocked = out_z ? 2 : (blocked && !last) ? 1 : 0;
     if (first) {                       // images below `split` come from img0, the others from img1: the slice's view of that
       if (b0 >= split) { a.in = img1 + (size_t)(b0 - split) * in_img; a.in2 = nullptr; a.split = nb; }
       else { a.in = in + (size_t)b0 * in_img; a.in2 = img1; a.split = split - b0; }
@@ -708,6 +729,7 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
     // fragment serves two tiles), one tile per workgroup otherwise ("conv" = "wino_h": always) -- the same arithmetic, bit for bit
     const bool winop = winoh && h->opt.conv_f16 == 1 && conv3x3_wino24p_preferred(a);
     const bool fused1p = fused1h && h->opt.conv_f16 == 1 && conv1ab_wino24p_preferred(a);
+    if ((in_z || out_z) && !winop) return fail(h, "%s: a tile-swizzled tensor needs the pair kernel on both sides (internal)", name);
     RUN(name, fused1p ? launch_conv1ab_wino24p(a, s) : fused1h ? launch_conv1ab_wino24h(a, s) : fused1 ? launch_conv1ab_wino24(a, s) : winop ? launch_conv3x3_wino24p(a, s) : winoh ? launch_conv3x3_wino24h(a, s) :
               wino ? launch_conv3x3_wino24(a, s) : launch_conv3x3(a, s));
     }

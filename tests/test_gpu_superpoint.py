@@ -285,13 +285,16 @@ def test_an_image_of_a_260_image_batch_equals_the_same_image_alone():
 
 
 @pytest.mark.parametrize("H,W,B", [(120, 160, 24), (80, 96, 35), (123, 165, 40)])
-def test_tile_pair_winograd_form_is_bit_identical_to_the_tile_per_workgroup_form(H, W, B):
+def test_tile_pair_winograd_form_is_bit_identical_to_the_tile_per_workgroup_form(H, W, B, monkeypatch):
     """Round 5: conv3x3_wino24p.hip runs the fp16-plane Winograd layers on PAIRS of tiles, the 24 positions split over two waves whose
     accumulators meet through LDS before conv3x3_wino24h's epilogue -- chosen per layer where there is at least one item per CU
     ("conv" = "wino"), the tile-per-workgroup kernel otherwise ("conv" = "wino_h": always).  Every output of the pair form sees
     conv3x3_wino24h's arithmetic in the same order, so the two settings must agree BIT FOR BIT on semi and the descriptors -- which
     carries every parity statement made for conv3x3_wino24h over to the pair form.  Shapes: whole tiles; 80x96 with 35 images (an odd
-    number of tiles at the second level: the last pair has a dead tile); ragged 123x165 (partial tiles, masked stores)."""
+    number of tiles at the second level: the last pair has a dead tile); ragged 123x165 (partial tiles, masked stores).
+    Between two pair-form layers without a pool between them (conv2a -> conv2b, ...) the tensor is TILE-SWIZZLED (the accumulators' own
+    lane order, 1 KB per store instruction; whole padded tiles, the consumer zeroes what lies outside the image): pure data movement, so
+    the same bits again -- also against IMX_CONV_SWZ=0, which keeps the pixel-major blocked layout."""
     from image_matching_amd import _lib as L
     from image_matching_amd.engine import Engine
     d = 128
@@ -299,9 +302,13 @@ def test_tile_pair_winograd_form_is_bit_identical_to_the_tile_per_workgroup_form
     eng.load_state_dict(L.NET_SUPERPOINT, util.sp_sd(d))
     xs = torch.cat([util.pair(700 + i, H, W)[i & 1] * (1.0 + (i % 5)) for i in range(B)]).cuda()
     got = {}
-    for mode in ("wino_h", "wino"):
-        eng.set_option("conv", mode)
-        assert eng.get_option("conv") == mode
+    for mode in ("wino_h", "wino", "wino/blocked"):
+        if mode == "wino/blocked":
+            monkeypatch.setenv("IMX_CONV_SWZ", "0")
+        else:
+            monkeypatch.delenv("IMX_CONV_SWZ", raising=False)
+        eng.set_option("conv", mode.split("/")[0])
+        assert eng.get_option("conv") == mode.split("/")[0]
         eng.timing_reset()
         eng.set_timing(True)
         semi, desc = eng.superpoint_dense(xs)
@@ -316,6 +323,7 @@ def test_tile_pair_winograd_form_is_bit_identical_to_the_tile_per_workgroup_form
     assert all(fp[k] in ("conv3x3_wino24p:f16x2", "conv3x3_wino24h:f16x2") for k in layers), fp
     assert torch.equal(got["wino"][0], got["wino_h"][0]), "semi differs between the pair form and the tile-per-workgroup form"
     assert torch.equal(got["wino"][1], got["wino_h"][1]), "descriptors differ between the pair form and the tile-per-workgroup form"
+    assert torch.equal(got["wino"][0], got["wino/blocked"][0]) and torch.equal(got["wino"][1], got["wino/blocked"][1]), "tile-swizzled vs blocked tensors between the pair-form layers"
     assert torch.isfinite(got["wino"][0]).all()
 
 
