@@ -701,8 +701,12 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
     const int b0 = amax ? sl * kSlice : 0, nb = amax ? std::min(kSlice, B - b0) : B;
     const bool in_z = !first && swz_pair(li - 1, hh, ww, nb), out_z = !first && !pool && !last && swz_pair(li, hh, ww, nb);
     const size_t ztile = (size_t)((hh + 7) / 8) * ((ww + 15) / 16) * 2048;       // floats per image and 16-channel block of a swizzled tensor
-    const size_t in_img = in_z ? ztile * (w.cin / 16) : (size_t)hh * ww * (first ? 1 : w.cin);
-    const size_t out_img = out_z ? ztile * (w.cout / 16) : (size_t)(pool ? hh / 2 : hh) * (pool ? ww / 2 : ww) * w.cout;
+    // (a slice's images are packed with their layout's own size; the SLICES of a tensor that may be swizzled are spaced by the padded
+    // size whatever each slice's layout is -- a short last slice can fall back to the blocked layout, and its region must not start
+    // inside the region of the slice before it)
+    const bool in_cand = li == 2 || li == 4 || li == 6, out_cand = li == 1 || li == 3 || li == 5;
+    const size_t in_img = in_cand ? ztile * (w.cin / 16) : (size_t)hh * ww * (first ? 1 : w.cin);
+    const size_t out_img = out_cand ? ztile * (w.cout / 16) : (size_t)(pool ? hh / 2 : hh) * (pool ? ww / 2 : ww) * w.cout;
     if (amax) {
       unsigned* am = amax + (size_t)sl * 8 * 256;
       a.amax_out = last ? nullptr : am + (size_t)li * 256;
