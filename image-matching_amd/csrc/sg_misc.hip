@@ -172,7 +172,11 @@ __global__ __launch_bounds__(1024) void sinkhorn_cols(SinkhornArgs a) {
 // as many workgroups resident per CU to cover each other's load latency and barriers.
 // Round 5: a workgroup walks G consecutive slabs and merges their column partials in registers before writing them: the partials
 // were 2 x 68 MB of an iteration's traffic at C3 (written here, read by sinkhorn_vmerge) beside the 268 MB of S.
-template <int R, int NW, int G>
+// PF (round 5, IMX_SINKHORN_PREFETCH): before a slab's barriers and column pass, each wave touches the 128-byte lines of ITS segment of
+// the NEXT slab's row (one dword per line and lane: 32 lines of a 1024-column segment in one instruction, one register, result
+// unused), so the next row pass's float4 loads find their lines on the way or in L2 instead of starting an HBM latency after the
+// barrier.  Same loads, same arithmetic: bit-identical.
+template <int R, int NW, int G, bool PF>
 __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* __restrict__ part, int ngroup_max) {   // (eight waves per SIMD: <= 64 registers)
   extern __shared__ float sm[];
   float* tile = sm;                       // [R][N1p]
@@ -191,6 +195,7 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
   LSE cacc[MAXC], cdust{-INFINITY, 0.f};  // (the dustbin column j = n: thread 0's)
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) cacc[c] = LSE{-INFINITY, 0.f};
+  [[maybe_unused]] float pf_line = 0.f;   // (PF: the touched word of the next slab's row segment)
   // (G is a template parameter and the loop fully unrolled: as a run-time loop hipcc keeps 40 more vector and 50 more scalar registers
   // across the slabs -- 81 / 105 against 43 / 58 -- and the kernel falls off its eight waves per SIMD)
 #pragma unroll
@@ -288,6 +293,7 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
     if (i <= m && seg == W - 1 && lane == 0) lse_add(acc, a.alpha + vs[n]);      // the dustbin column, once per row
     if (lane == 0) { pm[wave] = acc.m; ps[wave] = acc.s; }
   }
+  if constexpr (PF && G > 1) { if (g > 0) asm volatile("" :: "v"(pf_line)); }
   __syncthreads();
   if (tid < R && i0 + tid <= m) {
     LSE t{pm[tid * W], ps[tid * W]};
@@ -300,6 +306,13 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
     a.u[(size_t)b * (a.N0p + 1) + i] = ui;
   }
   __syncthreads();
+  if constexpr (PF && G > 1) {
+    // (a plain load whose value is only "used" by an empty asm after the NEXT slab's row pass, where every load of the wave has been
+    // consumed: the compiler's own vmcnt tracking keeps the register until then and the wait it inserts there is free.  A volatile
+    // load becomes flat_load sc0 sc1 + vmcnt(0) on the spot -- a stall, not a prefetch.)
+    const int i = i0 + R + wave / W, seglen = a.N1p / W;
+    if (g + 1 < G && i < m && lane * 32 < seglen) pf_line = a.S[((size_t)b * a.N0p + i) * a.N1p + (wave % W) * seglen + lane * 32];
+  }
   const int rows = min(R, m + 1 - i0);      // rows of this slab, the last may be the dustbin row
   // all R rows REAL (i0 + R <= m): `rows == R` alone also admits a slab whose last row is the dustbin row i == m
   // (m % R == R-1), and that row of `tile` is never written by the row pass
@@ -568,18 +581,25 @@ hipError_t launch_gather_desc(const float* src, int64_t sb, int64_t sc, int64_t 
   return hipGetLastError();
 }
 
-template <int R, int NW, int G>
+template <int R, int NW, int G, bool PF>
 static void launch_slab_g(const SinkhornArgs& a, int nslab_max, hipStream_t s) {
   const size_t lds = ((size_t)R * a.N1p + a.N1p + 1) * sizeof(float);
   static unsigned long long attr = 0;
-  raise_lds_limit(reinterpret_cast<const void*>(sinkhorn_slab<R, NW, G>), 96 * 1024, attr);
-  hipLaunchKernelGGL((sinkhorn_slab<R, NW, G>), dim3((unsigned)nslab_max, (unsigned)a.B), dim3(64 * NW), lds, s, a, a.part, nslab_max);
+  raise_lds_limit(reinterpret_cast<const void*>(sinkhorn_slab<R, NW, G, PF>), 96 * 1024, attr);
+  hipLaunchKernelGGL((sinkhorn_slab<R, NW, G, PF>), dim3((unsigned)nslab_max, (unsigned)a.B), dim3(64 * NW), lds, s, a, a.part, nslab_max);
 }
 template <int R, int NW>
 static void launch_slab_k(const SinkhornArgs& a, int nslab_max, int G, hipStream_t s) {
-  if (G == 4) launch_slab_g<R, NW, 4>(a, nslab_max, s);
-  else if (G == 2) launch_slab_g<R, NW, 2>(a, nslab_max, s);
-  else launch_slab_g<R, NW, 1>(a, nslab_max, s);
+  // PF on where a row is split over two waves of a 16-wave workgroup (N1p = 2048: two workgroups per CU, each slab's loads an exposed
+  // latency): C5, 8 pairs x 100 iterations 4.20 -> 4.03 ms; off for the 8-wave form (four workgroups per CU cover each other: C3
+  // 1.98 -> 2.01 with it).  Measured and dropped beside it: dispatching every pair's short last group (the dustbin row's slab) after
+  // all full groups, so that the leftovers of 520 workgroups on 512 slots are the short ones -- 4.19 -> 4.29 ms at C5, nothing at C3
+  // (tools/sinkhorn_time.py --prefetch 0 1; IMX_SINKHORN_PREFETCH=0|1 overrides, _NOW is re-read per launch for the same-process A/B)
+  static const bool pf = [] { const char* e = getenv("IMX_SINKHORN_PREFETCH"); return e ? atoi(e) != 0 : NW == 16; }();
+  const bool p = [&] { const char* e = getenv("IMX_SINKHORN_PREFETCH_NOW"); return e ? atoi(e) != 0 : pf; }();   // (re-read per launch: tools/sinkhorn_time.py's same-process A/B)
+  if (G == 4) { if (p) launch_slab_g<R, NW, 4, true>(a, nslab_max, s); else launch_slab_g<R, NW, 4, false>(a, nslab_max, s); }
+  else if (G == 2) { if (p) launch_slab_g<R, NW, 2, true>(a, nslab_max, s); else launch_slab_g<R, NW, 2, false>(a, nslab_max, s); }
+  else launch_slab_g<R, NW, 1, false>(a, nslab_max, s);
 }
 
 template <int R>

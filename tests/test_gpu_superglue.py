@@ -416,3 +416,26 @@ def test_sinkhorn_grouped_slabs_equal_a_partial_per_slab(name, monkeypatch):
         assert np.abs(res[G][1] - res["1"][1]).max() <= 2e-6 * max(1.0, np.abs(res["1"][1]).max()), (G, np.abs(res[G][1] - res["1"][1]).max())
         assert np.abs(res[G][2] - res["1"][2]).max() <= 2e-6 * max(1.0, np.abs(res["1"][2]).max()), (G, np.abs(res[G][2] - res["1"][2]).max())
     assert np.array_equal(res["2"][0][0], g["matches0"])
+
+
+@pytest.mark.parametrize("name", ["c3_pair_s59.npz", "c5_pair_s19.npz"])
+def test_sinkhorn_next_slab_prefetch_is_bit_identical(name, monkeypatch):
+    """Round 5: a grouped Sinkhorn workgroup touches the lines of its next slab's rows before the current slab's column pass
+    (IMX_SINKHORN_PREFETCH_NOW=1).  Only the timing of the loads changes: potentials and matches bit for bit those of the form
+    without it, for both group sizes."""
+    g = util.golden(name)
+    H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
+    data = {k: v.cuda() for k, v in _oracle_pair_inputs(seed, H, W, d, K).items()}
+    eng, L = _engine(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(d))
+    eng.set_debug(True)
+    for G in ("2", "4"):
+        monkeypatch.setenv("IMX_SINKHORN_GROUP", G)
+        res = {}
+        for pf in ("0", "1"):
+            monkeypatch.setenv("IMX_SINKHORN_PREFETCH_NOW", pf)
+            out = _run(eng, data, (1, 1, H, W))
+            res[pf] = (out, eng.fetch("u").copy(), eng.fetch("v").copy())
+        for i in range(3):
+            assert np.array_equal(res["0"][0][i], res["1"][0][i]), (G, i)
+        assert np.array_equal(res["0"][1], res["1"][1]) and np.array_equal(res["0"][2], res["1"][2]), G

@@ -18,6 +18,7 @@ ap.add_argument("--pairs", type=int, default=64)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--workload", default="c3")
 ap.add_argument("--groups", type=int, nargs="+", default=[1, 2, 4, 8])
+ap.add_argument("--prefetch", type=int, nargs="+", default=[None], help="IMX_SINKHORN_PREFETCH_NOW settings to cross with --groups (0 / 1)")
 a = ap.parse_args()
 wl = bench.WORKLOADS[a.workload]
 m, *_ = bench.build_matching(wl, torch.device("cuda", 0))
@@ -28,8 +29,10 @@ i1 = torch.from_numpy(np.stack([p[1] for p in ims]))[:, None].cuda()
 m.match_batch(i0, i1)
 torch.cuda.synchronize()
 for rnd in range(2):
-    for G in a.groups:
+    for G, PF in [(g, p) for g in a.groups for p in a.prefetch]:
         os.environ["IMX_SINKHORN_GROUP"] = str(G)
+        if PF is not None:
+            os.environ["IMX_SINKHORN_PREFETCH_NOW"] = str(PF)
         m.match_batch(i0, i1)
         vals, tot = [], []
         for _ in range(a.reps):
@@ -41,4 +44,4 @@ for rnd in range(2):
             eng.set_timing(False)
             vals.append(rows["sinkhorn"][2])
             tot.append(sum(r[2] for r in rows.values()))
-        print(f"{a.workload} pairs {a.pairs} G={G}: sinkhorn {np.median(vals):.3f} ms per step (sum of kernels {np.median(tot):.2f} ms)", flush=True)
+        print(f"{a.workload} pairs {a.pairs} G={G} prefetch={PF}: sinkhorn {np.median(vals):.3f} ms per step (sum of kernels {np.median(tot):.2f} ms)", flush=True)
