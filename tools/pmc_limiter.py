@@ -8,15 +8,16 @@ from (same build-id rule as profiles/*_pmc_traffic.json).  Per kernel, per launc
   l1_data_path_frac TCP_TOTAL_CACHE_ACCESSES_sum (64-byte accesses) against 64 bytes per clock and CU
   l2_read_latency   TCP_TCC_READ_REQ_LATENCY_sum / TCP_TCC_READ_REQ_sum (cycles)
   lds_conflict      SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
-usage: tools/pmc_limiter.py <prefix of the pass tables> <pairs> <out.json>   (run on the GPU box, same build as the passes)"""
+usage: tools/pmc_limiter.py <prefix of the pass tables> <pairs> <out.json> [build string] [workload note]
+(run on the GPU box, same build as the passes; off the box, tables of another build / workload -- tools/gpu_pmc_c5.sh -- name their build)"""
 import json
 import os
 import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-NAMES = {"conv1ab_pool": r"conv1ab_wino24", "conv3x3_pair": r"conv3x3_wino24p", "conv3x3_tile": r"conv3x3_wino24h", "attention": r"attention_x3_kernel|attention_kernel",
-         "sinkhorn": r"sinkhorn_slab", "gnn_tail": r"gnn_tail_h2|gnn_tail_x3"}
+NAMES = {"conv1ab_pool": r"conv1ab_wino24", "conv3x3_pair": r"conv3x3_wino24p", "conv3x3_tile": r"conv3x3_wino24h", "attention": r"attention_x3p?_kernel|attention_kernel",
+         "sinkhorn": r"sinkhorn_slab", "gnn_tail": r"gnn_tail_h2|gnn_tail_x3", "gemm_x3": r"gemm_x3<"}
 NSIMD, NCU, NXCD = 4, 256, 8
 
 
@@ -55,9 +56,10 @@ def col(d, suffix):
     return None
 
 
-def main(prefix, pairs, out):
-    from image_matching_amd import _lib
-    build = _lib.load_library().imx_version().decode()
+def main(prefix, pairs, out, build=None, workload=None):
+    if build is None:
+        from image_matching_amd import _lib
+        build = _lib.load_library().imx_version().decode()
     tabs = {}
     for tag in ("sqa", "sqb", "ta2", "tcp", "tcp2"):
         try:
@@ -107,7 +109,7 @@ def main(prefix, pairs, out):
             k["ta_addr_stalled_by_tc_per_cu_cycle"] = round(col(t, "TA_ADDR_STALLED_BY_TC_CYCLES_sum") / (NCU * tg), 4)
             k["ta_data_stalled_by_tc_per_cu_cycle"] = round(col(t, "TA_DATA_STALLED_BY_TC_CYCLES_sum") / (NCU * tg), 4)
         kernels[name] = k
-    json.dump({"note": "rocprofv3 --pmc (kernel trace only), tools/gpu_pmc_limiter.sh over tools/run_pairs.py --pairs 64: passes sqa, sqb (SQ), ta2 (TA stall "
+    json.dump({"workload": workload or "c3", "note": "rocprofv3 --pmc (kernel trace only), tools/gpu_pmc_limiter.sh over tools/run_pairs.py --pairs 64 (or tools/gpu_pmc_c5.sh: --workload c5 --pairs 8): passes sqa, sqb (SQ), ta2 (TA stall "
                        "cycles), tcp, tcp2 (TCP); per-launch averages over the launches of two steps (the pair / tile Winograd entries average their "
                        "layers); GRBM_GUI_ACTIVE / 8 = GPU cycles; TA_BUSY / TA_BUFFER_* make rocprofv3 abort on this box and are not collected",
                "build": build, "pairs_per_gpu": int(pairs), "kernels": kernels}, open(out, "w"), indent=1)
@@ -115,4 +117,4 @@ def main(prefix, pairs, out):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:6])
