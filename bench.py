@@ -339,8 +339,13 @@ class ClockSampler:
             try:
                 out, _ = self._thread.communicate("stop\n", timeout=5)
                 self.samples = [tuple(x) for x in json.loads(out)]
-            except Exception:       # noqa: BLE001 -- the sampler is a report, never a reason to fail the bench
+            except Exception as e:  # noqa: BLE001 -- the sampler is a report, never a reason to fail the bench
                 self._thread.kill()
+                try:
+                    self._thread.wait(timeout=5)        # (reap it: a killed child left un-waited is a zombie -- ADVICE r5)
+                except Exception:   # noqa: BLE001
+                    pass
+                print(f"bench: clock sampler lost its samples ({type(e).__name__}: {e})", file=sys.stderr)
             self._thread = None
 
     def report(self):
@@ -527,13 +532,13 @@ def roofline_block(rows, wl, B, steps, dt, lib_build, workload):
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_limiter.json")), reverse=True):
             with open(path) as fh:
                 cand = json.load(fh)
-            if cand.get("build") == lib_build:
+            # build, workload and batch must all match (the first same-build file used to end the search even when it
+            # belonged to another workload and a matching one existed)
+            if cand.get("build") == lib_build and cand.get("workload", "c3") == workload and cand.get("pairs_per_gpu") == B:
                 lim, lim_path = cand, path
                 break
         if lim is None:
-            rf["limiter_note"] = "dropped: no profiles/r*_pmc_limiter.json was taken on this build"
-        elif workload != "c3" or lim["pairs_per_gpu"] != B:
-            rf["limiter_note"] = f"dropped: the counter passes were taken at {lim['pairs_per_gpu']} C3 pairs per step, this run is {workload} at {B}"
+            rf["limiter_note"] = f"dropped: no profiles/r*_pmc_limiter.json was taken on this build for {workload} at {B} pairs per step"
         elif name in lim["kernels"]:
             k = lim["kernels"][name]
             rf["limiter"] = {
@@ -816,6 +821,14 @@ def main():
         line["parity_in_run_strict"] = strict
     line["step_ms"] = stats["step_ms"]
     line["clocks"] = sampler.report()
+    # the box beside the number: boxes of this pool differ by +-4 % in sustained clock under this power-bound step, as
+    # much as a round's gain; `value` is what was measured, `value_at_2400MHz` the same scaled to the clock the peaks are quoted at
+    _clk = (line["clocks"].get("sclk_mhz") or {}).get("median")
+    line["sclk_mhz_median"] = _clk
+    line["socket_power_w_median"] = (line["clocks"].get("socket_power_w") or {}).get("median")
+    line["value_at_2400MHz"] = round(value * 2400.0 / _clk, 3) if _clk else None
+    line["value_at_2400MHz_note"] = ("value x 2400 / median sclk of rank 0's GPU inside the timed region: a normalisation for comparing runs on "
+                                     "different boxes, not a measurement (HBM-bound kernels do not scale with sclk)")
     if use_pg:
         line["backend"] = {"process_group": dist.get_backend(), "collective": "RCCL gather (ncclSend/ncclRecv group) over xGMI" if backend == "nccl" else f"{backend} on the host (bring-up hook)"}
         line["world_checked"] = {"WORLD_SIZE": world, "--gpus": args.gpus, "process_group_size": dist.get_world_size(), "ranks_counted_by_all_reduce": world}

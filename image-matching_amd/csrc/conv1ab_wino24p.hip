@@ -423,7 +423,8 @@ __global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, 
 
 bool conv1ab_wino24p_supported(const ConvArgs& a) { return conv1ab_wino24h_supported(a); }
 
-// at least one tile pair per CU (below that conv1ab_wino24h, with twice the workgroups, fills more of the chip)
+// at least TWO tile pairs per CU (the software pipeline over pairs needs a second pair to fill; below that conv1ab_wino24h, with twice the
+// workgroups, fills more of the chip)
 bool conv1ab_wino24p_preferred(const ConvArgs& a) {
   if (!conv1ab_wino24p_supported(a)) return false;
   static int ncu = 0;

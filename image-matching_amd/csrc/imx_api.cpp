@@ -680,9 +680,8 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   int layer = 0;
   // conv2a -> conv2b, conv3a -> conv3b, conv4a -> conv4b: the tensor between them is tile-swizzled (ConvArgs::out_blocked / in_blocked
   // = 2) when BOTH layers run the pair kernel on this slice -- its stores are then 1 KB contiguous per instruction
-  // (conv3x3_wino24p.hip).  IMX_CONV_SWZ=0: never (the A/B switch of tools and tests; the results are bit-identical either way).
-  const char* swz_env = getenv("IMX_CONV_SWZ");
-  const bool swz_on = !(swz_env && swz_env[0] == '0');
+  // (conv3x3_wino24p.hip).  "conv_swizzle" = "off": never (the A/B switch of tools and tests; the results are bit-identical either way).
+  const bool swz_on = h->opt.conv_swizzle != 0;
   auto swz_pair = [&](int li_prod, int hh, int ww, int nb) -> bool {
     if (!amax || !swz_on || h->opt.conv_f16 != 1 || (li_prod != 1 && li_prod != 3 && li_prod != 5)) return false;
     for (int k = 0; k < 2; ++k) {
@@ -908,8 +907,7 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   bool have_amax_x = false;
   // (IMX_QKV_AMAX=kernel: the maxima of a projected q|k|v by the separate pass even where the projection's epilogue can write them --
   // the A/B switch of tests/test_gpu_superglue.py; the two must agree bit for bit)
-  const char* amax_env = getenv("IMX_QKV_AMAX");
-  const bool amax_by_kernel = amax_env && !strcmp(amax_env, "kernel");
+  const bool amax_by_kernel = h->opt.qkv_amax != 0;      // "qkv_amax" = "kernel": the bit-identity test's A/B
   for (size_t l = 0; l < h->layers.size(); ++l) {
     const GnnLayer& L = h->layers[l];
     if (!have_next) {
@@ -989,7 +987,7 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     WS(pt, float, "sg.part", (size_t)B * (N0p / Rs + 1) * (N1p + 1) * 2 * f);
     part = pt;
   }
-  SinkhornArgs sk{S, u, v, B, N0p, N1p, sd[0].n, sd[1].n, N0, N1, h->bin_score, c.sinkhorn_iterations, part};
+  SinkhornArgs sk{S, u, v, B, N0p, N1p, sd[0].n, sd[1].n, N0, N1, h->bin_score, c.sinkhorn_iterations, part, h->opt.sinkhorn_group, h->opt.sinkhorn_prefetch};
   RUN("sinkhorn", launch_sinkhorn(sk, s));
   MatchArgs ma{S, u, v, B, N0p, N1p, sd[0].n, sd[1].n, N0, N1, h->bin_score, c.match_threshold,
                max0, idx0, max1, idx1, m0, m1, ms0, ms1};
@@ -1006,7 +1004,8 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   return 0;
 }
 
-// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | wino_h | wino32 | direct, "gnn_tail" = auto | fused | bf16x3 | unfused, "attention" = auto | f16x2 | bf16x3.  Returns 0, or -1 for an unknown key / value.
+// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | wino_h | wino32 | direct, "gnn_tail" = auto | fused | bf16x3 | unfused, "attention" = auto | f16x2 | bf16x3;
+// the A/B switches "conv_swizzle" = on | off, "qkv_amax" = epilogue | kernel, "sinkhorn_group" = auto | 1 | 2 | 4, "sinkhorn_prefetch" = auto | off | on.  Returns 0, or -1 for an unknown key / value.
 int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
   Options& o = h->opt;
   if (key == "mfma") {
@@ -1028,6 +1027,14 @@ int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
     }
     else if (v == "direct") o.conv_direct = 1;
     else return -1;
+  } else if (key == "conv_swizzle") {
+    if (v == "on" || v == "1") o.conv_swizzle = 1; else if (v == "off" || v == "0") o.conv_swizzle = 0; else return -1;
+  } else if (key == "qkv_amax") {
+    if (v == "epilogue") o.qkv_amax = 0; else if (v == "kernel") o.qkv_amax = 1; else return -1;
+  } else if (key == "sinkhorn_group") {
+    if (v == "auto" || v == "0") o.sinkhorn_group = 0; else if (v == "1" || v == "2" || v == "4") o.sinkhorn_group = v[0] - '0'; else return -1;
+  } else if (key == "sinkhorn_prefetch") {
+    if (v == "auto") o.sinkhorn_prefetch = -1; else if (v == "off" || v == "0") o.sinkhorn_prefetch = 0; else if (v == "on" || v == "1") o.sinkhorn_prefetch = 1; else return -1;
   } else {
     return -1;
   }
@@ -1095,9 +1102,9 @@ int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
     // switches of earlier rounds that no longer exist: say so once instead of silently measuring the default path
     static std::atomic<bool> warned{false};
     for (const char* old : {"IMX_GEMM", "IMX_GEMM_SMALL", "IMX_ATTN", "IMX_ATTN_SPLIT", "IMX_NMS", "IMX_CONV_BLOCKED", "IMX_WINO_EXP", "IMX_WINO_WGS",
-                            "IMX_X3_WGS", "IMX_SINKHORN_WAVES"})
+                            "IMX_X3_WGS", "IMX_SINKHORN_WAVES", "IMX_CONV_SWZ", "IMX_QKV_AMAX", "IMX_SINKHORN_GROUP", "IMX_SINKHORN_PREFETCH", "IMX_SINKHORN_PREFETCH_NOW"})
       if (getenv(old) && !warned.exchange(true))
-        fprintf(stderr, "libimx: the environment variable %s (and the other per-kernel switches of rounds 1-2) was removed; it is ignored. "
+        fprintf(stderr, "libimx: the environment variable %s (and the other per-kernel switches of rounds 1-5) was removed; it is ignored. "
                         "Kernel forms are handle options now: imx_set_option(h, \"mfma\" | \"latency_forms\" | \"conv\", ...), seeded from IMX_MFMA / "
                         "IMX_LATENCY_FORMS / IMX_CONV at imx_create (an unknown VALUE of those three makes imx_create fail).\n", old);
     build_expected(h.get());
@@ -1519,7 +1526,7 @@ int imx_set_option(imx_handle_t h, const char* key, const char* value) {
   return guarded(h, "imx_set_option", [&]() -> int {
     if (!h) return -1;
     if (!key || !value) return fail(h, "imx_set_option: null argument");
-    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino_h|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3)", key, value);
+    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino_h|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3, conv_swizzle = on|off, qkv_amax = epilogue|kernel, sinkhorn_group = auto|1|2|4, sinkhorn_prefetch = auto|off|on)", key, value);
     return 0;
   });
 }
@@ -1534,6 +1541,10 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : o.conv_f16 == 2 ? "wino_h" : o.conv_f16 ? "wino" : "wino32";
     else if (k == "gnn_tail") h->opt_text = o.gnn_tail < 0 ? "auto" : o.gnn_tail == 2 ? "bf16x3" : o.gnn_tail ? "fused" : "unfused";
     else if (k == "attention") h->opt_text = o.attention < 0 ? "auto" : o.attention ? "f16x2" : "bf16x3";
+    else if (k == "conv_swizzle") h->opt_text = o.conv_swizzle ? "on" : "off";
+    else if (k == "qkv_amax") h->opt_text = o.qkv_amax ? "kernel" : "epilogue";
+    else if (k == "sinkhorn_group") h->opt_text = o.sinkhorn_group ? std::to_string(o.sinkhorn_group) : std::string("auto");
+    else if (k == "sinkhorn_prefetch") h->opt_text = o.sinkhorn_prefetch < 0 ? "auto" : o.sinkhorn_prefetch ? "on" : "off";
     else if (k == "arith_guard") {      // read-only: what the weights-derived guards decided (after imx_finalize_weights)
       char buf[96];
       float sp = 0.f;

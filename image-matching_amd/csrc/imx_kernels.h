@@ -23,6 +23,11 @@ struct Options {
   int conv_direct = 0;     // "conv": 0 = "wino" / "wino32" (Winograd F(2x4,3x3); direct only for shapes it rejects), 1 = "direct"
   int conv_f16 = 1;        //         (2 = "wino_h": conv3x3_wino24h for every layer, never the tile-pair form conv3x3_wino24p)  "wino" (default): the layers after the first run the Winograd products on the fp16 matrix pipe (two planes per
                            //         transformed operand, conv3x3_wino24h.hip; needs "mfma" = "x3"); "wino32": every product on the fp32 MFMA
+  // A/B switches of the bit-identity tests and of tools/ (round 6: handle options; environment variables of these names are not read)
+  int conv_swizzle = 1;    // "conv_swizzle": 1 = "on" (the tensor between two pair-form layers without a pool is tile-swizzled), 0 = "off" (blocked)
+  int qkv_amax = 0;        // "qkv_amax": 0 = "epilogue" (a plain q|k|v projection's epilogue writes the (side, pair) maxima), 1 = "kernel" (the separate pass)
+  int sinkhorn_group = 0;  // "sinkhorn_group": 0 = "auto" (2 slabs per workgroup up to 1024 columns, 4 above, 1 below 64 slabs), 1 | 2 | 4
+  int sinkhorn_prefetch = -1;  // "sinkhorn_prefetch": -1 = "auto" (on for the 16-wave form), 0 = "off", 1 = "on"
 };
 
 // The form a launcher picked ("gemm_x3:bf16x3", "conv3x3_wino24:f32", ...: kernel family, then the matrix pipe it runs on or
@@ -273,6 +278,8 @@ struct SinkhornArgs {
   float alpha;               // bin_score
   int iters;
   float* part;               // scratch (B, N0p/R + 1, N1p + 1, 2) for the slab form, R = sinkhorn_slab_rows(N1p); may be null
+  int group = 0;             // Options::sinkhorn_group (0 = auto)
+  int prefetch = -1;         // Options::sinkhorn_prefetch (-1 = auto)
 };
 int sinkhorn_slab_rows(int N1p);
 hipError_t launch_sinkhorn(const SinkhornArgs& a, hipStream_t s);

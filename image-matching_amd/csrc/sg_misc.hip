@@ -594,9 +594,8 @@ static void launch_slab_k(const SinkhornArgs& a, int nslab_max, int G, hipStream
   // latency): C5, 8 pairs x 100 iterations 4.20 -> 4.03 ms; off for the 8-wave form (four workgroups per CU cover each other: C3
   // 1.98 -> 2.01 with it).  Measured and dropped beside it: dispatching every pair's short last group (the dustbin row's slab) after
   // all full groups, so that the leftovers of 520 workgroups on 512 slots are the short ones -- 4.19 -> 4.29 ms at C5, nothing at C3
-  // (tools/sinkhorn_time.py --prefetch 0 1; IMX_SINKHORN_PREFETCH=0|1 overrides, _NOW is re-read per launch for the same-process A/B)
-  static const bool pf = [] { const char* e = getenv("IMX_SINKHORN_PREFETCH"); return e ? atoi(e) != 0 : NW == 16; }();
-  const bool p = [&] { const char* e = getenv("IMX_SINKHORN_PREFETCH_NOW"); return e ? atoi(e) != 0 : pf; }();   // (re-read per launch: tools/sinkhorn_time.py's same-process A/B)
+  // (tools/sinkhorn_time.py --prefetch 0 1; the handle option "sinkhorn_prefetch" = auto | off | on overrides)
+  const bool p = a.prefetch < 0 ? NW == 16 : a.prefetch != 0;
   if (G == 4) { if (p) launch_slab_g<R, NW, 4, true>(a, nslab_max, s); else launch_slab_g<R, NW, 4, false>(a, nslab_max, s); }
   else if (G == 2) { if (p) launch_slab_g<R, NW, 2, true>(a, nslab_max, s); else launch_slab_g<R, NW, 2, false>(a, nslab_max, s); }
   else launch_slab_g<R, NW, 1, false>(a, nslab_max, s);
@@ -629,11 +628,11 @@ hipError_t launch_sinkhorn(const SinkhornArgs& a, hipStream_t s) {
   const int R = sinkhorn_slab_rows(a.N1p);
   if (R > 0 && a.part) {
     // G slabs per workgroup (their column partials merged in registers): where a pair has enough slabs to fill its share of the
-    // chip anyway (IMX_SINKHORN_GROUP overrides: the A/B switch of the parity tests; 1 = a partial per slab, as before round 5)
+    // chip anyway (the handle option "sinkhorn_group" overrides: the A/B switch of the parity tests; 1 = a partial per slab, as before round 5)
     // (measured, tools/sinkhorn_time.py: C3, 129 slabs of 1024 columns x 64 pairs: 2.28 / 2.02 / 2.03 ms per 30 iterations with 1 / 2 / 4
     // slabs per workgroup; C5, 257 slabs of 2048 columns x 8 pairs: 4.49 / 4.63 / 4.18 per 100)
     int G = a.N0p / R + 1 < 64 ? 1 : a.N1p <= 1024 ? 2 : 4;
-    if (const char* e = getenv("IMX_SINKHORN_GROUP")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) G = v; }
+    if (a.group == 1 || a.group == 2 || a.group == 4) G = a.group;
     const int nslab_max = (a.N0p / R + 1 + G - 1) / G;           // groups per pair = the partial buffer's rows per pair (<= N0p / R + 1: a.part's size)
     // (Round 5: walking the batch in groups whose score matrices fit the 256-MB Infinity Cache -- all iterations of a group back to
     // back -- was measured and is SLOWER: 2.22 ms for the 64 C3 pairs in one group, 2.58 / 2.88 / 3.16 / 4.25 ms with groups of 150 /

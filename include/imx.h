@@ -26,6 +26,13 @@
 
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: the entry points below are its ONLY dynamic symbols (tests/test_host.py checks nm -D). */
+#if defined(__GNUC__) || defined(__clang__)
+#define IMX_API __attribute__((visibility("default")))
+#else
+#define IMX_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -63,26 +70,26 @@ typedef struct imx_config {
 } imx_config_t;
 
 /* Replaces Matching.__init__ / `.to(device)` (matching_test.py:49-52, superpoint_glue_test.py:69). */
-int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out);
-int imx_destroy(imx_handle_t h);
+IMX_API int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out);
+IMX_API int imx_destroy(imx_handle_t h);
 /* Text of the last error on this handle (h == NULL: last error of a failed imx_create). */
-const char* imx_last_error(imx_handle_t h);
+IMX_API const char* imx_last_error(imx_handle_t h);
 
 /* Replaces load_state_dict (superpoint_test.py:87-99, superglue_test.py:221-227,
  * superglue/models/superpoint.py:136-137).  `name` is the reference state-dict key, `host` a
  * HOST pointer to the fp32 tensor in the reference's layout (Conv2d: (Cout,Cin,kh,kw), Conv1d:
  * (Cout,Cin,1), BN vectors, bin_score: scalar).  The library copies.  Unknown keys are an error;
  * '*.num_batches_tracked' need not be passed. */
-int imx_load_weight(imx_handle_t h, int net, const char* name, const float* host,
+IMX_API int imx_load_weight(imx_handle_t h, int net, const char* name, const float* host,
                     int ndim, const int64_t* shape);
 /* Folds eval-mode BatchNorm (eps 1e-5) into the preceding conv, re-lays weights out for the
  * kernels and uploads them.  Fails listing the first missing key. */
-int imx_finalize_weights(imx_handle_t h, int net);
+IMX_API int imx_finalize_weights(imx_handle_t h, int net);
 
 /* SuperPoint.forward, detection half: encoder, heads, softmax+pixel-shuffle, simple_nms,
  * threshold, remove_borders, top-k (superpoint_test.py:113-149).  img_dev: (B,1,H,W).
  * counts_dev (may be NULL): B int32, number of keypoints kept per image. */
-int imx_superpoint_detect(imx_handle_t h, const float* img_dev, int B, int H, int W,
+IMX_API int imx_superpoint_detect(imx_handle_t h, const float* img_dev, int B, int H, int W,
                           int32_t* counts_dev, void* stream);
 /* SuperPoint.forward, description half (superpoint_test.py:151-155) for the images of the last
  * imx_superpoint_detect: writes, per image b, rows [0,count_b) of
@@ -90,13 +97,13 @@ int imx_superpoint_detect(imx_handle_t h, const float* img_dev, int B, int H, in
  *   desc_dev   (B,Kcap,d)  one L2-normalised descriptor per row (the transpose of the
  *                          reference's (d,K) tensor; rows >= count_b are zero-filled)
  * Kcap must be >= every count (for max_keypoints >= 0, Kcap = max_keypoints suffices). */
-int imx_superpoint_describe(imx_handle_t h, int B, int Kcap, float* kpts_dev, float* scores_dev,
+IMX_API int imx_superpoint_describe(imx_handle_t h, int B, int Kcap, float* kpts_dev, float* scores_dev,
                             float* desc_dev, void* stream);
 
 /* Dense SuperPoint forward used by training / pseudo-label export (superpoint/models/superpoint_train.py:31-57):
  * semi_dev (B,65,H/8,W/8) and desc_dev (B,d,H/8,W/8) in the reference's channel-major layout, descriptors divided
  * by their channel norm (:53-54). */
-int imx_superpoint_dense(imx_handle_t h, const float* img_dev, int B, int H, int W,
+IMX_API int imx_superpoint_dense(imx_handle_t h, const float* img_dev, int B, int H, int W,
                          float* semi_dev, float* desc_dev, void* stream);
 
 /* SuperGlue.forward (superglue_test.py:230-285) on B pairs.
@@ -107,7 +114,7 @@ int imx_superpoint_dense(imx_handle_t h, const float* img_dev, int B, int H, int
  *   H,W per side: only the image *shape* is used (normalize_keypoints, :63-70).
  * Outputs (B,N0)/(B,N1): matches int64 (-1 = unmatched), matching_scores fp32; entries at
  * i >= count are -1 / 0.  A pair with a zero count yields all -1 / 0 (:235-242). */
-int imx_superglue_forward(imx_handle_t h, int B,
+IMX_API int imx_superglue_forward(imx_handle_t h, int B,
                           const float* kpts0_dev, const float* scores0_dev, const float* desc0_dev,
                           int64_t desc0_stride_b, int64_t desc0_stride_c, int64_t desc0_stride_n,
                           const int32_t* n0_dev, int N0, int H0, int W0,
@@ -121,7 +128,7 @@ int imx_superglue_forward(imx_handle_t h, int B,
  * max_keypoints = K >= 0: SuperPoint on img0/img1 (each (B,1,H,W)), then SuperGlue, no host
  * synchronisation.  Outputs per side s: kpts (B,K,2), scores (B,K), counts (B) int32,
  * desc (B,K,d) or NULL, matches (B,K) int64, mscores (B,K). */
-int imx_match_pairs(imx_handle_t h, const float* img0_dev, const float* img1_dev, int B, int H, int W,
+IMX_API int imx_match_pairs(imx_handle_t h, const float* img0_dev, const float* img1_dev, int B, int H, int W,
                     float* kpts0_dev, float* kpts1_dev, float* scores0_dev, float* scores1_dev,
                     int32_t* counts0_dev, int32_t* counts1_dev, float* desc0_dev, float* desc1_dev,
                     int64_t* matches0_dev, int64_t* matches1_dev,
@@ -135,7 +142,7 @@ int imx_match_pairs(imx_handle_t h, const float* img0_dev, const float* img1_dev
  * one gather to the rank that writes the results (the reference's loop over pairs has no cross-pair state:
  * superpoint_glue_test.py:66,72-78); image-matching_amd/shard.py does it with torch.distributed over RCCL, a C host with
  * ncclGroupStart / ncclSend / ncclRecv on the same buffers. */
-int imx_pack_records(imx_handle_t h, const int32_t* pair_ids_dev, int B, int K,
+IMX_API int imx_pack_records(imx_handle_t h, const int32_t* pair_ids_dev, int B, int K,
                      const float* kpts0_dev, const float* kpts1_dev, const int32_t* counts0_dev, const int32_t* counts1_dev,
                      const int64_t* matches0_dev, const int64_t* matches1_dev,
                      const float* mscores0_dev, const float* mscores1_dev, int32_t* rec_dev, int rows, void* stream);
@@ -145,7 +152,7 @@ int imx_pack_records(imx_handle_t h, const int32_t* pair_ids_dev, int B, int K,
  * rank; ignored on the other ranks -- as ONE group of ncclSend / ncclRecv over xGMI, enqueued on `stream`.  nccl_comm: an
  * ncclComm_t the host created with RCCL (ncclCommInitRank); rank and world size are read from it.  The RCCL entry points are
  * resolved at run time from the RCCL already loaded in the process (else librccl.so). */
-int imx_gather_records(imx_handle_t h, const int32_t* rec_dev, int rows, int width, int32_t* out_dev, int dst,
+IMX_API int imx_gather_records(imx_handle_t h, const int32_t* rec_dev, int rows, int width, int32_t* out_dev, int dst,
                        void* nccl_comm, void* stream);
 
 /* Registration post-step inside the reference's timed region: RANSAC partial-affine (4-DoF similarity) fit
@@ -155,7 +162,7 @@ int imx_gather_records(imx_handle_t h, const int32_t* rec_dev, int rows, int wid
  * closed-form least-squares refit on its inliers.  M_dev (B,2,3); inlier_dev (B,K) uint8 in keypoints0 index
  * space; n_inliers_dev (B) = 0 when the pair has <= 3 matches (no fit, M = 0).  counts0_dev may be NULL.  Any K (the matched
  * coordinates are staged in LDS up to K = 8192 and in HBM above). */
-int imx_estimate_affine_partial(imx_handle_t h, const float* kpts0_dev, const float* kpts1_dev,
+IMX_API int imx_estimate_affine_partial(imx_handle_t h, const float* kpts0_dev, const float* kpts1_dev,
                                 const int64_t* matches0_dev, const int32_t* counts0_dev, int B, int K,
                                 float ransac_threshold, int hypotheses, uint32_t seed,
                                 float* M_dev, uint8_t* inlier_dev, int32_t* n_inliers_dev, void* stream);
@@ -165,7 +172,7 @@ int imx_estimate_affine_partial(imx_handle_t h, const float* kpts0_dev, const fl
  * superpoint_flann_test.py:66-74 (FLANN's KD-tree search is approximate; this is the exact search it approximates).
  * desc{0,1}_dev addressed like imx_superglue_forward's descriptors; n{0,1}_dev optional valid counts.
  * matches_dev (B,N0) int64 nearest index in side 1 or -1; dist{1,2}_dev (B,N0) L2 distances to the two neighbours. */
-int imx_knn_ratio_match(imx_handle_t h, int B,
+IMX_API int imx_knn_ratio_match(imx_handle_t h, int B,
                         const float* desc0_dev, int64_t desc0_stride_b, int64_t desc0_stride_c, int64_t desc0_stride_n,
                         const int32_t* n0_dev, int N0,
                         const float* desc1_dev, int64_t desc1_stride_b, int64_t desc1_stride_c, int64_t desc1_stride_n,
@@ -176,39 +183,39 @@ int imx_knn_ratio_match(imx_handle_t h, int B,
  * (datasets/SSHIDataset.py:19-27) on the GPU: src_dev (B,Hs,Ws) uint8 (batch stride src_stride_b bytes) ->
  * dst_dev (B,H,W) float32 in [0,1], ready for imx_superpoint_detect / imx_match_pairs.  H==Hs, W==Ws is the
  * `resize_scale is None` path (plain /255). */
-int imx_ingest_resize_u8(imx_handle_t h, const uint8_t* src_dev, int B, int Hs, int Ws, int64_t src_stride_b,
+IMX_API int imx_ingest_resize_u8(imx_handle_t h, const uint8_t* src_dev, int B, int Hs, int Ws, int64_t src_stride_b,
                          float* dst_dev, int H, int W, void* stream);
 
 /* Warp post-step: cv2.warpAffine(source_original*255, Matrix, (W,H)) as written by cv2.imwrite
  * (superpoint_glue_test.py:101-113, superpoint_flann_test.py:88-92).  M_host: forward 2x3 matrix, 6 doubles on
  * the host (row-major).  src_dev (Hs,Ws) uint8 -> dst_dev (H,W) uint8. */
-int imx_warp_affine_u8(imx_handle_t h, const uint8_t* src_dev, int Hs, int Ws, const double* M_host,
+IMX_API int imx_warp_affine_u8(imx_handle_t h, const uint8_t* src_dev, int Hs, int Ws, const double* M_host,
                        uint8_t* dst_dev, int H, int W, void* stream);
 
 /* Single-stage entry point: simple_nms (superpoint_test.py:7-22) on a caller-supplied score map
  * (B,H,W) -> out (B,H,W).  Compare-only arithmetic: bit-exact given identical input. */
-int imx_op_nms(imx_handle_t h, const float* scores_dev, float* out_dev, int B, int H, int W,
+IMX_API int imx_op_nms(imx_handle_t h, const float* scores_dev, float* out_dev, int B, int H, int W,
                int radius, void* stream);
 
 /* Parity-test taps: when enabled, forwards keep copies of named intermediates
  * ("x4","semi","desc","score_map","nms","kenc","gnn<i>","mdesc","scores_in","u","v", ...).
  * imx_debug_fetch copies one to HOST (synchronises the device); shape_out gets up to 4 dims. */
-int imx_set_debug(imx_handle_t h, int enable);
-int imx_debug_fetch(imx_handle_t h, const char* name, float* host_out, int64_t capacity,
+IMX_API int imx_set_debug(imx_handle_t h, int enable);
+IMX_API int imx_debug_fetch(imx_handle_t h, const char* name, float* host_out, int64_t capacity,
                     int64_t* shape_out, int* ndim_out);
 
 /* Per-kernel timing for bench.py's roofline block: when enabled, every kernel launch is
  * bracketed by HIP events on the launch stream.  imx_timing_report(h, -1, ...) synchronises,
  * aggregates by kernel name and returns the number of rows; imx_timing_report(h, i>=0, ...)
  * returns row i as (name, launches, total_ms). */
-int imx_set_timing(imx_handle_t h, int enable);
-int imx_timing_report(imx_handle_t h, int index, const char** name_out, int64_t* launches_out,
+IMX_API int imx_set_timing(imx_handle_t h, int enable);
+IMX_API int imx_timing_report(imx_handle_t h, int index, const char** name_out, int64_t* launches_out,
                       double* total_ms_out);
-int imx_timing_reset(imx_handle_t h);
+IMX_API int imx_timing_reset(imx_handle_t h);
 /* The kernel form row `index` of the last report ran as: "<kernel family>:<pipe>", pipe = f32 (fp32 MFMA), bf16x3 (fp32
  * products as six bf16 term products on the bf16 MFMA) or hbm (streaming kernel); "" for single-form kernels.  A name whose
  * launches took different forms has one row per form.  bench.py prices each row against the peak of the pipe named HERE. */
-const char* imx_timing_form(imx_handle_t h, int index);
+IMX_API const char* imx_timing_form(imx_handle_t h, int index);
 
 /* Kernel-form options of a handle.  Defaults come from the environment ONCE, at imx_create (IMX_MFMA, IMX_LATENCY_FORMS,
  * IMX_CONV, IMX_GNN_TAIL, IMX_ATTENTION); afterwards only this call changes them -- nothing reads the environment on the launch path.
@@ -227,23 +234,37 @@ const char* imx_timing_form(imx_handle_t h, int index);
  *                           bit for bit; "wino_h" never uses the pair form (the A/B reference of that choice); "wino32" the same with every
  *                           product on the fp32 MFMA (the A/B reference); "direct" the direct implicit-GEMM kernel for every 3x3 layer
  *                           (the fallback for shapes Winograd rejects);
- *   "gnn_tail"       "auto" (default) = "fused": wherever the throughput forms run (more than 4096 feature rows, descriptor_dim 128) the
+ *   "gnn_tail"       "auto" (default): wherever the throughput forms run (more than 4096 feature rows, descriptor_dim 128) the
  *                           tail of a GNN layer (mlp.0 -> mlp.3 + residual -> the next layer's q|k|v or final_proj) is ONE launch: three fp16
  *                           plane products of two-plane operands beside the two-plane attention (the operands' powers of two come from
- *                           bounds: the (side, pair) maxima of x and v, the weights' column L1 norms), else six bf16 plane products;
- *                           "bf16x3" the six-product launch; "unfused" three launches (the A/B reference: another summation order);
+ *                           bounds: the (side, pair) maxima of x and v, the weights' column L1 norms) -- EXCEPT on layers whose bounds
+ *                           the weights-derived guard finds too loose for fp16's range (read-only option "arith_guard" lists them),
+ *                           which run the six-bf16-product launch; "fused" forces the fp16 launch on every layer (the guard's A/B);
+ *                           "bf16x3" the six-product launch everywhere; "unfused" three launches (the A/B reference: another summation order);
  *   "attention"      "auto" (default) = "f16x2": the throughput attention (head dims 32 / 64, "mfma" = "x3") cuts q, k, v and the softmax
  *                           weights into TWO fp16 planes (22 bits; every operand scaled by a power of two taken from the maximum of its
  *                           (side, pair) over the valid rows) and keeps three term products per k-step; "bf16x3" three bf16 planes and
  *                           six term products (the A/B reference; both are closer to a float64 evaluation than the fp32 MFMA form).
+ * A/B switches of the bit-identity tests and of tools/ (results agree bit for bit, the Sinkhorn group to 2e-6 in the potentials with
+ * equal matches); none of them is read from the environment:
+ *   "conv_swizzle"      "on" (default) the tensor between two pair-form 3x3 layers without a pool is tile-swizzled; "off": blocked;
+ *   "qkv_amax"          "epilogue" (default) a plain q|k|v projection writes the (side, pair) maxima in its epilogue; "kernel": a separate pass;
+ *   "sinkhorn_group"    "auto" (default: 2 slabs per workgroup up to 1024 columns, 4 above, 1 below 64 slabs) | "1" | "2" | "4";
+ *   "sinkhorn_prefetch" "auto" (default: on for the 16-wave form, i.e. above 1024 columns) | "off" | "on".
+ * Read-only (imx_get_option only): "arith_guard" -- what the weights-derived guards decided at imx_finalize_weights: the largest spread
+ * of a layer's transformed convolution weights and the pipe the 3x3 chain runs on, the GNN layers whose tail runs bf16x3, the largest
+ * bound looseness.  The guards cover the convolution weights' per-output-channel spread and the layer tails' bounds; the two-plane
+ * attention is scaled by the ACTUAL q / k / v maxima of each (side, pair) and has no weight-derived fallback: a checkpoint with one
+ * q, k or v channel 2^15 above the rest loses the low plane of the typical channels there ("attention" = "bf16x3" has no range limit).
+ * "conv" also accepts "wx3" (round 3's removed bf16-plane convolution: runs "wino32" and says so on stderr).
  * Unknown keys / values are an error.  imx_get_option returns the current value ("" for an unknown key); the pointer is valid
  * until the next call on the handle. */
-int imx_set_option(imx_handle_t h, const char* key, const char* value);
-const char* imx_get_option(imx_handle_t h, const char* key);
+IMX_API int imx_set_option(imx_handle_t h, const char* key, const char* value);
+IMX_API const char* imx_get_option(imx_handle_t h, const char* key);
 
 /* Library build string, e.g. "imx 0.4 gfx950 hip-7.2 fp32 build 3f2a91c07d1e" (the id is a digest of the library
  * sources: measurements taken on one build are only quoted for that build). */
-const char* imx_version(void);
+IMX_API const char* imx_version(void);
 
 #ifdef __cplusplus
 }

@@ -361,7 +361,7 @@ def test_fused_small_layer_equals_the_three_launch_form(d):
 def test_qkv_maxima_from_the_projection_epilogue_equal_the_separate_pass(tail, monkeypatch):
     """Round 5: where a layer's q|k|v is a plain projection (layer 0; every layer under "gnn_tail" = "unfused", which is C5's d = 256
     path), gemm_x3's epilogue writes the (side, pair) maxima the two-plane attention scales by -- no `qkv_amax` launch.  A maximum
-    does not depend on the order it is taken in: everything downstream must equal the separate pass (IMX_QKV_AMAX=kernel) bit for
+    does not depend on the order it is taken in: everything downstream must equal the separate pass ("qkv_amax" = "kernel") bit for
     bit, on a full-size pair and on a batch with ragged per-pair counts (rows past a count must not enter the maxima)."""
     g = util.golden("c3_pair_s59.npz")
     H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
@@ -376,10 +376,7 @@ def test_qkv_maxima_from_the_projection_epilogue_equal_the_separate_pass(tail, m
     eng.set_debug(True)
     res = {}
     for how in ("epilogue", "kernel"):
-        if how == "kernel":
-            monkeypatch.setenv("IMX_QKV_AMAX", "kernel")
-        else:
-            monkeypatch.delenv("IMX_QKV_AMAX", raising=False)
+        eng.set_option("qkv_amax", how)
         eng.timing_reset()
         eng.set_timing(True)
         a = _run(eng, one, (1, 1, H, W))
@@ -399,7 +396,7 @@ def test_qkv_maxima_from_the_projection_epilogue_equal_the_separate_pass(tail, m
 def test_sinkhorn_grouped_slabs_equal_a_partial_per_slab(name, monkeypatch):
     """Round 5: a Sinkhorn workgroup walks two consecutive 8-row slabs and merges their column partials in registers (half the
     partial traffic).  The merge is the same log-sum-exp with one more pairwise step: potentials equal to 2e-6, match indices equal,
-    against the one-partial-per-slab form (IMX_SINKHORN_GROUP=1) and against a group of four."""
+    against the one-partial-per-slab form ("sinkhorn_group" = 1) and against a group of four."""
     g = util.golden(name)
     H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
     data = {k: v.cuda() for k, v in _oracle_pair_inputs(seed, H, W, d, K).items()}
@@ -408,7 +405,7 @@ def test_sinkhorn_grouped_slabs_equal_a_partial_per_slab(name, monkeypatch):
     eng.set_debug(True)
     res = {}
     for G in ("1", "2", "4"):
-        monkeypatch.setenv("IMX_SINKHORN_GROUP", G)
+        eng.set_option("sinkhorn_group", G)
         out = _run(eng, data, (1, 1, H, W))
         res[G] = (out, eng.fetch("u").copy(), eng.fetch("v").copy())
     for G in ("2", "4"):
@@ -421,7 +418,7 @@ def test_sinkhorn_grouped_slabs_equal_a_partial_per_slab(name, monkeypatch):
 @pytest.mark.parametrize("name", ["c3_pair_s59.npz", "c5_pair_s19.npz"])
 def test_sinkhorn_next_slab_prefetch_is_bit_identical(name, monkeypatch):
     """Round 5: a grouped Sinkhorn workgroup touches the lines of its next slab's rows before the current slab's column pass
-    (IMX_SINKHORN_PREFETCH_NOW=1).  Only the timing of the loads changes: potentials and matches bit for bit those of the form
+    ("sinkhorn_prefetch" = "on").  Only the timing of the loads changes: potentials and matches bit for bit those of the form
     without it, for both group sizes."""
     g = util.golden(name)
     H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
@@ -430,10 +427,10 @@ def test_sinkhorn_next_slab_prefetch_is_bit_identical(name, monkeypatch):
     eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(d))
     eng.set_debug(True)
     for G in ("2", "4"):
-        monkeypatch.setenv("IMX_SINKHORN_GROUP", G)
+        eng.set_option("sinkhorn_group", G)
         res = {}
         for pf in ("0", "1"):
-            monkeypatch.setenv("IMX_SINKHORN_PREFETCH_NOW", pf)
+            eng.set_option("sinkhorn_prefetch", pf)
             out = _run(eng, data, (1, 1, H, W))
             res[pf] = (out, eng.fetch("u").copy(), eng.fetch("v").copy())
         for i in range(3):

@@ -296,7 +296,7 @@ def test_tile_pair_winograd_form_is_bit_identical_to_the_tile_per_workgroup_form
     number of tiles at the second level: the last pair has a dead tile); ragged 123x165 (partial tiles, masked stores).
     Between two pair-form layers without a pool between them (conv2a -> conv2b, ...) the tensor is TILE-SWIZZLED (the accumulators' own
     lane order, 1 KB per store instruction; whole padded tiles, the consumer zeroes what lies outside the image): pure data movement, so
-    the same bits again -- also against IMX_CONV_SWZ=0, which keeps the pixel-major blocked layout."""
+    the same bits again -- also against "conv_swizzle" = "off", which keeps the pixel-major blocked layout."""
     from image_matching_amd import _lib as L
     from image_matching_amd.engine import Engine
     d = 128
@@ -305,10 +305,7 @@ def test_tile_pair_winograd_form_is_bit_identical_to_the_tile_per_workgroup_form
     xs = torch.cat([util.pair(700 + i, H, W)[i & 1] * (1.0 + (i % 5)) for i in range(B)]).cuda()
     got = {}
     for mode in ("wino_h", "wino", "wino/blocked"):
-        if mode == "wino/blocked":
-            monkeypatch.setenv("IMX_CONV_SWZ", "0")
-        else:
-            monkeypatch.delenv("IMX_CONV_SWZ", raising=False)
+        eng.set_option("conv_swizzle", "off" if mode == "wino/blocked" else "on")
         eng.set_option("conv", mode.split("/")[0])
         assert eng.get_option("conv") == mode.split("/")[0]
         eng.timing_reset()

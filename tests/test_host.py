@@ -26,6 +26,22 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.imx_version()
 
 
+def test_library_exports_nothing_but_the_declared_symbols():
+    """the library is built with -fvisibility=hidden and a linker version script (csrc/imx.map), so its dynamic
+    symbol table is exactly the C ABI of include/imx.h -- none of the ~60 mangled imx::launch_* symbols of round 5, no vague-linkage
+    C++ symbols."""
+    import shutil
+    import subprocess
+    if not shutil.which("nm"):
+        pytest.skip("nm not present")
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    defined = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    header = open(os.path.join(ROOT, "include", "imx.h")).read()
+    declared = set(re.findall(r"\b(imx_[a-z0-9_]+)\s*\(", header))
+    assert defined == declared, f"extra: {sorted(defined - declared)[:8]} missing: {sorted(declared - defined)[:8]}"
+    assert all(re.search(r"^IMX_API [^\n]*\b" + n + r"\(", header, re.M) for n in declared), "an entry point lacks IMX_API"
+
+
 def test_header_is_plain_c_and_the_c_example_links(tmp_path):
     """include/imx.h must be consumable from C (it is the drop-in boundary, not a C++/torch header): the plain-C
     example compiles as C99, links against libimx.so + the HIP runtime only, and -- with no GPU here -- exits through

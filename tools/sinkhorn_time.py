@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Time the Sinkhorn launches of the fused pair path for a few settings of IMX_SINKHORN_GROUP (slabs per workgroup), same process,
+"""Time the Sinkhorn launches of the fused pair path for a few settings of the handle option "sinkhorn_group" (slabs per workgroup), same process,
 same box: tools/sinkhorn_time.py --workload c3 --pairs 64 --groups 1 2 4 8.  Per setting: HIP events around every launch
 (imx_set_timing), ms per step summed over the 'sinkhorn' rows, median of --reps steps."""
 import argparse
@@ -18,7 +18,7 @@ ap.add_argument("--pairs", type=int, default=64)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--workload", default="c3")
 ap.add_argument("--groups", type=int, nargs="+", default=[1, 2, 4, 8])
-ap.add_argument("--prefetch", type=int, nargs="+", default=[None], help="IMX_SINKHORN_PREFETCH_NOW settings to cross with --groups (0 / 1)")
+ap.add_argument("--prefetch", type=int, nargs="+", default=[None], help="\"sinkhorn_prefetch\" settings to cross with --groups (0 / 1)")
 a = ap.parse_args()
 wl = bench.WORKLOADS[a.workload]
 m, *_ = bench.build_matching(wl, torch.device("cuda", 0))
@@ -30,9 +30,9 @@ m.match_batch(i0, i1)
 torch.cuda.synchronize()
 for rnd in range(2):
     for G, PF in [(g, p) for g in a.groups for p in a.prefetch]:
-        os.environ["IMX_SINKHORN_GROUP"] = str(G)
+        eng.set_option("sinkhorn_group", G)
         if PF is not None:
-            os.environ["IMX_SINKHORN_PREFETCH_NOW"] = str(PF)
+            eng.set_option("sinkhorn_prefetch", PF)
         m.match_batch(i0, i1)
         vals, tot = [], []
         for _ in range(a.reps):

@@ -57,8 +57,10 @@ constexpr int VGRP = 2 * VPLANE;               // halves per tile
 constexpr int UPOS = 2 * 4 * 64 * 8;           // halves of U per (item block, chunk, position): [plane][channel block][lane][8]
 constexpr int AMAX_SLOTS = 256;                // image b -> slot b % 256 (conv3x3_wino24h.hip)
 constexpr int RING = 6;                        // of the wave's twelve positions, in flight (NLP % RING == 0)
-constexpr int XCH = 6 * 64 * 16;               // bytes of one wave's exchange block: the row stage's six results for the partner's tile
 constexpr unsigned OOB = 0x7ffffff0u;          // byte offset beyond any image: buffer loads return 0
+#ifndef P_EXP
+#define P_EXP 0      // experiments (tools/tmp_ab): 1 no patch loads, 2 cache-hot patches, 4 patch loads at the end of slot B / stores at the end of slot A, 8 U refills after the half's MFMAs
+#endif
 #ifdef P_TRACE
 // phase clocks (tools/ubench/conv_h_bench.cpp, -DP_TRACE): cycles of wave 0 of every 16th workgroup in each phase of chunk_step
 __device__ long long p_trace_buf[16 * 16];
@@ -151,42 +153,40 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
     vrdS = (const _Float16*)((__attribute__((address_space(3))) unsigned char*)(uintptr_t)b);
   }
 
-  // ---- loader: the 256 threads of tile tg -> two (pixel, channel half) float4 of each of its 10x18x8 sub-patches
-  // (conv3x3_wino24.hip's table; the pixel coordinates are recomputed in loader_tile, once per item, not kept across the main loop)
-  auto loader_slot = [&](int t, int k, int& py, int& px_, int& half) __attribute__((always_inline)) {
-    const int e = (k == 1 && t + 256 < RH * RW * 2) ? t + 256 : t;
-    const int px = p.in_blocked ? e >> 1 : e % (RH * RW);
-    half = p.in_blocked ? e & 1 : e / (RH * RW);
-    py = px / RW - 1;
-    px_ = px % RW - 1;
-    return px * RSC + half * 4;
-  };
+  // ---- loader (round 6): wave (tq, tg) fetches ITS OWN sub-patch -- 10 x 18 pixels x 8 channels = 360 float4, six per lane -- so
+  // the raw patch is private to the wave that transforms it and the store of the next chunk's patch needs no barrier after the
+  // transform that read this chunk's (LDS operations of one wave execute in order).  Blocked / NHWC input: slot k of a lane is the
+  // float4 e = lane + 64 k of the sub-patch (pixel e >> 1, channel half e & 1; e >= 360 falls into the twelve padding pixels of the
+  // sub-patch's 192 and loads zeros).
   // Tile-swizzled input (in_blocked == 2; round 5): the producer (this kernel, out_blocked == 2) wrote the tensor as
   // [image][tile row][tile column][16-channel block][r][x][channel quarter][wtile][4] -- its accumulators' own lane order, 1 KB per store
-  // instruction -- so a tile's 32 channels of a chunk are 16 KB contiguous: thread t takes the float4 t, t + 256, t + 512, t + 768 of
-  // them (pixel (2 wr + r, 4 wc + x): x = t >> 6, r = k & 1, block k >> 1) and up to two of the 52 x 8 float4 of the one-pixel halo
-  // from the neighbouring tiles.
+  // instruction.  The wave's eight channels are two adjacent quarters of block tq >> 1: 512 contiguous bytes per (r, x), four float4
+  // per lane (slot k: r = k >> 1, x = 2 (k & 1) + (lane >> 5)), plus up to two of the 52 x 2 float4 of the one-pixel halo from the
+  // neighbouring tiles.
   constexpr bool inz = INZ;                  // (a template parameter: with both loaders in one kernel their state cost 16 spilled registers)
-  auto halo_slot = [&](int t, int j, int& py, int& px_, int& piece) __attribute__((always_inline)) -> bool {
-    const int hh = t + 256 * j, hp = hh >> 3;
-    piece = hh & 7;
+  constexpr int NLD = 6;                     // float4 per lane and chunk
+  auto halo_slot = [&](int l, int j, int& py, int& px_, int& half) __attribute__((always_inline)) -> bool {
+    const int hh = l + 64 * j, hp = hh >> 1;
+    half = hh & 1;
     py = hp < 18 ? 0 : hp < 36 ? RH - 1 : hp < 44 ? hp - 35 : hp - 43;
     px_ = hp < 18 ? hp : hp < 36 ? hp - 18 : hp < 44 ? 0 : RW - 1;
-    return hh < 52 * 8;
+    return hh < 52 * 2;
   };
-  int ldst[2], ldmain = 0;
+  // LDS store offsets (floats): blocked / NHWC: wave_raw + (lane >> 1) RSC + (lane & 1) 4 + k * 32 RSC; swizzled: the own pixels at
+  // lraw + (k >> 1) RW RSC + (k & 1) 2 RSC, the halo at ldst[j] (lanes without a halo slot write a padding pixel)
+  const int wave_raw = (tg * NSUB + tq) * RAWC;
+  int lraw, ldst[2] = {0, 0};
   if constexpr (inz) {
-    const int t = tid & 255, n = t & 15, kq = (t >> 4) & 3, x = t >> 6;
-    ldmain = tg * NSUB * RAWC + (kq >> 1) * RAWC + ((1 + 2 * (n >> 2)) * RW + 1 + 4 * (n & 3) + x) * RSC + (kq & 1) * 4;
+    const int n = lane & 15;
+    lraw = wave_raw + ((1 + 2 * (n >> 2)) * RW + 1 + 4 * (n & 3) + (lane >> 5)) * RSC + ((lane >> 4) & 1) * 4;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int py, px, piece;
-      halo_slot(t, j, py, px, piece);
-      ldst[j] = tg * NSUB * RAWC + ((piece >> 2) * 2 + ((piece & 3) >> 1)) * RAWC + (py * RW + px) * RSC + (piece & 1) * 4;
+      int py, px, half;
+      const bool used = halo_slot(lane, j, py, px, half);
+      ldst[j] = wave_raw + (used ? (py * RW + px) * RSC + half * 4 : (RH * RW + (lane & 7)) * RSC);
     }
   } else {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { int a, b, c; ldst[k] = tg * NSUB * RAWC + loader_slot(tid & 255, k, a, b, c); }
+    lraw = wave_raw + (lane >> 1) * RSC + (lane & 1) * 4;
   }
   // an item = (pair of consecutive tiles, 64-channel output block); a wave only ever needs ITS tile of the pair.  Items vb + k grid:
   // the host makes grid a multiple of ncob whenever a workgroup has more than one item, so the output block is fixed (vb % ncob) and
@@ -214,68 +214,71 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
   };
   int item_c = vb, lchunk = 0;
   __amdgpu_buffer_rsrc_t lrs;
-  unsigned goff[2], gmain = 0, mmask = 0xfu;                      // (swizzled input: the halo slots, the tile's own block, its rows' validity)
+  unsigned goff[NLD], mmask = 0xfu;                               // (swizzled input: goff[0] the tile's own block, goff[4..5] the halo slots; its rows' validity)
   float lsv;                                                      // s_v of the loader's tile
   const int nblk_in = Cin / 16;                                   // swizzled input: 16-channel blocks of 8 KB per tile
   const int zimg = tiles_x * tiles_y * nblk_in * 8192;            // bytes per image
   const bool inb = p.in_blocked != 0;
   const int pxb = inb ? 8 * 4 : Cin * 4;                          // bytes from one pixel to the next
   const int sub_step = inb ? H * W * 8 * 4 : 8 * 4;               // bytes from one 8-channel group to the next
-  auto loader_tile = [&](const Tile& t) __attribute__((always_inline)) {
-    const int t8 = (wave_s & 3) * 64 + lane_now();
-    int lpy[2], lpx[2], lhalf[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) loader_slot(t8, k, lpy[k], lpx[k], lhalf[k]);
+  auto loader_tile = [&](const Tile& tin) __attribute__((always_inline)) {
+    Tile t = tin;
+    if constexpr ((P_EXP & 2) != 0) { t.x0 &= 1; t.y0 &= 1; t.b = 0; }
+    const int l = lane_now();
     const bool lv = t.live != 0;
     const int b = __builtin_amdgcn_readfirstlane(lv ? t.b : 0);
     lsv = v_scale(amax_c[b & (AMAX_SLOTS - 1)]);
     if constexpr (inz) {
       lrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)b * (zimg >> 2)), 0, lv ? zimg : 0, 0x00020000);
-      const int n = t8 & 15, x = t8 >> 6;
-      gmain = (unsigned)((t.y0 * tiles_x + t.x0) * nblk_in * 8192 + t8 * 16);
-      const bool xin = t.x0 * OW + 4 * (n & 3) + x < W;
-      const int gy0 = t.y0 * OH + 2 * (n >> 2);
-      mmask = ((xin && gy0 < H) ? 5u : 0u) | ((xin && gy0 + 1 < H) ? 10u : 0u);        // bit k: slot k (row r = k & 1) lies inside the image
+      const int n = l & 15;
+      goff[0] = (unsigned)((t.y0 * tiles_x + t.x0) * nblk_in * 8192 + (l & 31) * 16 + (l >> 5) * 1024);
+      const int gx0 = t.x0 * OW + 4 * (n & 3) + (l >> 5), gy0 = t.y0 * OH + 2 * (n >> 2);
+      // bit k: slot k (row r = k >> 1, column x = 2 (k & 1) + (lane >> 5)) lies inside the image
+      mmask = ((gx0 < W && gy0 < H) ? 1u : 0u) | ((gx0 + 2 < W && gy0 < H) ? 2u : 0u) | ((gx0 < W && gy0 + 1 < H) ? 4u : 0u) | ((gx0 + 2 < W && gy0 + 1 < H) ? 8u : 0u);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        int py, px, piece;
-        const bool used = halo_slot(t8, j, py, px, piece);
+        int py, px, half;
+        const bool used = halo_slot(l, j, py, px, half);
         const int gy = t.y0 * OH - 1 + py, gx = t.x0 * OW - 1 + px;
         const bool in = (int)used & (int)lv & (int)((unsigned)gy < (unsigned)H) & (int)((unsigned)gx < (unsigned)W);
-        goff[j] = in ? (unsigned)((((gy >> 3) * tiles_x + (gx >> 4)) * nblk_in + (piece >> 2)) * 8192 + ((gy & 1) * 4 + (gx & 3)) * 1024 + (piece & 3) * 256 +
-                                  (((gy & 7) >> 1) * 4 + ((gx & 15) >> 2)) * 16)
-                     : OOB;
+        goff[4 + j] = in ? (unsigned)(((gy >> 3) * tiles_x + (gx >> 4)) * nblk_in * 8192 + ((gy & 1) * 4 + (gx & 3)) * 1024 + half * 256 +
+                                      (((gy & 7) >> 1) * 4 + ((gx & 15) >> 2)) * 16)
+                         : OOB;
       }
       return;
     }
     lrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)b * H * W * Cin), 0, lv ? img_bytes : 0, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int gy = t.y0 * OH + lpy[k], gx = t.x0 * OW + lpx[k];
-      const bool in = (int)lv & (int)((unsigned)gy < (unsigned)H) & (int)((unsigned)gx < (unsigned)W);
-      goff[k] = in ? (unsigned)((gy * W + gx) * pxb + lhalf[k] * 16) : OOB;
+    for (int k = 0; k < NLD; ++k) {
+      const int e = l + 64 * k, px = e >> 1;
+      const int gy = t.y0 * OH + px / RW - 1, gx = t.x0 * OW + px % RW - 1;
+      const bool in = (int)lv & (int)(px < RH * RW) & (int)((unsigned)gy < (unsigned)H) & (int)((unsigned)gx < (unsigned)W);
+      goff[k] = in ? (unsigned)((gy * W + gx) * pxb + (e & 1) * 16) : OOB;
     }
   };
-  f32x4 rr[NSUB][2];
+  f32x4 rr[NLD];
   float rr_sv = 1.f;                                              // the scale that goes with the registers' chunk
   unsigned rr_mask = 0xfu;                                        // (swizzled input: the validity bits that go with it)
   auto issue_load = [&]() __attribute__((always_inline)) {
-    if constexpr (inz) {                                          // rr[k][0]: the tile's own block, slot k; rr[j][1]: the halo slots
-      const int so = __builtin_amdgcn_readfirstlane(lchunk * 2 * 8192);
+    if constexpr ((P_EXP & 1) != 0) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) rr[k][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)gmain, so + k * 4096, 0));
+      for (int k = 0; k < NLD; ++k) rr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      rr_sv = lsv; rr_mask = mmask;
+      return;
+    }
+    if constexpr (inz) {                                          // rr[0..3]: the tile's own block, slot k; rr[4..5]: the halo slots
+      const int so = __builtin_amdgcn_readfirstlane(lchunk * 2 * 8192 + (tq >> 1) * 8192 + (tq & 1) * 512);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) rr[j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)goff[j], so, 0));
+      for (int k = 0; k < 4; ++k) rr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)goff[0], so + (k >> 1) * 4096 + (k & 1) * 2048, 0));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) rr[4 + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)goff[4 + j], so, 0));
       rr_sv = lsv;
       rr_mask = mmask;
       return;
     }
-    const int so = __builtin_amdgcn_readfirstlane(lchunk * NSUB * sub_step);
+    const int so = __builtin_amdgcn_readfirstlane((lchunk * NSUB + tq) * sub_step);
 #pragma unroll
-    for (int q = 0; q < NSUB; ++q) {
-      rr[q][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)goff[0], so + q * sub_step, 0));
-      rr[q][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)goff[1], so + q * sub_step, 0));
-    }
+    for (int k = 0; k < NLD; ++k) rr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, (int)goff[k], so, 0));
     rr_sv = lsv;
   };
   // (called right before issue_load: the registers of the previous patch are dead by then)
@@ -290,38 +293,28 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
   };
   auto store_raw = [&]() __attribute__((always_inline)) {
     const f32x4 s4 = {rr_sv, rr_sv, rr_sv, rr_sv};
+    auto put = [&](float* d, const f32x4& v) __attribute__((always_inline)) {
+      *reinterpret_cast<f32x2*>(d) = (f32x2){v[0], v[1]};
+      *reinterpret_cast<f32x2*>(d + 2) = (f32x2){v[2], v[3]};
+    };
     if constexpr (inz) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {                               // (pixels of the padded tile outside the image hold the producer's values: zero here)
         const float mk = (rr_mask >> k) & 1u ? 1.f : 0.f;
-        const f32x4 v = rr[k][0] * s4 * (f32x4){mk, mk, mk, mk};
-        float* d = raw + ldmain + (k & 1) * (RW * RSC) + (k >> 1) * (2 * RAWC);
-        *reinterpret_cast<f32x2*>(d) = (f32x2){v[0], v[1]};
-        *reinterpret_cast<f32x2*>(d + 2) = (f32x2){v[2], v[3]};
+        put(raw + lraw + (k >> 1) * (RW * RSC) + (k & 1) * (2 * RSC), rr[k] * s4 * (f32x4){mk, mk, mk, mk});
       }
-      const int t8 = (wave_s & 3) * 64 + lane_now();
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (t8 + 256 * j < 52 * 8) {
-          const f32x4 v = rr[j][1] * s4;
-          float* d = raw + ldst[j];
-          *reinterpret_cast<f32x2*>(d) = (f32x2){v[0], v[1]};
-          *reinterpret_cast<f32x2*>(d + 2) = (f32x2){v[2], v[3]};
-        }
+      for (int j = 0; j < 2; ++j) put(raw + ldst[j], rr[4 + j] * s4);
       return;
     }
 #pragma unroll
-    for (int q = 0; q < NSUB; ++q)
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const f32x4 v = rr[q][k] * s4;
-        float* d = raw + q * RAWC + ldst[k];
-        *reinterpret_cast<f32x2*>(d) = (f32x2){v[0], v[1]};
-        *reinterpret_cast<f32x2*>(d + 2) = (f32x2){v[2], v[3]};
-      }
+    for (int k = 0; k < NLD; ++k) put(raw + lraw + k * (32 * RSC), rr[k] * s4);
   };
 
-  // ---- U ring: slot lp % RING holds local position lp's two planes (eight halves each per lane)
+  // ---- U ring: six slots.  A wave's twelve positions are consumed in two halves of six (transformed rows 0-1, then rows 2-3, of
+  // its three columns: half hb, sequence index q -> local position (q >> 1) * 4 + 2 hb + (q & 1)); slot q holds the q-th position of
+  // the half being multiplied and is refilled in place with the q-th position of the NEXT half (rows 2-3 of this chunk, or rows 0-1
+  // of the next chunk / the next item's block) -- a whole slot of the pipeline (~3 k cycles) ahead of its use
   u32x4 ub[RING][2];
   auto u_load = [&](int slot, int cobv, int chv, int lp) __attribute__((always_inline)) {
     const int pos = lp;                                                            // (+ 12 ph: in uoff_lane)
@@ -329,15 +322,6 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
     ub[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(ur, uoff_lane, so, 0);
     ub[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(ur, uoff_lane, so + 4 * 64 * 16, 0);
   };
-
-  for (int i = tid; i < AMAX_SLOTS; i += 512) amax_tab[i] = 0;       // (visible after the fill's barrier)
-  // ---- pipeline fill: chunk 0 of the first item into raw, the U ring of chunk 0
-  loader_tile(cur);
-  issue_load();
-  store_raw();
-#pragma unroll
-  for (int g = 0; g < RING; ++g) u_load(g, cob, 0, g);
-  __syncthreads();
 
   f32x4 accK[NLP], accS[NLP];    // this wave's positions of the tile it finishes / of its partner's tile; an item's first chunk
                                  // starts every accumulator from a literal-zero C operand
@@ -358,13 +342,15 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
     *reinterpret_cast<f16x2*>(vwr + pos * 512) = h;
     *reinterpret_cast<f16x2*>(vwr + VPLANE + pos * 512) = m;
   };
-  // phase A: this wave's sub-patch (scaled) -> its four transformed rows in the V planes.  Rows of B2^T: r0 - r2, r1 + r2, r2 - r1,
-  // r1 - r3 (as fma(+-1, b, a): conv3x3_wino24h.hip's instruction)
 #ifdef P_TRACE
   long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
-  auto transform = [&]() __attribute__((always_inline)) {
-    f32x2 r1[6], r2[6], rx[6];
+  // Input transform, HALF hb of it: this wave's sub-patch (scaled) -> transformed rows 2 hb, 2 hb + 1 in the V planes.  Rows of
+  // B2^T: r0 - r2, r1 + r2 | r2 - r1, r1 - r3 (as fma(+-1, b, a): conv3x3_wino24h.hip's instruction); each half reads three of the
+  // four patch rows.
+  auto transform_half = [&](auto halfc) __attribute__((always_inline)) {
+    constexpr int HB = decltype(halfc)::value ? 1 : 0;
+    f32x2 ra[6], rb[6], rc[6];
     auto row_load = [&](f32x2 (&d)[6], int row) __attribute__((always_inline)) {
 #pragma unroll
       for (int bb = 0; bb < 6; ++bb) d[bb] = *reinterpret_cast<const f32x2*>(rp + (row * RW + bb) * RSC);
@@ -382,31 +368,30 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
         v_store2(jj * 4 + i, h, m);
       }
     };
-    row_load(r1, 1);
-    row_load(r2, 2);
-    row_load(rx, 0);
-    row_out(1, one2, r2, r1);        // r1 + r2
-    P_STAMP(9)
-    row_out(2, mone2, r1, r2);       // r2 - r1
-    P_STAMP(10)
-    row_out(0, mone2, r2, rx);       // r0 - r2
-    P_STAMP(11)
-    row_load(rx, 3);
-    row_out(3, mone2, rx, r1);       // r1 - r3
-    P_STAMP(12)
+    row_load(ra, HB);              // r0 | r1
+    row_load(rb, HB + 1);          // r1 | r2
+    row_load(rc, HB + 2);          // r2 | r3
+    if constexpr (HB == 0) {
+      row_out(0, mone2, rc, ra);   // r0 - r2
+      row_out(1, one2, rc, rb);    // r1 + r2
+    } else {
+      row_out(2, mone2, ra, rb);   // r2 - r1
+      row_out(3, mone2, rc, ra);   // r1 - r3
+    }
   };
-  // phase B: 72 MFMAs; per position one U fragment (two planes) against the B operands of both tiles; the U slot is refilled in
-  // place with the wave's position lp + RING (of this chunk, or of the next chunk / the next item's block)
-  auto mfma_phase = [&](auto firstc, int c) __attribute__((always_inline)) {
+  // Matrix work, HALF hb of a chunk: 36 MFMAs; per position one U fragment (two planes) against the B operands of both tiles; the
+  // U slot is refilled in place (above)
+  auto mfma_half = [&](auto firstc, auto halfc, int c) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(firstc)::value;
+    constexpr int HB = decltype(halfc)::value ? 1 : 0;
     // (c through an opaque scalar: for an item's first chunk, c == 0, hipcc hoisted (cob nchunk + nch) out of the item loop as a VECTOR
     // value, spilled it, and reloaded it in the middle of this phase -- a scratch reload is a vector-memory operation that is waited
-    // for with vmcnt(0), i.e. behind the six U refills just issued)
+    // for with vmcnt(0), i.e. behind the U refills just issued)
     int cs = c;
     asm volatile("" : "+s"(cs));
     const bool lastc = cs + 1 == nchunk;
     const int nch = lastc ? 0 : cs + 1;
-    // the B operands of position lp + 1 are requested beneath the MFMAs of position lp (without this the phase waits for the LDS
+    // the B operands of the next position are requested beneath the MFMAs of this one (without this the phase waits for the LDS
     // once per position -- ~270 cycles per position and wave against 96 of MFMAs: the trace of the first build)
     f16x8 bq[2][4];              // [buffer][K h, K m, S h, S m]
     auto b_load = [&](int buf, int lp) __attribute__((always_inline)) {
@@ -416,54 +401,141 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
       bq[buf][2] = *reinterpret_cast<const f16x8*>(vrdS + po);
       bq[buf][3] = *reinterpret_cast<const f16x8*>(vrdS + VPLANE + po);
     };
-    b_load(0, 0);
+    b_load(0, 2 * HB);
 #pragma unroll
-    for (int lp = 0; lp < NLP; ++lp) {
-      const int buf = lp & 1;
-      if (lp + 1 < NLP) b_load(buf ^ 1, lp + 1);
+    for (int q = 0; q < RING; ++q) {
+      const int lp = (q >> 1) * 4 + 2 * HB + (q & 1), buf = q & 1;
+      if (q + 1 < RING) b_load(buf ^ 1, ((q + 1) >> 1) * 4 + 2 * HB + ((q + 1) & 1));
       __builtin_amdgcn_sched_barrier(0);
       const f16x8 bKh = bq[buf][0], bKm = bq[buf][1], bSh = bq[buf][2], bSm = bq[buf][3];
-      const f16x8 ah = __builtin_bit_cast(f16x8, ub[lp % RING][0]), am = __builtin_bit_cast(f16x8, ub[lp % RING][1]);
+      const f16x8 ah = __builtin_bit_cast(f16x8, ub[q][0]), am = __builtin_bit_cast(f16x8, ub[q][1]);
       accK[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bKm, FIRST ? zero4c : accK[lp], 0, 0, 0);
       accS[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bSm, FIRST ? zero4c : accS[lp], 0, 0, 0);
       accK[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bKh, accK[lp], 0, 0, 0);
       accS[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bSh, accS[lp], 0, 0, 0);
       accK[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bKh, accK[lp], 0, 0, 0);
       accS[lp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bSh, accS[lp], 0, 0, 0);
-      {
-        const int np = lp + RING;
-        if (np < NLP) u_load(lp % RING, cob, c, np);
-        else u_load(lp % RING, cob, nch, np - NLP);
+      if constexpr ((P_EXP & 8) == 0) {
+        if constexpr (HB == 0) u_load(q, cob, c, (q >> 1) * 4 + 2 + (q & 1));
+        else u_load(q, cob, nch, (q >> 1) * 4 + (q & 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr ((P_EXP & 8) != 0) {
+#pragma unroll
+      for (int q = 0; q < RING; ++q) {
+        if constexpr (HB == 0) u_load(q, cob, c, (q >> 1) * 4 + 2 + (q & 1));
+        else u_load(q, cob, nch, (q >> 1) * 4 + (q & 1));
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // The patches of chunk s + 1 are requested at the START of chunk step s (after the barrier that closes step s - 1, and after the
-  // epilogue when that step ended an item): their registers are dead through the epilogue and the loader's item bookkeeping.
-  auto chunk_step = [&](auto firstc, int c) __attribute__((always_inline)) {
-    P_STAMP(5)                     // (epilogue and item bookkeeping)
-    advance_loader();
-    issue_load();
-    P_STAMP(8)                     // item bookkeeping + patch loads issued
-    transform();
-    P_STAMP(0)
-    __syncthreads();               // V complete; raw free
+  // ---- the pipeline (round 6).  Round 5's chunk step was transform | barrier | 72 MFMAs | barrier with all eight waves in the same
+  // phase: the matrix pipe idle through every transform, the VALU idle through every matrix phase, and whatever a wave waited for
+  // (U from L2, the LDS, the slower waves at the barrier) was nobody's cover.  Here a chunk's V lives in two halves -- transformed
+  // rows 0-1 and rows 2-3, disjoint positions of the same planes -- and every slot between two barriers holds one half transform AND
+  // one half of the matrix work, on different halves:
+  //   slot A(c): rows 2-3 of chunk c      | MFMAs on rows 0-1 of chunk c     | the raw patch of chunk c + 1 (registers -> LDS)
+  //   slot B(c): rows 0-1 of chunk c + 1  | MFMAs on rows 2-3 of chunk c     | (the global loads of chunk c + 2 issued first)
+  // The waves of position half 0 run transform-then-MFMAs, those of half 1 MFMAs-then-transform: the two waves of a SIMD (w, w + 4)
+  // are in opposite kinds of work.  Same instructions on the same values in the same per-accumulator order as round 5's form:
+  // bit-identical to conv3x3_wino24h.
+  auto slot_a = [&](auto ordc, auto firstc, int c) __attribute__((always_inline)) {
+    P_STAMP(5)
+    if constexpr (!decltype(ordc)::value) {
+      transform_half(BoolC<true>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((P_EXP & 4) == 0) store_raw();
+      P_STAMP(0)
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_half(firstc, BoolC<false>{}, c);
+      P_STAMP(2)
+      if constexpr ((P_EXP & 4) != 0) { __builtin_amdgcn_sched_barrier(0); store_raw(); }
+    } else {
+      mfma_half(firstc, BoolC<false>{}, c);
+      P_STAMP(2)
+      __builtin_amdgcn_sched_barrier(0);
+      transform_half(BoolC<true>{});
+      __builtin_amdgcn_sched_barrier(0);
+      store_raw();
+      P_STAMP(0)
+    }
+    __syncthreads();               // rows 2-3 of chunk c complete, rows 0-1 consumed
     P_STAMP(1)
-    mfma_phase(firstc, c);
-    P_STAMP(2)
-    store_raw();                   // the next chunk's patch (requested at the start of this step)
-    P_STAMP(3)
-    __syncthreads();               // raw complete; V free
+  };
+  auto slot_b = [&](auto ordc, auto firstc, int c) __attribute__((always_inline)) {
+    if constexpr ((P_EXP & 4) == 0) {
+      advance_loader();
+      issue_load();
+    }
+    P_STAMP(8)
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!decltype(ordc)::value) {
+      transform_half(BoolC<false>{});
+      P_STAMP(9)
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_half(firstc, BoolC<true>{}, c);
+      P_STAMP(3)
+    } else {
+      mfma_half(firstc, BoolC<true>{}, c);
+      P_STAMP(3)
+      __builtin_amdgcn_sched_barrier(0);
+      transform_half(BoolC<false>{});
+      P_STAMP(9)
+    }
+    if constexpr ((P_EXP & 4) != 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      advance_loader();
+      issue_load();
+    }
+    __syncthreads();               // rows 0-1 of the next chunk complete, rows 2-3 consumed
     P_STAMP(4)
   };
 
   unsigned amax_run = 0;           // this lane's largest stored value of the current tile (bit pattern; values >= 0 after ReLU, |.| otherwise)
+  // The item loop exists twice -- once per order -- and a wave enters the copy of its position half: inside ONE loop a wave-uniform
+  // branch around the two orders made hipcc merge the 96 accumulators' live ranges at every join (285 spilled registers).
+  auto item_loop = [&](auto ordc) __attribute__((always_inline)) {
+  for (int i = tid; i < AMAX_SLOTS; i += 512) amax_tab[i] = 0;       // (visible after the fill's barrier)
+  // ---- pipeline fill: chunk 0 of the first item into raw, the U ring with rows 0-1 of chunk 0, the loads of chunk 1, rows 0-1
+  loader_tile(cur);
+  issue_load();
+  store_raw();
+#pragma unroll
+  for (int g = 0; g < RING; ++g) u_load(g, cob, 0, (g >> 1) * 4 + (g & 1));
+  advance_loader();
+  issue_load();
+  transform_half(BoolC<false>{});
+  __syncthreads();
+
 #pragma unroll 1
   for (;;) {
-    chunk_step(BoolC<true>{}, 0);
+    slot_a(ordc, BoolC<true>{}, 0);
+    slot_b(ordc, BoolC<true>{}, 0);
 #pragma unroll 1
-    for (int c = 1; c < nchunk; ++c) chunk_step(BoolC<false>{}, c);
+    for (int c = 1; c < nchunk; ++c) {
+      slot_a(ordc, BoolC<false>{}, c);
+      slot_b(ordc, BoolC<false>{}, c);
+    }
 
+    // (experiment 16) the patches of the item after next into L2, one dword per 128-byte line, by LDS-DMA into a dummy region: the
+    // HBM misses of a whole item in one burst, inside the epilogue's quiet window, instead of one bubble in the U stream per chunk
+    if constexpr ((P_EXP & 16) != 0 && !inz) {
+      Tile t2 = step_tile(nxt);
+      const bool lv2 = t2.b < p.B && item_c + 2 * grid < nitems;
+      const int b2 = __builtin_amdgcn_readfirstlane(lv2 ? t2.b : 0);
+      const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (size_t)b2 * H * W * Cin), 0, lv2 ? img_bytes : 0, 0x00020000);
+      const int l = lane_now(), r = l / 6, seg = l - 6 * r;
+      const int gy = t2.y0 * OH - 1 + r, gx0 = t2.x0 * OW - 1;
+      const int first = gx0 < 0 ? 0 : gx0, lastb = ((gx0 + RW < W ? gx0 + RW : W) * pxb) - 4;      // byte range of the row inside the image
+      int off = (gy * W) * pxb + first * pxb + seg * 128;
+      if (off > gy * W * pxb + lastb) off = gy * W * pxb + lastb;
+      const unsigned poff = (r < RH && (unsigned)gy < (unsigned)H && lastb > first * pxb) ? (unsigned)off : OOB;
+      __attribute__((address_space(3))) void* dummy = (__attribute__((address_space(3))) void*)(uintptr_t)(lds0 + (unsigned)(NG * VGRP * 2 + NG * NSUB * RAWC * 4 + AMAX_SLOTS * 4));
+#pragma unroll 1
+      for (int ch = 0; ch < nchunk; ++ch)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, dummy, 4, (int)poff, __builtin_amdgcn_readfirstlane((ch * NSUB + tq) * sub_step), 0, 0);
+    }
     // ---- item done.  The accumulators of the partner's tile go to LDS (the V region: every wave is past the barrier that closed the
     // last matrix phase), the partner's accumulators of THIS wave's tile come back: all 24 positions of 16 channels x 16 wtiles
     typedef __attribute__((address_space(3))) f32x4* lds4p;
@@ -493,15 +565,21 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
     // wave's three columns of both tiles; the six results for the PARTNER's tile go through LDS (half of the twelve accumulators that
     // went before round 5's second form), the partner's six for this wave's tile come back, and the column stage runs on all six
     // columns: the instructions of conv3x3_wino24h's output transform on the same values -- bit-identical.
-    const unsigned xw = lds0 + (unsigned)(wave_s * XCH + lq * 16), xr = lds0 + (unsigned)((wave_s ^ 4) * XCH + lq * 16);
+    // (round 6: the exchange blocks lie in the positions of transformed rows 2-3 of both tiles' planes -- 2 tiles x 2 planes x 12
+    // positions x 1 KB = the 48 KB the eight waves need -- which the last matrix slot has just consumed; rows 0-1 already hold the
+    // next item's first half transform.)  Wave w: tile w >> 2, plane (w >> 1) & 1, positions (3 (w & 1) + (k >> 1)) * 4 + 2 + (k & 1)
+    auto xbase = [&](int w) __attribute__((always_inline)) {
+      return lds0 + (unsigned)((w >> 2) * (VGRP * 2) + ((w >> 1) & 1) * (VPLANE * 2) + ((w & 1) * 12 + 2) * 1024 + lq * 16);
+    };
+    const unsigned xw = xbase(wave_s), xr = xbase(wave_s ^ 4);
     f32x4 sK0[3], sK1[3];
     {
       f32x4 sS0[3], sS1[3];
 #pragma unroll
       for (int jj = 0; jj < 3; ++jj) {
         w24_out_rows(accS[jj * 4 + 0], accS[jj * 4 + 1], accS[jj * 4 + 2], accS[jj * 4 + 3], sS0[jj], sS1[jj]);
-        *(lds4p)(uintptr_t)(xw + (2 * jj) * 1024) = sS0[jj];
-        *(lds4p)(uintptr_t)(xw + (2 * jj + 1) * 1024) = sS1[jj];
+        *(lds4p)(uintptr_t)(xw + (4 * jj) * 1024) = sS0[jj];
+        *(lds4p)(uintptr_t)(xw + (4 * jj + 1) * 1024) = sS1[jj];
       }
 #pragma unroll
       for (int jj = 0; jj < 3; ++jj) w24_out_rows(accK[jj * 4 + 0], accK[jj * 4 + 1], accK[jj * 4 + 2], accK[jj * 4 + 3], sK0[jj], sK1[jj]);
@@ -510,8 +588,8 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
     f32x4 gs0[3], gs1[3];
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) {
-      gs0[jj] = *(lds4p)(uintptr_t)(xr + (2 * jj) * 1024);
-      gs1[jj] = *(lds4p)(uintptr_t)(xr + (2 * jj + 1) * 1024);
+      gs0[jj] = *(lds4p)(uintptr_t)(xr + (4 * jj) * 1024);
+      gs1[jj] = *(lds4p)(uintptr_t)(xr + (4 * jj + 1) * 1024);
     }
     __syncthreads();               // (the next transform overwrites the region)
     P_STAMP(6)
@@ -607,6 +685,13 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
     if (item_c >= nitems) break;
     cur = nxt;
   }
+  };
+#if defined(P_ORDER) && P_ORDER == 0
+  item_loop(BoolC<false>{});       // (experiment: every wave transform-then-MFMAs)
+#else
+  if (ph == 0) item_loop(BoolC<false>{});
+  else item_loop(BoolC<true>{});
+#endif
   if (p.amax_out) {
     __syncthreads();
     for (int i = tid; i < AMAX_SLOTS; i += 512)
@@ -628,7 +713,7 @@ hipError_t launch_p2(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = (a.W + OW - 1) / OW, tiles_y = (a.H + OH - 1) / OH;
   const int ntiles = tiles_x * tiles_y * a.B;
   const int nitems = ((ntiles + NG - 1) / NG) * (a.Cout / NT);
-  const size_t lds = (size_t)NG * VGRP * 2 + (size_t)NG * NSUB * RAWC * sizeof(float) + AMAX_SLOTS * sizeof(unsigned);
+  const size_t lds = (size_t)NG * VGRP * 2 + (size_t)NG * NSUB * RAWC * sizeof(float) + AMAX_SLOTS * sizeof(unsigned) + ((P_EXP & 16) ? 256 : 0);
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
@@ -656,10 +741,10 @@ hipError_t launch_p(const ConvArgs& a, hipStream_t s) {
 void conv_p_trace_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(p_trace_buf), sizeof(long long) * 16 * 16); }
 #endif
 
-// (the tile-swizzled tensors are addressed with 32-bit byte offsets of the PADDED tile grid, which must stay below the out-of-bounds
-// sentinel too: an image just under the limit with H % 8 or W % 16 != 0 would wrap -- ADVICE r5)
+// (the pipeline runs two chunks ahead of the matrix work: at least two chunks per item; the tile-swizzled tensors are addressed
+// with 32-bit byte offsets of the PADDED tile grid, which must stay below the out-of-bounds sentinel too: ADVICE r5)
 bool conv3x3_wino24p_supported(const ConvArgs& a) {
-  if (!conv3x3_wino24h_supported(a)) return false;
+  if (!conv3x3_wino24h_supported(a) || a.Cin < 2 * CKH) return false;
   const size_t padded = (size_t)((a.H + OH - 1) / OH * OH) * ((a.W + OW - 1) / OW * OW) * 4;
   return padded * a.Cin < (size_t)OOB && padded * a.Cout < (size_t)OOB;
 }
