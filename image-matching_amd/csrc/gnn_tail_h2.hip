@@ -8,7 +8,7 @@
 // (gnn_tail_pack_h2: each matrix's largest |value| to [2^13, 2^14)).  The activations' come from BOUNDS that are uniform over a wave (its
 // 32 rows belong to one (side, pair)):
 //     |[x | att]| <= bound_in = max(amax_x, amax_v)      amax_x: the (side, pair)'s largest |x| over its valid rows, written by the kernel that
-//                                                        produced x (this kernel's epilogue for the previous layer; rows_amax for layer 0);
+//                                                        produced x (this kernel's epilogue for the previous layer; rows_amax (gemm_h2.hip) for layer 0);
 //                                                        amax_v: the key side's largest |v| (att is a convex combination of v rows)
 //     |hidden|    <= bound_h  = bound_in L1(W1') + max|b1|           (largest column L1 norm of the folded mlp.0)
 //     |x'|        <= bound_x  = amax_x + bound_h L1(W2) + max|b2|
@@ -309,32 +309,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gnn_tail_h2_kernel(GnnTailArg
 }
 
 }  // namespace
-
-namespace {
-// max |x| over the valid rows of every (side, pair): grid (chunks, 2 B), 256 threads = 8 rows x 32 float4 (d = 128)
-__global__ __launch_bounds__(256) void rows_amax_kernel(const float* x, int B, int N0p, int N1p, const int* n0, const int* n1, int N0, int N1, unsigned* amax) {
-  const int side = blockIdx.y / B, b = blockIdx.y % B;
-  const int Np = side ? N1p : N0p;
-  const int n = side ? (n1 ? n1[b] : N1) : (n0 ? n0[b] : N0);
-  const size_t base = (side ? (size_t)B * N0p : 0) + (size_t)b * Np;
-  const u32x4* src = reinterpret_cast<const u32x4*>(x) + base * 32 + (threadIdx.x & 31);
-  unsigned mx = 0;
-  for (int r = blockIdx.x * 8 + (threadIdx.x >> 5); r < n; r += gridDim.x * 8) {
-    const u32x4 v = src[(size_t)r * 32];
-    mx = max(mx, max(max(v[0] & 0x7fffffffu, v[1] & 0x7fffffffu), max(v[2] & 0x7fffffffu, v[3] & 0x7fffffffu)));
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
-  if ((threadIdx.x & 63) == 0 && mx) atomicMax(amax + blockIdx.y, mx);
-}
-}  // namespace
-
-hipError_t launch_rows_amax(const float* x, int d, int B, int N0p, int N1p, const int* n0, const int* n1, int N0, int N1, unsigned* amax, hipStream_t s) {
-  if (d != 128 || B <= 0) return hipErrorInvalidValue;
-  const int nmax = N0p > N1p ? N0p : N1p;
-  hipLaunchKernelGGL(rows_amax_kernel, dim3((unsigned)(nmax >= 512 ? 8 : 1), (unsigned)(2 * B)), dim3(256), 0, s, x, B, N0p, N1p, n0, n1, N0, N1, amax);
-  return hipGetLastError();
-}
 
 bool gnn_tail_h2_supported(const GnnTailArgs& a) {
   if (!a.stream_h2 || !a.amax_x_in || !a.amax_v || !(a.w1_inv > 0.f) || !(a.w2_inv > 0.f) || !(a.w3_inv > 0.f)) return false;

@@ -56,6 +56,9 @@ struct GemmW {
   float* w = nullptr;
   float* wx3 = nullptr;   // the same weights as three bf16 terms per value in MFMA fragment order (split_bf16x3; gemm_x3.hip)
   float* wf = nullptr;    // the same fp32 weights in the B-fragment order of gnn_small.hip (fragment_order; K % 16 == 0 only)
+  float* wh2 = nullptr;   // the same weights as two fp16 planes of w s in MFMA fragment order (split_f16x2; gemm_h2.hip), 1 / s, and how far
+  float wh2_inv = 0.f;    // the largest |w| sits above the median over output columns of their largest |w| (the guard of the fp16 form:
+  float wh2_spread = 0.f; // beyond kConvSpreadMax the typical column loses its low plane and the layer stays on gemm_x3)
   float* b = nullptr;
   int K = 0, N = 0, Npad = 0;
 };
@@ -381,11 +384,46 @@ std::vector<float> fragment_order(const std::vector<float>& w, int K, int Npad) 
   return f;
 }
 
+// w s = h + m with two fp16 planes, s = the power of two that brings max |w| to [2^13, 2^14) (round-to-nearest-even, subnormals kept:
+// exact to 2^-38 of max |w|), in the fragment order of v_mfma_f32_32x32x16_f16's B operand: [column block of 32][16-k step][plane]
+// [lane = (col & 31) + 32 kb][8] holds W[16 st + 8 kb + j][32 nb + (col & 31)].  Returns 1 / s and the spread (GemmW::wh2_spread).
+std::vector<float> split_f16x2(const std::vector<float>& w, int K, int N, int Npad, float* s_inv, float* spread) {
+  const int nst = K / 16;
+  double mx = 0.0;
+  std::vector<double> colmax(N > 0 ? N : 1, 0.0);
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < N; ++n) {
+      const double a = std::fabs((double)w[(size_t)k * Npad + n]);
+      colmax[n] = std::max(colmax[n], a);
+      mx = std::max(mx, a);
+    }
+  std::nth_element(colmax.begin(), colmax.begin() + colmax.size() / 2, colmax.end());
+  const double med = colmax[colmax.size() / 2];
+  *spread = (float)std::min(1e30, med > 0 ? mx / med : (mx > 0 ? 1e30 : 1.0));
+  int e = 0;
+  if (mx > 0) std::frexp(mx, &e);
+  const double sc = std::ldexp(1.0, 14 - e);
+  *s_inv = (float)(1.0 / sc);
+  std::vector<uint16_t> pl((size_t)2 * Npad * K);
+  for (int k = 0; k < K; ++k)
+    for (int n = 0; n < Npad; ++n) {
+      const float x = (float)((double)w[(size_t)k * Npad + n] * sc);
+      const uint16_t hh = gt_f16_rne(x), mm = gt_f16_rne(x - gt_f16_f(hh));
+      const int nb = n >> 5, st = k >> 4, lane = (n & 31) + 32 * ((k >> 3) & 1), j = k & 7;
+      pl[((((size_t)nb * nst + st) * 2 + 0) * 64 + lane) * 8 + j] = hh;
+      pl[((((size_t)nb * nst + st) * 2 + 1) * 64 + lane) * 8 + j] = mm;
+    }
+  std::vector<float> out((pl.size() + 1) / 2);
+  memcpy(out.data(), pl.data(), pl.size() * sizeof(uint16_t));
+  return out;
+}
+
 int upload_gemm(imx_handle_t h, GemmW& out, const std::vector<float>& w, const std::vector<float>& b, int K, int N, int Npad,
                 const char* what) {
   out.w = upload(h, w);
   out.wf = (K % 16 == 0 && K <= 512 && N == Npad) ? upload(h, fragment_order(w, K, Npad)) : nullptr;
   out.wx3 = upload(h, split_bf16x3(w, K, Npad));
+  if (K % 32 == 0 && Npad % 64 == 0) out.wh2 = upload(h, split_f16x2(w, K, N, Npad, &out.wh2_inv, &out.wh2_spread));
   out.b = upload(h, b);
   out.K = K;
   out.N = N;
@@ -517,6 +555,7 @@ int finalize_superglue(imx_handle_t h) {
       host_qkv.push_back(w);
       L.qkv.w = upload(h, w);
       L.qkv.wx3 = upload(h, split_bf16x3(w, d, N));
+      if (d % 32 == 0 && N % 64 == 0) L.qkv.wh2 = upload(h, split_f16x2(w, d, N, N, &L.qkv.wh2_inv, &L.qkv.wh2_spread));
       L.qkv.wf = (d % 16 == 0) ? upload(h, fragment_order(w, d, N)) : nullptr;
       L.qkv.b = upload(h, b);
       L.qkv.K = d;
@@ -594,21 +633,48 @@ int pad32(int n) { return ((n + 31) / 32) * 32; }
 
 // `am` (optional; the q|k|v projection): where the maxima of the output's thirds over the valid rows go if the throughput form can
 // write them from its epilogue; am->done says whether it did (else the caller runs launch_qkv_amax)
-struct GemmAmax { unsigned* amax; const int* n0; const int* n1; int B, N0p, N1p, N0, N1; bool done; };
+// What a linear layer of the GNN needs beside its operands: the (side, pair) row structure and, optionally, the q|k|v maxima its
+// epilogue should write (amax: gemm_x3 / gemm_h2), the scale sources of gemm_h2's A operand (sa0 / sa1) and the word its epilogue
+// should leave for the next kernel (amax_row).  done / h2: what the launch actually did.
+struct GemmAmax {
+  unsigned* amax; const int* n0; const int* n1; int B, N0p, N1p, N0, N1; bool done;
+  const unsigned* sa0 = nullptr; int sa0_stride = 1, sa0_off = 0;
+  const unsigned* sa1 = nullptr; int sa1_stride = 1, sa1_off = 0, sa1_cross = 0;
+  unsigned* amax_row = nullptr; int amax_row_stride = 1, amax_row_off = 0;
+  bool want_h2 = false, h2 = false;
+};
+constexpr float kLinearSpreadMax = 16384.f;      // the guard of gemm_h2's weight planes (GemmW::wh2_spread; the same 2^14 as the convolutions')
+bool gemm_h2_weights_ok(const GemmW& W) { return W.wh2 && W.wh2_inv > 0.f && W.wh2_spread <= kLinearSpreadMax && W.K % 32 == 0 && W.Npad % 64 == 0; }
 int gemm(imx_handle_t h, hipStream_t s, const char* name, const GemmW& W, const float* a0, int lda0, int K0, const float* a1,
          int lda1, int K1, const float* res, int ldr, float* out, int ldo, int M, bool relu, GemmAmax* am = nullptr) {
   if (K0 + K1 != W.K) return fail(h, "internal: gemm '%s' K mismatch (%d+%d vs %d)", name, K0, K1, W.K);
   GemmArgs g{a0, lda0, K0, a1, lda1, K1, W.w, W.b, res, ldr, out, ldo, M, W.N, W.Npad, relu ? 1 : 0};
-  if (am) am->done = false;
-  // Three forms, each with its reason:
+  if (am) { am->done = false; am->h2 = false; }
+  // Four forms, each with its reason:
   //   gemm_small  M <= 4096 rows (one or two pairs): the latency form ("latency_forms": auto / off / on);
-  //   gemm_x3     the throughput form: fp32 products as six bf16 term products on the bf16 matrix pipe;
+  //   gemm_h2     the GNN's plain linear layers in the throughput path: three fp16 plane products, operands scaled by their actual
+  //               (side, pair) maxima ("linear" = auto / f16x2; the caller decides it for the whole chain: want_h2);
+  //   gemm_x3     the throughput form of everything else: fp32 products as six bf16 term products on the bf16 matrix pipe;
   //   gemm_tiled  fp32 MFMA: the "mfma" = "f32" A/B reference of the parity tests and the fallback for shapes gemm_x3 rejects.
   // Measured per layer inside the C3 step (64 pairs, gemm_x3 vs the fp32-MFMA forms of round 2): mlp.0 1.85 vs 2.57 ms, mlp.3
   // 1.11 vs 1.45, convPb 0.23 vs 0.51, convDb 0.25 vs 0.35, q|k|v 2.06 vs 2.08.
   const Options& o = h->opt;
   const bool small = gemm_small_supported(g) && (o.latency_forms >= 0 ? o.latency_forms != 0 : M <= 4096);
   const bool x3 = !small && !o.mfma_f32 && W.wx3 && gemm_x3_supported(g);
+  if (am && am->want_h2) {
+    GemmArgs gh = g;
+    gh.amax = am->amax; gh.an0 = am->n0; gh.an1 = am->n1; gh.aB = am->B; gh.aN0p = am->N0p; gh.aN1p = am->N1p; gh.aN0 = am->N0; gh.aN1 = am->N1;
+    gh.sa0 = am->sa0; gh.sa0_stride = am->sa0_stride; gh.sa0_off = am->sa0_off;
+    gh.sa1 = am->sa1; gh.sa1_stride = am->sa1_stride; gh.sa1_off = am->sa1_off; gh.sa1_cross = am->sa1_cross;
+    gh.amax_row = am->amax_row; gh.amax_row_stride = am->amax_row_stride; gh.amax_row_off = am->amax_row_off;
+    gh.w_inv = W.wh2_inv;
+    if (small || o.mfma_f32 || !gemm_h2_weights_ok(W) || !gemm_h2_supported(gh))
+      return fail(h, "internal: gemm '%s' was planned on fp16 planes but cannot run there", name);
+    am->done = am->amax != nullptr;
+    am->h2 = true;
+    RUN(name, launch_gemm_h2(gh, W.wh2, s));
+    return 0;
+  }
   if (am && am->amax && x3) {
     GemmArgs ga = g;
     ga.amax = am->amax; ga.an0 = am->n0; ga.an1 = am->n1; ga.aB = am->B; ga.aN0p = am->N0p; ga.aN1p = am->N1p; ga.aN0 = am->N0; ga.aN1 = am->N1;
@@ -904,15 +970,37 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     amax = am;
     amax_x = am + nl * 2 * B * 4;
   }
-  bool have_amax_x = false;
-  // (IMX_QKV_AMAX=kernel: the maxima of a projected q|k|v by the separate pass even where the projection's epilogue can write them --
+  long x_max_layer = -1;       // amax_x + 2 B x_max_layer holds max |x| of the CURRENT x (-1: not computed)
+  // ("qkv_amax" = "kernel": the maxima of a projected q|k|v by the separate pass even where the projection's epilogue can write them --
   // the A/B switch of tests/test_gpu_superglue.py; the two must agree bit for bit)
-  const bool amax_by_kernel = h->opt.qkv_amax != 0;      // "qkv_amax" = "kernel": the bit-identity test's A/B
+  const bool amax_by_kernel = h->opt.qkv_amax != 0;
+  // "linear" = auto / f16x2 (round 6): the plain linear layers of the GNN -- every layer's q|k|v, mlp.0' and mlp.3 where the tail is
+  // not fused (descriptor_dim 256: C5), layer 0's q|k|v and final_proj otherwise -- as three fp16 plane products (gemm_h2.hip), each
+  // operand scaled by its ACTUAL (side, pair) maximum: max |x| from rows_amax (layer 0) or the producing mlp.3's epilogue, max |v|
+  // (which bounds the attention output) from the q|k|v epilogue, max |hidden| from mlp.0's.  Decided for the whole chain: the
+  // two-plane attention's tables exist and its kernel runs, the throughput forms apply, every matrix passes the spread guard.
+  bool lin_h2 = amax && !small_form && h->opt.linear != 0 && N0p % 128 == 0 && N1p % 128 == 0 && R == B * (N0p + N1p) && gemm_h2_weights_ok(h->final_proj);
+  for (const GnnLayer& L : h->layers) lin_h2 = lin_h2 && gemm_h2_weights_ok(L.qkv) && gemm_h2_weights_ok(L.mlp1) && gemm_h2_weights_ok(L.mlp2);
+  {
+    AttnArgs a{};
+    a.B = B; a.N0p = N0p; a.N1p = N1p; a.d = d; a.heads = HEADS; a.mfma_f32 = h->opt.mfma_f32; a.latency_forms = h->opt.latency_forms;
+    lin_h2 = lin_h2 && attention_takes_x3(a);
+  }
+  const size_t nl_ = h->layers.size();
+  auto x_max_now = [&](size_t l) -> int {      // max |x| of the rows about to be projected, unless the kernel that produced x left it
+    if (x_max_layer != (long)l) RUN("rows_amax", launch_rows_amax_any(x, d, B, N0p, N1p, sd[0].n, sd[1].n, N0, N1, amax_x + (size_t)2 * B * l, s));
+    x_max_layer = (long)l;
+    return 0;
+  };
   for (size_t l = 0; l < h->layers.size(); ++l) {
     const GnnLayer& L = h->layers[l];
     if (!have_next) {
       // (the maxima of this q|k|v, if the two-plane attention will want them, out of the projection's epilogue where it can)
       GemmAmax gam{amax && !amax_by_kernel ? amax + 8 * B * l : nullptr, sd[0].n, sd[1].n, B, N0p, N1p, N0, N1, false};
+      if (lin_h2) {
+        if (x_max_now(l)) return -1;
+        gam.want_h2 = true; gam.sa0 = amax_x + (size_t)2 * B * l;
+      }
       if (gemm(h, s, "qkv_proj", L.qkv, x, d, d, nullptr, 0, 0, nullptr, 0, qkv, 3 * d, R, false, &gam)) return -1;
       have_amax = gam.done;
     }
@@ -955,22 +1043,32 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
       ta.cross = c.gnn_layer_is_cross[l];
       ta.n0 = sd[0].n; ta.n1 = sd[1].n; ta.B = B; ta.N0p = N0p; ta.N1p = N1p; ta.N0 = N0; ta.N1 = N1;
       tail_h2 = gnn_tail_h2_supported(ta);
-      if (tail_h2 && !have_amax_x) RUN("rows_amax", launch_rows_amax(x, d, B, N0p, N1p, sd[0].n, sd[1].n, N0, N1, amax_x + (size_t)2 * B * l, s));
+      if (tail_h2 && x_max_now(l)) return -1;
     }
-    have_amax_x = false;
     if (small_form && h->opt.latency_forms != 2 && L.mlp1.Npad == 2 * d && L.mlp2.Npad == d && nx.Npad == nx.N && gnn_layer_small_supported(ga)) {
       RUN("gnn_layer", launch_gnn_layer_small(ga, s));
       have_next = !last;
       have_mdesc = last;
+      x_max_layer = -1;
     } else if (tail) {
       RUN("gnn_tail", tail_h2 ? launch_gnn_tail_h2(ta, s) : launch_gnn_tail_x3(ta, s));
       have_next = !last;
       have_mdesc = last;
       have_amax = ta.amax != nullptr;
-      have_amax_x = tail_h2 && !last;
+      x_max_layer = tail_h2 && !last ? (long)l + 1 : -1;     // (the tail's epilogue leaves max |x'| for the next layer)
     } else {
-      if (gemm(h, s, "gnn_mlp1", L.mlp1, x, d, d, att, d, d, nullptr, 0, hid, 2 * d, R, true)) return -1;   // merge folded in
-      if (gemm(h, s, "gnn_mlp2", L.mlp2, hid, 2 * d, 2 * d, nullptr, 0, 0, x, d, x, d, R, false)) return -1;
+      GemmAmax g1{nullptr, sd[0].n, sd[1].n, B, N0p, N1p, N0, N1, false}, g2 = g1;
+      if (lin_h2) {                      // (x's maximum: this layer's q|k|v projection had it; v's: the attention's table)
+        if (x_max_now(l)) return -1;
+        g1.want_h2 = true; g1.sa0 = amax_x + (size_t)2 * B * l;
+        g1.sa1 = amax + 8 * B * l; g1.sa1_stride = 4; g1.sa1_off = 2; g1.sa1_cross = c.gnn_layer_is_cross[l] ? 1 : 0;
+        g1.amax_row = amax + 8 * B * l; g1.amax_row_stride = 4; g1.amax_row_off = 3;               // max |hidden|: the table's fourth word
+        g2.want_h2 = true; g2.sa0 = amax + 8 * B * l; g2.sa0_stride = 4; g2.sa0_off = 3;
+        g2.amax_row = amax_x + (size_t)2 * B * (l + 1);                                              // max |x'|: the next projection's scale
+      }
+      if (gemm(h, s, "gnn_mlp1", L.mlp1, x, d, d, att, d, d, nullptr, 0, hid, 2 * d, R, true, &g1)) return -1;   // merge folded in
+      if (gemm(h, s, "gnn_mlp2", L.mlp2, hid, 2 * d, 2 * d, nullptr, 0, 0, x, d, x, d, R, false, &g2)) return -1;
+      x_max_layer = lin_h2 ? (long)l + 1 : -1;
     }
     if (h->debug) {
       std::string nm = "gnn" + std::to_string(l);
@@ -979,7 +1077,14 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
       tap(h, nm.c_str(), tg, {R, d});
     }
   }
-  if (!have_mdesc && gemm(h, s, "final_proj", h->final_proj, x, d, d, nullptr, 0, 0, nullptr, 0, mdesc, d, R, false)) return -1;
+  if (!have_mdesc) {
+    GemmAmax gf{nullptr, sd[0].n, sd[1].n, B, N0p, N1p, N0, N1, false};
+    if (lin_h2) {
+      if (x_max_now(nl_)) return -1;
+      gf.want_h2 = true; gf.sa0 = amax_x + (size_t)2 * B * nl_;
+    }
+    if (gemm(h, s, "final_proj", h->final_proj, x, d, d, nullptr, 0, 0, nullptr, 0, mdesc, d, R, false, &gf)) return -1;
+  }
   ScoreArgs sc{mdesc, mdesc + off1 * d, S, B, N0p, N1p, d, (float)(1.0 / std::sqrt((double)d))};
   RUN("score_gemm", launch_score_gemm(sc, s));
   float* part = nullptr;
@@ -1004,7 +1109,8 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
   return 0;
 }
 
-// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | wino_h | wino32 | direct, "gnn_tail" = auto | fused | bf16x3 | unfused, "attention" = auto | f16x2 | bf16x3;
+// "mfma" = x3 | f32, "latency_forms" = auto | off | on | unfused, "conv" = wino | wino_h | wino32 | direct, "gnn_tail" = auto | fused | bf16x3 | unfused, "attention" = auto | f16x2 | bf16x3,
+// "linear" = auto | f16x2 | bf16x3;
 // the A/B switches "conv_swizzle" = on | off, "qkv_amax" = epilogue | kernel, "sinkhorn_group" = auto | 1 | 2 | 4, "sinkhorn_prefetch" = auto | off | on.  Returns 0, or -1 for an unknown key / value.
 int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
   Options& o = h->opt;
@@ -1027,6 +1133,8 @@ int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
     }
     else if (v == "direct") o.conv_direct = 1;
     else return -1;
+  } else if (key == "linear") {
+    if (v == "auto") o.linear = -1; else if (v == "f16x2" || v == "1") o.linear = 1; else if (v == "bf16x3" || v == "x3" || v == "0") o.linear = 0; else return -1;
   } else if (key == "conv_swizzle") {
     if (v == "on" || v == "1") o.conv_swizzle = 1; else if (v == "off" || v == "0") o.conv_swizzle = 0; else return -1;
   } else if (key == "qkv_amax") {
@@ -1093,7 +1201,7 @@ int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
     h->device = device_id;
     h->cfg = *cfg;
     // the environment seeds the options once, here; afterwards only imx_set_option changes them
-    for (const char* key : {"mfma", "latency_forms", "conv", "gnn_tail", "attention"}) {
+    for (const char* key : {"mfma", "latency_forms", "conv", "gnn_tail", "attention", "linear"}) {
       std::string env = std::string("IMX_") + key;
       for (char& ch : env) ch = (char)toupper((unsigned char)ch);
       if (const char* e = getenv(env.c_str()))
@@ -1526,7 +1634,7 @@ int imx_set_option(imx_handle_t h, const char* key, const char* value) {
   return guarded(h, "imx_set_option", [&]() -> int {
     if (!h) return -1;
     if (!key || !value) return fail(h, "imx_set_option: null argument");
-    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino_h|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3, conv_swizzle = on|off, qkv_amax = epilogue|kernel, sinkhorn_group = auto|1|2|4, sinkhorn_prefetch = auto|off|on)", key, value);
+    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino_h|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3, linear = auto|f16x2|bf16x3, conv_swizzle = on|off, qkv_amax = epilogue|kernel, sinkhorn_group = auto|1|2|4, sinkhorn_prefetch = auto|off|on)", key, value);
     return 0;
   });
 }
@@ -1541,6 +1649,7 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : o.conv_f16 == 2 ? "wino_h" : o.conv_f16 ? "wino" : "wino32";
     else if (k == "gnn_tail") h->opt_text = o.gnn_tail < 0 ? "auto" : o.gnn_tail == 2 ? "bf16x3" : o.gnn_tail ? "fused" : "unfused";
     else if (k == "attention") h->opt_text = o.attention < 0 ? "auto" : o.attention ? "f16x2" : "bf16x3";
+    else if (k == "linear") h->opt_text = o.linear < 0 ? "auto" : o.linear ? "f16x2" : "bf16x3";
     else if (k == "conv_swizzle") h->opt_text = o.conv_swizzle ? "on" : "off";
     else if (k == "qkv_amax") h->opt_text = o.qkv_amax ? "kernel" : "epilogue";
     else if (k == "sinkhorn_group") h->opt_text = o.sinkhorn_group ? std::to_string(o.sinkhorn_group) : std::string("auto");

@@ -28,6 +28,9 @@ struct Options {
   int qkv_amax = 0;        // "qkv_amax": 0 = "epilogue" (a plain q|k|v projection's epilogue writes the (side, pair) maxima), 1 = "kernel" (the separate pass)
   int sinkhorn_group = 0;  // "sinkhorn_group": 0 = "auto" (2 slabs per workgroup up to 1024 columns, 4 above, 1 below 64 slabs), 1 | 2 | 4
   int sinkhorn_prefetch = -1;  // "sinkhorn_prefetch": -1 = "auto" (on for the 16-wave form), 0 = "off", 1 = "on"
+  int linear = -1;         // "linear": -1 = "auto" = 1 = "f16x2" (gemm_h2: the GNN's plain linear layers -- q|k|v, mlp.0', mlp.3, final_proj where the
+                           //         layer tail is not fused -- as three fp16 plane products, scaled by the operands' actual (side, pair) maxima; needs
+                           //         "attention" = f16x2 and weights inside the spread guard), 0 = "bf16x3" (gemm_x3: six bf16 plane products)
 };
 
 // The form a launcher picked ("gemm_x3:bf16x3", "conv3x3_wino24:f32", ...: kernel family, then the matrix pipe it runs on or
@@ -114,8 +117,23 @@ struct GemmArgs {
   unsigned* amax;
   const int* an0; const int* an1;
   int aB, aN0p, aN1p, aN0, aN1;
+  // gemm_h2 only (two fp16 planes per operand; gemm_h2.hip).  The A operand of a 128-row tile is scaled by the power of two that brings
+  // max(sa0[sp sa0_stride + sa0_off], sa1[sp' sa1_stride + sa1_off]) to 2^13: words (bit patterns of max |value| over the valid rows
+  // of (side, pair) sp = side aB + pair) written by the kernels that produced a0 / a1 (sa1 null: a0 alone; sa1_cross: sp' is the pair
+  // on the OTHER side -- the attention output of a cross layer is bounded by the key side's max |v|).  amax_row (optional): max |out|
+  // over the valid rows of each (side, pair), all columns, into amax_row[sp amax_row_stride + amax_row_off].  w_inv: 1 / (the power of
+  // two the fp16 weight planes were scaled by).  Rows as for `amax`: aB, aN0p, aN1p (% 128 == 0), an0 / an1, aN0 / aN1.
+  const unsigned* sa0; int sa0_stride, sa0_off;
+  const unsigned* sa1; int sa1_stride, sa1_off, sa1_cross;
+  unsigned* amax_row; int amax_row_stride, amax_row_off;
+  float w_inv;
 };
 bool gemm_x3_amax_supported(const GemmArgs& a);
+// wh2 = the weights as two fp16 planes of w s in B-fragment order [Npad/32][K/16][2][64][8] (imx_api.cpp: split_f16x2)
+bool gemm_h2_supported(const GemmArgs& a);
+hipError_t launch_gemm_h2(const GemmArgs& a, const void* wh2, hipStream_t s);
+// max |x| over the valid rows of every (side, pair), rows of d floats (d % 4 == 0): what gnn_tail_h2 / gemm_h2 scale layer 0's x by
+hipError_t launch_rows_amax_any(const float* x, int d, int B, int N0p, int N1p, const int* n0, const int* n1, int N0, int N1, unsigned* amax, hipStream_t s);
 // (K0, K1) % 32 == 0.
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 // The tail of one GNN layer for small row counts, fused (gnn_small.hip): hidden = relu([x | att] w1 + b1); x += hidden w2 + b2;
@@ -263,7 +281,6 @@ hipError_t launch_gnn_tail_x3(const GnnTailArgs& a, hipStream_t s);
 bool gnn_tail_h2_supported(const GnnTailArgs& a);
 hipError_t launch_gnn_tail_h2(const GnnTailArgs& a, hipStream_t s);
 // max |x| over the valid rows of every (side, pair) of a [B (N0p + N1p)][d] tensor -> amax[2 B] (zeroed words), d = 128: layer 0's amax_x_in
-hipError_t launch_rows_amax(const float* x, int d, int B, int N0p, int N1p, const int* n0, const int* n1, int N0, int N1, unsigned* amax, hipStream_t s);
 
 // both products as six bf16 term products on the bf16 matrix pipe (attention_x3.hip): head dim 32 or 64
 bool attention_x3_supported(const AttnArgs& a);

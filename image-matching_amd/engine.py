@@ -320,7 +320,9 @@ class Engine:
     # ------------------------------------------------------------------ kernel-form options (include/imx.h: imx_set_option)
     def set_option(self, key, value):
         """'mfma' = 'x3' | 'f32', 'latency_forms' = 'auto' | 'off' | 'on' | 'unfused', 'conv' = 'wino' | 'wino_h' | 'wino32' | 'direct',
-        'gnn_tail' = 'auto' | 'fused' | 'bf16x3' | 'unfused', 'attention' = 'auto' | 'f16x2' | 'bf16x3'."""
+        'gnn_tail' = 'auto' | 'fused' | 'bf16x3' | 'unfused', 'attention' = 'auto' | 'f16x2' | 'bf16x3', 'linear' = 'auto' | 'f16x2' | 'bf16x3';
+        the A/B switches 'conv_swizzle' = 'on' | 'off', 'qkv_amax' = 'epilogue' | 'kernel', 'sinkhorn_group' = 'auto' | 1 | 2 | 4,
+        'sinkhorn_prefetch' = 'auto' | 'off' | 'on' (include/imx.h)."""
         self._check(self.lib.imx_set_option(self.handle, key.encode(), str(value).encode()))
         return self
 

@@ -245,6 +245,14 @@ IMX_API const char* imx_timing_form(imx_handle_t h, int index);
  *                           weights into TWO fp16 planes (22 bits; every operand scaled by a power of two taken from the maximum of its
  *                           (side, pair) over the valid rows) and keeps three term products per k-step; "bf16x3" three bf16 planes and
  *                           six term products (the A/B reference; both are closer to a float64 evaluation than the fp32 MFMA form).
+ *   "linear"         "auto" (default) = "f16x2": the plain linear layers of the GNN in the throughput path (every layer's q|k|v, mlp.0',
+ *                           mlp.3 and final_proj where the layer tail is not fused -- descriptor_dim 256 --, layer 0's q|k|v otherwise) as
+ *                           three fp16 plane products (gemm_h2): both operands as two fp16 planes, the weights scaled by one power of
+ *                           two per matrix, the activations by the power of two of their ACTUAL maximum over the valid rows of each
+ *                           (side, pair) -- written by the producing kernel's epilogue (the attention output by max |v|, of whose rows
+ *                           it is a convex combination).  Needs "attention" = f16x2 (its tables carry the maxima), padded keypoint
+ *                           counts that are multiples of 128 and weights inside the spread guard (largest |w| at most 2^14 above the
+ *                           median column's largest); otherwise, and under "bf16x3", gemm_x3's six bf16 plane products;
  * A/B switches of the bit-identity tests and of tools/ (results agree bit for bit, the Sinkhorn group to 2e-6 in the potentials with
  * equal matches); none of them is read from the environment:
  *   "conv_swizzle"      "on" (default) the tensor between two pair-form 3x3 layers without a pool is tile-swizzled; "off": blocked;

@@ -253,7 +253,7 @@ def test_bench_through_the_driver_launch_line_with_rccl():
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] == "weak" and "roofline" in line
     # what was timed is checked against the reference's committed outputs in the same process (pairs 0..3 = sweep seeds 1000..1003)
     assert line["parity_in_run"]["pairs"] == 4 and line["parity_in_run"]["unexplained"] == 0
-    assert line["roofline"]["kernels"]["qkv_proj"]["form"] in ("gemm_x3:bf16x3", "gemm_small:f32")
+    assert line["roofline"]["kernels"]["qkv_proj"]["form"] in ("gemm_h2:f16x2", "gemm_x3:bf16x3", "gemm_small:f32")
 
 
 def test_bench_default_invocation_prints_exactly_one_line():

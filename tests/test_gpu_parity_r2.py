@@ -298,7 +298,7 @@ def test_unselected_seed_sweep_as_one_batched_call(name, B):
     out = m.match_batch(i0, i1)
     torch.cuda.synchronize()
     forms = {r[0]: r[3] for r in _forms_of_a_step(m, i0, i1)}
-    assert forms["qkv_proj"] == "gemm_x3:bf16x3" and forms["attention"] == "attention_h2:f16x2" and forms["conv2a"] == "conv3x3_wino24p:f16x2", forms
+    assert forms["qkv_proj"] == "gemm_h2:f16x2" and forms["attention"] == "attention_h2:f16x2" and forms["conv2a"] == "conv3x3_wino24p:f16x2", forms
     k0, k1, m0 = out["keypoints0"].cpu().numpy(), out["keypoints1"].cpu().numpy(), out["matches0"].cpu().numpy()
     assert (out["counts0"].cpu().numpy() == K).all() and (out["counts1"].cpu().numpy() == K).all()
     results = [util.sweep_compare_end_to_end(g, b % n, k0[b], k1[b], m0[b]) for b in range(B)]

@@ -46,12 +46,14 @@ def _pair_taps(eng, K):
     return x[:K].T, x[Kp:Kp + K].T
 
 
-@pytest.mark.parametrize("forms,mfma,attention", [("auto", "x3", "auto"), ("off", "x3", "auto"), ("off", "x3", "bf16x3"), ("off", "f32", "auto")])
+@pytest.mark.parametrize("forms,mfma,attention,linear", [("auto", "x3", "auto", "auto"), ("off", "x3", "auto", "auto"), ("off", "x3", "auto", "bf16x3"),
+                                                        ("off", "x3", "bf16x3", "auto"), ("off", "f32", "auto", "auto")])
 @pytest.mark.parametrize("name", ["strict_c3.npz", "strict_c5.npz"])
-def test_strict_bar_superglue_every_form(name, forms, mfma, attention):
+def test_strict_bar_superglue_every_form(name, forms, mfma, attention, linear):
     """SuperGlue alone, the reference's keypoints injected, on every kernel form a caller can reach (latency forms; the
-    throughput forms bench.py times -- attention on two fp16 planes; the same with attention on three bf16 planes; their fp32-MFMA
-    counterparts): gnn17, scores_in and Z element-wise inside
+    throughput forms bench.py times -- attention and the plain linear layers (gemm_h2: every layer's q|k|v, mlp.0', mlp.3 at d = 256,
+    layer 0's q|k|v at d = 128) on two fp16 planes; the same with the linear layers on three bf16 planes ("linear" = bf16x3); with the
+    attention on three bf16 planes (which takes the linear layers there too); their fp32-MFMA counterparts): gnn17, scores_in and Z element-wise inside
     1e-4 + 1e-4|ref| of the oracle's (every element) and of the reference's (fixture samples); matches0 / matches1 equal to the
     reference's; matching scores at the same tolerance."""
     g, per_seed = _strict_inputs(name)
@@ -61,21 +63,32 @@ def test_strict_bar_superglue_every_form(name, forms, mfma, attention):
     eng = Engine(util.sp_config(d, K), util.sg_config(d), "cuda")
     sd_sg = util.sg_sd(d, variant="t")
     eng.load_state_dict(L.NET_SUPERGLUE, sd_sg)
-    eng.set_option("latency_forms", forms).set_option("mfma", mfma).set_option("attention", attention)
+    eng.set_option("latency_forms", forms).set_option("mfma", mfma).set_option("attention", attention).set_option("linear", linear)
     eng.set_debug(True)
     alpha = float(sd_sg["bin_score"])
+    want_h2 = forms == "off" and mfma == "x3" and attention == "auto" and linear == "auto"
     worst = {"gnn17": 0.0, "scores_in": 0.0, "Z": 0.0, "mscores": 0.0}
     thr, band, other = float(util.sg_config(d)["match_threshold"]), 0, 0
     for s, seed in enumerate(g["seeds"]):
         data, ref = per_seed[s]
+        if s == 0:
+            eng.timing_reset()
+            eng.set_timing(True)
         out = eng.superglue(data["keypoints0"].cuda(), data["scores0"].cuda(), data["descriptors0"].cuda(), (1, 1, H, W),
                             data["keypoints1"].cuda(), data["scores1"].cuda(), data["descriptors1"].cuda(), (1, 1, H, W))
         torch.cuda.synchronize()
+        if s == 0:                        # the forms that ran are the forms the parameters name
+            ran = {r[0]: r[3] for r in eng.timing_report(forms=True)}
+            eng.set_timing(False)
+            if forms == "off" and mfma == "x3":
+                assert ran["qkv_proj"] == ("gemm_h2:f16x2" if want_h2 else "gemm_x3:bf16x3"), ran
+                if d == 256:
+                    assert ran["gnn_mlp1"] == ran["gnn_mlp2"] == ran["final_proj"] == ("gemm_h2:f16x2" if want_h2 else "gemm_x3:bf16x3"), ran
         m0, m1, ms0, ms1 = (o.cpu().numpy() for o in out)
         g0, g1 = _pair_taps(eng, K)
         S = eng.fetch("scores_in")[0, :K, :K]
         Z = util.transport_Z(S, eng.fetch("u")[0], eng.fetch("v")[0], K, K, alpha)
-        tag = f"{name} seed {seed} [{forms}/{mfma}/{attention}]"
+        tag = f"{name} seed {seed} [{forms}/{mfma}/{attention}/linear={linear}]"
         for key, mine, full in (("gnn17", np.stack([g0, g1]), np.stack([ref["gnn0"], ref["gnn1"]])), ("scores_in", S, ref["scores_in"]), ("Z", Z, ref["Z"])):
             util.assert_close(mine, full, f"{tag}: {key} vs the oracle, every element")
             worst[key] = max(worst[key], util.tolerance_used(mine, full))
@@ -88,7 +101,7 @@ def test_strict_bar_superglue_every_form(name, forms, mfma, attention):
         util.assert_close(ms1[0][same1], g["mscores1"][s][same1], f"{tag}: matching_scores1")
         worst["mscores"] = max(worst["mscores"], util.tolerance_used(ms0[0][same0], g["mscores0"][s][same0]))
     n = len(g["seeds"])
-    print(f"[strict] {name} [{forms}/{mfma}/attention={attention}]: {n} unselected seeds, {2 * K * n} match indices: 0 differ outside the threshold band; {band} rows have their "
+    print(f"[strict] {name} [{forms}/{mfma}/attention={attention}/linear={linear}]: {n} unselected seeds, {2 * K * n} match indices: 0 differ outside the threshold band; {band} rows have their "
           f"reference score within 1e-4 of the threshold, {other} of them sit on the other side here; worst fraction of the 1e-4+1e-4|ref| tolerance used: "
           + ", ".join(f"{k} {v:.3f}" for k, v in worst.items()))
 
@@ -165,7 +178,7 @@ def test_strict_bar_as_one_batched_call_from_images(name, B):
     torch.cuda.synchronize()
     forms = {r[0]: r[3] for r in eng.timing_report(forms=True)}
     eng.set_timing(False)
-    assert forms["qkv_proj"] == "gemm_x3:bf16x3" and forms["attention"] == "attention_h2:f16x2" and forms["conv2a"] == "conv3x3_wino24p:f16x2", forms
+    assert forms["qkv_proj"] == "gemm_h2:f16x2" and forms["attention"] == "attention_h2:f16x2" and forms["conv2a"] == "conv3x3_wino24p:f16x2", forms
     alpha = float(util.sg_sd(d, variant="t")["bin_score"])
     summary = util.strict_compare_batch(g, out, eng, B, alpha, float(util.sg_config(d)["match_threshold"]))
     print(f"[strict e2e] {name} as one call of {B} pairs: {summary}")
