@@ -47,9 +47,14 @@ def strict_inputs_job(name, s):
     return {k: data[k].numpy() for k in keys}, ref
 
 
-def stage_job(d, K, H, W, seed, own):
+def stage_job(d, K, H, W, seed, own, strides=None):
     """The per-stage check of one pair of a batched call: the oracle's SuperPoint on the pair's images, and the oracle's SuperGlue on
-    the LIBRARY's own SuperPoint outputs of that pair (`own`: numpy keypoints / scores / descriptors (d, K) per side)."""
+    the LIBRARY's own SuperPoint outputs of that pair (`own`: numpy keypoints / scores / descriptors (d, K) per side).
+    With `strides` = (stride_s, stride_g) of a strict fixture (round 6): also the oracle's SuperGlue in FLOAT64 on
+    both input sets -- the library's SuperPoint outputs and the oracle's (= the reference's) -- cut to the fixture's sample points in
+    the reference's keypoint order: `own64` (the float64 evaluation the library's end-to-end result is anchored on) and
+    `delta` = own64 - ref64, the response of the 18-layer SuperGlue, element by element and free of rounding, to exactly the
+    perturbation the library's SuperPoint applies to its inputs."""
     from oracle import superglue_ref, superpoint_ref
     from tests import util
     ims = util.pair(seed, H, W)
@@ -61,5 +66,30 @@ def stage_job(d, K, H, W, seed, own):
     for side in ("0", "1"):
         for k in ("keypoints", "scores", "descriptors"):
             data[k + side] = torch.from_numpy(own[k + side])[None]
-    dn = superglue_ref.superglue_forward(data, util.sg_sd(d, variant="t"), util.sg_config(d), return_dense=True)["dense"]
-    return sp, {"gnn0": dn["gnn0"][0].numpy(), "gnn1": dn["gnn1"][0].numpy(), "scores_in": dn["scores_in"][0].numpy(), "Z": dn["Z"][0].numpy()}
+    sd = util.sg_sd(d, variant="t")
+    dn = superglue_ref.superglue_forward(data, sd, util.sg_config(d), return_dense=True)["dense"]
+    res = {"gnn0": dn["gnn0"][0].numpy(), "gnn1": dn["gnn1"][0].numpy(), "scores_in": dn["scores_in"][0].numpy(), "Z": dn["Z"][0].numpy()}
+    if strides is None:
+        return sp, res
+    ss, sg = strides
+    to64 = lambda t: {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in t.items()}
+    sd64 = to64(sd)
+
+    def run64(dat, perm0, perm1):        # -> the fixture's samples, rows / columns in the REFERENCE's keypoint order
+        o = superglue_ref.superglue_forward(to64(dat), sd64, util.sg_config(d), return_dense=True)["dense"]
+        g0, g1 = o["gnn0"][0].numpy()[:, perm0], o["gnn1"][0].numpy()[:, perm1]
+        S = o["scores_in"][0].numpy()[perm0][:, perm1]
+        Z = o["Z"][0].numpy()[np.append(perm0, K)][:, np.append(perm1, K)]
+        return {"gnn17": np.stack([g0[:, ::sg], g1[:, ::sg]]), "scores_in": S[::ss, ::ss], "Z": Z[::ss, ::ss]}
+    perms = []
+    for si, side in enumerate(("0", "1")):       # reference row r is the library's row perm[r] (same keypoint SET: asserted by the caller)
+        pos = {tuple(q): i for i, q in enumerate(own["keypoints" + side].astype(int))}
+        perms.append(np.array([pos[tuple(q)] for q in sp[si]["keypoints"].astype(int)]))
+    own64 = run64(data, perms[0], perms[1])
+    ref_data = {"image_shape0": (1, 1, H, W), "image_shape1": (1, 1, H, W)}
+    for si, side in enumerate(("0", "1")):
+        for k in ("keypoints", "scores", "descriptors"):
+            ref_data[k + side] = torch.from_numpy(sp[si][k])[None]
+    ident = np.arange(K)
+    ref64 = run64(ref_data, ident, ident)
+    return sp, res, {"own64": own64, "delta": {k: own64[k] - ref64[k] for k in own64}}
