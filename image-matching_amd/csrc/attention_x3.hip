@@ -235,8 +235,12 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnArgs p, float 
       x4 kp[NP], vp[NP];
       f32x4 kq = kr[it], vq = vr[it];
       if constexpr (F::SCALED) {
-        const bool fin = t * TK + TK <= nk || t * TK + key < nk;
-        if (!fin) { kq = (f32x4){0.f, 0.f, 0.f, 0.f}; vq = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        // (block-uniform branch: only the tile that holds the end of the pair's keys pays the eight selects -- they were 5 % of the
+        // kernel's VALU instructions in every tile)
+        if (t * TK + TK > nk) {
+          asm volatile("" ::: "memory");            // (not to be if-converted back into selects)
+          if (t * TK + key >= nk) { kq = (f32x4){0.f, 0.f, 0.f, 0.f}; vq = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
         kq *= sk; vq *= sv;
       }
 #pragma unroll
@@ -500,8 +504,10 @@ __global__ __launch_bounds__(256, 2) void attention_x3p_kernel(AttnArgs p, float
       x4 kp[NP], vp[NP];
       f32x4 kq = kreg[it], vq = vreg[it];
       if constexpr (F::SCALED) {        // keys past the valid count are zeroed (amax does not cover them: 0 x inf), the rest scaled
-        const bool fin = tload * TK + TK <= nk || tload * TK + key < nk;
-        if (!fin) { kq = (f32x4){0.f, 0.f, 0.f, 0.f}; vq = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        if (tload * TK + TK > nk) {     // (block-uniform: see attention_x3_kernel)
+          asm volatile("" ::: "memory");
+          if (tload * TK + key >= nk) { kq = (f32x4){0.f, 0.f, 0.f, 0.f}; vq = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
         kq *= sk; vq *= sv;
       }
 #pragma unroll

@@ -115,10 +115,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
     const f32x4 s4 = {sc, sc, sc, sc};
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      f32x4 v = areg[it] * s4;
-      if (lf < BM) {                       // block-uniform: the tile that holds the end of its pair's keypoints
-        if ((tid >> 3) + 32 * it >= lf) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
+      const f32x4 v = areg[it] * s4;
       f16x4 h, m;
 #pragma unroll
       for (int t = 0; t < 4; t += 2) {
@@ -129,6 +126,20 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
       const int o = ((tid >> 3) + 32 * it) * RS + (tid & 7) * 4;
       *reinterpret_cast<f16x4*>(&Ad[0][o]) = h;
       *reinterpret_cast<f16x4*>(&Ad[1][o]) = m;
+    }
+  };
+  // rows past the pair's keypoint count (the tile that holds its end: block-uniform, rare): their planes are overwritten with zeros
+  // AFTER the straight-line split above -- a mask inside it was a branch per row group in the middle of the region that has to
+  // interleave with the MFMAs
+  auto lzero = [&](_Float16 (&Ad)[2][BM * RS], int lf) __attribute__((always_inline)) {
+    if (lf < BM) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        if ((tid >> 3) + 32 * it >= lf) {
+          const int o = ((tid >> 3) + 32 * it) * RS + (tid & 7) * 4;
+          *reinterpret_cast<f16x4*>(&Ad[0][o]) = (f16x4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+          *reinterpret_cast<f16x4*>(&Ad[1][o]) = (f16x4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        }
     }
   };
   // a wave's weight fragments: column block nb, step st, plane pl -> 512 halves at ((nb * nst + st) * 2 + pl) * 512
@@ -167,7 +178,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
     const int rbase = cu.r0 + wr * WROWS + 4 * kb;
     const int col = cu.n0 + wc * 32 + i;
     const float inv = p.w_inv / cu.sA;                    // powers of two: exact
-    const int left = cu.left - (wr * WROWS + 4 * kb);      // rows (local index ro) below this are valid
+    // rows (local index ro) below `left` are valid; nothing is when no maximum is wanted (branch-free: as a nested condition hipcc
+    // compiled the tracking into a branch per element, 64 per tile and wave)
+    const bool track = p.amax || p.amax_row;
+    const int left = track ? cu.left - (wr * WROWS + 4 * kb) : -0x40000000;
     unsigned mx = 0;
     if (col < p.N) {
       const float bias = p.bias ? p.bias[col] : 0.f;
@@ -193,14 +207,11 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
           if (RES) v = rv[r] + v;
           o[ro * p.ldo] = v;
           // what the NEXT kernel scales this tensor by: the largest |value| over the pair's valid rows
-          if (p.amax || p.amax_row) {
-            const unsigned bits = __builtin_bit_cast(unsigned, v) & 0x7fffffffu;
-            mx = ro < left ? max(mx, bits) : mx;
-          }
+          mx = max(mx, ro < left ? __builtin_bit_cast(unsigned, v) & 0x7fffffffu : 0u);
         }
       }
     }
-    if (p.amax || p.amax_row) {
+    if (track) {
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
       if (lane == 0 && mx) {
@@ -228,6 +239,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
   gload(areg3, sc3, lf3, acur);      // chunk 3
   wload(wfa, wcur);
   lstore(As0, areg0, sc0, lf0);
+  lzero(As0, lf0);
   advance(acur);
   gload(areg0, sc0, lf0, acur);      // chunk 4
   __syncthreads();
@@ -238,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
     advance(wcur);
     wload(wnext, wcur);
     lstore(Ad, areg, sc, lf);                // chunk q+1
+    const int lf_stored = lf;
     advance(acur);
     gload(areg, sc, lf, acur);               // chunk q+5
     step(Ar, 0, wcurf[0]);
@@ -248,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
       __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // three VALU beneath it
       __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // and at most one LDS store
     }
+    lzero(Ad, lf_stored);
     __syncthreads();
     if (comp.c == nch - 1) {                 // block-uniform
       if (comp.r0 + BM <= p.M) epilogue(comp, BoolC<true>{}); else epilogue(comp, BoolC<false>{});
