@@ -100,7 +100,9 @@ inline std::vector<uint16_t> gnn_tail_pack(const float* w1, int ld1, const float
 // (largest column L1 norm) / (median column L2 norm) of mlp.0' (times the same ratio of mlp.3 for x'), times an activation crest
 // factor of 2^4.  The bound is brought to 2^13 (pow2_of_bound); a value keeps both fp16 planes down to 2^-3, so beyond 2^16 the
 // typical operand starts to lose its low plane and imx_api.cpp runs that layer's tail on three bf16 planes instead.
-struct GnnTailH2Consts { float w1_inv, w2_inv, w3_inv, l1_1, l1_2, loose_h, loose_x; };
+// w_spread (round 6): over the three matrices, (largest |w|) / (median over output columns of their largest |w|): each matrix carries ONE power of
+// two, so a runaway column pushes the typical one towards fp16's low end (2^12: the typical weight still keeps the scheme's 22 bits)
+struct GnnTailH2Consts { float w1_inv, w2_inv, w3_inv, l1_1, l1_2, loose_h, loose_x, w_spread; };
 inline uint16_t gt_f16_rne(float x) {      // fp32 -> fp16 bit pattern, round to nearest even (normal range and subnormals; the scaled weights never overflow)
   uint32_t u;
   memcpy(&u, &x, 4);
@@ -129,15 +131,18 @@ inline float gt_f16_f(uint16_t h) {
 }
 inline std::vector<uint16_t> gnn_tail_pack_h2(const float* w1, int ld1, const float* w2, int ld2, const float* w3, int ld3, int d, int n3,
                                               GnnTailH2Consts* consts) {
-  auto scale_of = [](const float* w, int rows, int cols, int ld, float* l1, double* gain_ratio = nullptr) {
+  double spread = 1.0;
+  auto scale_of = [&spread](const float* w, int rows, int cols, int ld, float* l1, double* gain_ratio = nullptr) {
     double mx = 0.0, best = 0.0;
-    std::vector<double> l2(cols, 0.0);
+    std::vector<double> l2(cols, 0.0), cmax(cols, 0.0);
     for (int c = 0; c < cols; ++c) {
       double acc = 0.0, sq = 0.0;
-      for (int k = 0; k < rows; ++k) { const double a = std::fabs((double)w[(size_t)k * ld + c]); acc += a; sq += a * a; if (a > mx) mx = a; }
+      for (int k = 0; k < rows; ++k) { const double a = std::fabs((double)w[(size_t)k * ld + c]); acc += a; sq += a * a; if (a > mx) mx = a; if (a > cmax[c]) cmax[c] = a; }
       if (acc > best) best = acc;
       l2[c] = std::sqrt(sq);
     }
+    std::nth_element(cmax.begin(), cmax.begin() + cols / 2, cmax.end());
+    spread = std::max(spread, cmax[cols / 2] > 0 ? mx / cmax[cols / 2] : (mx > 0 ? 1e30 : 1.0));
     if (l1) *l1 = (float)best;
     if (gain_ratio) {
       std::nth_element(l2.begin(), l2.begin() + cols / 2, l2.end());
@@ -152,6 +157,7 @@ inline std::vector<uint16_t> gnn_tail_pack_h2(const float* w1, int ld1, const fl
   consts->loose_h = (float)std::min(1e30, 16.0 * g1);
   consts->loose_x = (float)std::min(1e30, 16.0 * g1 * g2);
   consts->w1_inv = (float)(1.0 / s1); consts->w2_inv = (float)(1.0 / s2); consts->w3_inv = (float)(1.0 / s3);
+  consts->w_spread = (float)std::min(1e30, spread);
   const int per_step = 4 * 2 * 64 * 8;                                  // 16-bit values per k-step
   const int n_step = 2 * (16 + 8) + 8 * (n3 / d);
   std::vector<uint16_t> out((size_t)n_step * per_step, 0);

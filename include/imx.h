@@ -241,10 +241,13 @@ IMX_API const char* imx_timing_form(imx_handle_t h, int index);
  *                           the weights-derived guard finds too loose for fp16's range (read-only option "arith_guard" lists them),
  *                           which run the six-bf16-product launch; "fused" forces the fp16 launch on every layer (the guard's A/B);
  *                           "bf16x3" the six-product launch everywhere; "unfused" three launches (the A/B reference: another summation order);
- *   "attention"      "auto" (default) = "f16x2": the throughput attention (head dims 32 / 64, "mfma" = "x3") cuts q, k, v and the softmax
+ *   "attention"      "auto" (default): the throughput attention (head dims 32 / 64, "mfma" = "x3") cuts q, k, v and the softmax
  *                           weights into TWO fp16 planes (22 bits; every operand scaled by a power of two taken from the maximum of its
- *                           (side, pair) over the valid rows) and keeps three term products per k-step; "bf16x3" three bf16 planes and
- *                           six term products (the A/B reference; both are closer to a float64 evaluation than the fp32 MFMA form).
+ *                           (side, pair) over the valid rows) and keeps three term products per k-step -- EXCEPT in layers whose q, k or v
+ *                           projection has an output channel more than 2^12 above the median one (column L2 norms; "arith_guard" lists
+ *                           them), which run three bf16 planes; "f16x2" forces the fp16 form everywhere (the guard's A/B); "bf16x3"
+ *                           three bf16 planes and six term products everywhere (the A/B reference; no range limit; both are closer to
+ *                           a float64 evaluation than the fp32 MFMA form).
  *   "linear"         "auto" (default) = "f16x2": the plain linear layers of the GNN in the throughput path (every layer's q|k|v, mlp.0',
  *                           mlp.3 and final_proj where the layer tail is not fused -- descriptor_dim 256 --, layer 0's q|k|v otherwise) as
  *                           three fp16 plane products (gemm_h2): both operands as two fp16 planes, the weights scaled by one power of
@@ -261,9 +264,10 @@ IMX_API const char* imx_timing_form(imx_handle_t h, int index);
  *   "sinkhorn_prefetch" "auto" (default: on for the 16-wave form, i.e. above 1024 columns) | "off" | "on".
  * Read-only (imx_get_option only): "arith_guard" -- what the weights-derived guards decided at imx_finalize_weights: the largest spread
  * of a layer's transformed convolution weights and the pipe the 3x3 chain runs on, the GNN layers whose tail runs bf16x3, the largest
- * bound looseness.  The guards cover the convolution weights' per-output-channel spread and the layer tails' bounds; the two-plane
- * attention is scaled by the ACTUAL q / k / v maxima of each (side, pair) and has no weight-derived fallback: a checkpoint with one
- * q, k or v channel 2^15 above the rest loses the low plane of the typical channels there ("attention" = "bf16x3" has no range limit).
+ * bound looseness, the layers whose attention runs bf16x3 with the largest q|k|v channel spread, the largest spread of the plain
+ * linear layers' weights and the form they run.  The guards cover the convolution weights' per-output-channel spread, the layer
+ * tails' bounds, the q / k / v projections' channel spread (round 6) and the linear layers' weight spread; they are estimates from
+ * the WEIGHTS -- an input-dependent outlier (one activation 2^16 above the rest of its (side, pair)) is not seen by them.
  * "conv" also accepts "wx3" (round 3's removed bf16-plane convolution: runs "wino32" and says so on stderr).
  * Unknown keys / values are an error.  imx_get_option returns the current value ("" for an unknown key); the pointer is valid
  * until the next call on the handle. */

@@ -136,3 +136,57 @@ def test_convolution_guard_moves_the_chain_to_the_fp32_kernels():
     eng.set_timing(False)
     assert forms["conv2a"] == "conv3x3_wino24:f32" and forms["conv1ab_pool"] == "conv1ab_wino24:f32", forms
     util.assert_close(np.transpose(eng.fetch("semi"), (0, 3, 1, 2)), g["semi"], "semi behind the convolution guard")
+
+
+@pytest.mark.parametrize("attention", ["auto", "f16x2"])
+def test_attention_guard_moves_a_layer_with_a_runaway_qk_channel_to_bf16x3(attention):
+    """Round 6: the two-plane attention scales q, k, v of a (side, pair) by their ACTUAL maxima, so one channel far above the
+    rest pushes the typical channel towards fp16's low end.  Layer 7's q channel 21 at 2^14 and the matching k channel at 2^-14 (exact
+    for the reference: the products q_c k_c are unchanged, so the strict fixture still pins the result): the weights-derived guard --
+    (largest column L2 norm) / (median) of a projection beyond 2^12 -- must list the layer and run ITS attention on three bf16
+    planes (no range limit), the others stay on two fp16 planes; "attention" = "f16x2" forces the fp16 form there (the guard's A/B:
+    printed, held to the same bar -- the guard is conservative)."""
+    from image_matching_amd import _lib as L
+    name = "strict_c3.npz"
+    g, per_seed = _strict_inputs(name)
+    H, W, d, K = (int(g[k]) for k in ("H", "W", "d", "K"))
+    sd = synth.make_superglue_state_dict(d, variant="t")
+    layer, ch, e = 7, 21, 14
+    for k, ee in ((0, e), (1, -e)):
+        sd[f"gnn.layers.{layer}.attn.proj.{k}.weight"][ch] *= np.float32(2.0 ** ee)
+        sd[f"gnn.layers.{layer}.attn.proj.{k}.bias"][ch] *= np.float32(2.0 ** ee)
+    eng = _engine(d, K)
+    eng.load_state_dict(L.NET_SUPERGLUE, util.to_torch(sd))
+    eng.set_option("latency_forms", "off").set_option("attention", attention)
+    guard = eng.get_option("arith_guard")
+    assert guard.split("attention bf16x3 layers:")[1].split("(")[0].split() == [str(layer)], guard
+    # ... and the fused tail that PRODUCES that layer's q|k|v (layer 6's third product) carries one power of two for the whole matrix:
+    # its spread guard (2^12) moves it to three bf16 planes too (found by this test: on fp16 planes it used 0.8 of the tolerance)
+    assert guard.split("gnn_tail bf16x3 layers:")[1].split("(")[0].split() == [str(layer - 1)], guard
+    assert "-> bf16x3" in guard.split("linear:")[1], guard
+    eng.set_debug(True)
+    alpha, thr = float(sd["bin_score"]), float(util.sg_config(d)["match_threshold"])
+    worst = {"gnn17": 0.0, "scores_in": 0.0, "Z": 0.0}
+    for s in range(3):
+        data, ref = per_seed[s]
+        eng.timing_reset()
+        eng.set_timing(True)
+        out = eng.superglue(data["keypoints0"].cuda(), data["scores0"].cuda(), data["descriptors0"].cuda(), (1, 1, H, W),
+                            data["keypoints1"].cuda(), data["scores1"].cuda(), data["descriptors1"].cuda(), (1, 1, H, W))
+        torch.cuda.synchronize()
+        rows = [r for r in eng.timing_report(forms=True) if r[0] == "attention"]
+        eng.set_timing(False)
+        forms = sorted({r[3] for r in rows})
+        assert forms == (["attention_h2:f16x2", "attention_x3:bf16x3"] if attention == "auto" else ["attention_h2:f16x2"]), forms
+        m0, m1 = out[0].cpu().numpy(), out[1].cpu().numpy()
+        x = eng.fetch("x")
+        Kp = (K + 31) // 32 * 32
+        g0, g1 = x[:K].T, x[Kp:Kp + K].T
+        S = eng.fetch("scores_in")[0, :K, :K]
+        Z = util.transport_Z(S, eng.fetch("u")[0], eng.fetch("v")[0], K, K, alpha)
+        for key, mine, full in (("gnn17", np.stack([g0, g1]), np.stack([ref["gnn0"], ref["gnn1"]])), ("scores_in", S, ref["scores_in"]), ("Z", Z, ref["Z"])):
+            util.assert_close(mine, full, f"{name} seed {int(g['seeds'][s])} runaway q/k channel [attention={attention}]: {key}, every element")
+            worst[key] = max(worst[key], util.tolerance_used(mine, full))
+        util.strict_index_check(g, s, m0[0], m1[0], thr, f"runaway q/k channel seed {int(g['seeds'][s])}")
+    print(f"[heavy] attention guard, layer {layer} q/k channel {ch} at 2^+-{e}, attention={attention}: guard '{guard.split('; attention')[1]}'; worst fraction of the tolerance used: "
+          + ", ".join(f"{k} {v:.3f}" for k, v in worst.items()))
