@@ -16,6 +16,7 @@
 // stream; A rows arrive as fp32 float4, are scaled and split in registers (v_cvt_pk_f16_f32, two v_dot2c_f32_f16 residuals,
 // v_cvt_pk_f16_f32) and stored as two planes (80-byte rows) under the previous chunk's MFMAs.
 #include "imx_kernels.h"
+#include <cstdint>
 #include <cstdlib>
 
 namespace imx {
@@ -76,14 +77,20 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
     cu.n0 = (cu.t % nct) * BN;
     const int side = cu.r0 >= p.aB * p.aN0p ? 1 : 0;
     const int rel = cu.r0 - side * p.aB * p.aN0p, Np = side ? p.aN1p : p.aN0p;
-    const int b = rel / Np;
-    const int n = side ? (p.an1 ? p.an1[b] : p.aN1) : (p.an0 ? p.an0[b] : p.aN0);
+    const int b = __builtin_amdgcn_readfirstlane(rel / Np);
+    // (uniform words through the SCALAR cache -- written by earlier launches, so it is clean: as vector loads they were waited for with
+    // vmcnt(0), and any vector-memory access on a conditional path of the chunk loop makes hipcc's wait insertion fall back to
+    // vmcnt(0) at the loop header: see the loop)
+    typedef const int __attribute__((address_space(4)))* ci32p;
+    typedef const unsigned __attribute__((address_space(4)))* cu32p;
+    const ci32p cn = (ci32p)(uintptr_t)(side ? p.an1 : p.an0);
+    const int n = cn ? cn[b] : (side ? p.aN1 : p.aN0);
     cu.sp = side * p.aB + b;
     cu.left = n - (rel - b * Np);
-    float bound = __builtin_bit_cast(float, p.sa0[(size_t)cu.sp * p.sa0_stride + p.sa0_off]);
+    float bound = __builtin_bit_cast(float, ((cu32p)(uintptr_t)p.sa0)[(size_t)cu.sp * p.sa0_stride + p.sa0_off]);
     if (p.sa1) {
       const int ksp = p.sa1_cross ? (1 - side) * p.aB + b : cu.sp;
-      bound = fmaxf(bound, __builtin_bit_cast(float, p.sa1[(size_t)ksp * p.sa1_stride + p.sa1_off]));
+      bound = fmaxf(bound, __builtin_bit_cast(float, ((cu32p)(uintptr_t)p.sa1)[(size_t)ksp * p.sa1_stride + p.sa1_off]));
     }
     cu.sA = pow2_of_bound(fmaxf(bound, 1e-30f));
   };
@@ -92,13 +99,11 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
     else if (cu.t + G < ntiles) { cu.t += G; cu.c = 0; place(cu); }
   };
 
-  // FOUR chunks of A in flight (gemm_x3.hip keeps two: its three-plane split leaves no registers for more).  These layers move ~4 bytes
-  // per executed MFMA flop-cycle less than they could: with two chunks a workgroup has 32 KB requested, the chip 16 MB, and at the
-  // ~4 us a load takes under this load that is 3.6 TB/s of L2 + HBM traffic -- the measured rate of BOTH forms (round 6: halving the
-  // MFMA work alone changed nothing).  Four register sets = 64 KB per workgroup.
-  f32x4 areg0[4], areg1[4], areg2[4], areg3[4];
-  float sc0 = 1.f, sc1 = 1.f, sc2 = 1.f, sc3 = 1.f;      // ... with the scale and the valid-row count of the tiles they belong to
-  int lf0 = BM, lf1 = BM, lf2 = BM, lf3 = BM;
+  // two chunks of A in flight (gemm_x3.hip).  (Four -- 64 KB requested per workgroup -- measured the same, round 6: 1.64 / 1.48 / 1.14 ms
+  // per C5 step for mlp.0' / q|k|v / mlp.3 either way; the registers went to the operand fragments instead, below.)
+  f32x4 arega[4], aregb[4];
+  float sca = 1.f, scb = 1.f;    // ... with the scale and the valid-row count of the tiles they belong to
+  int lfa = BM, lfb = BM;
   auto gload = [&](f32x4 (&areg)[4], float& sc, int& lf, const Cursor& cu) __attribute__((always_inline)) {
     const int k0 = cu.c * KC;
     const float* src = k0 < p.K0 ? p.a0 + k0 : p.a1 + (k0 - p.K0);
@@ -157,14 +162,20 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
 
+  // The A fragments of BOTH 16-k steps of a chunk are requested before its first MFMA (sixteen ds_read_b128, 64 registers): left to
+  // the register allocator under this kernel's pressure each fragment was read into the same four registers right before its MFMA --
+  // ds_read, s_waitcnt lgkmcnt(0), v_mfma, sixteen times per chunk, an LDS latency each (round 6: the ISA of the first build).
+  auto frags = [&](const _Float16 (&Ar)[2][BM * RS], f16x8 (&af)[2][RB][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+          af[s][rb][pl] = *reinterpret_cast<const f16x8*>(&Ar[pl][(wr * WROWS + rb * 32 + i) * RS + s * 16 + kb * 8]);
+  };
   // three plane products per block, smallest first; the row blocks interleave so consecutive MFMAs use different accumulators
-  auto step = [&](const _Float16 (&Ar)[2][BM * RS], int s, const f16x8 (&wf)[2]) __attribute__((always_inline)) {
-    f16x8 af[RB][2];
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb)
-        af[rb][pl] = *reinterpret_cast<const f16x8*>(&Ar[pl][(wr * WROWS + rb * 32 + i) * RS + s * 16 + kb * 8]);
+  auto step = [&](const f16x8 (&af)[RB][2], const f16x8 (&wf)[2]) __attribute__((always_inline)) {
     constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -224,37 +235,41 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+    // This path (once per tile) rejoins the chunk loop with NOTHING outstanding: hipcc's s_waitcnt insertion merges the pending
+    // vector-memory state of all predecessors of a block, and with this path's stores and bias load in the mix it gave up counting and
+    // put s_waitcnt vmcnt(0) at the head of EVERY chunk -- the A rows and weight fragments requested one and two chunks ahead were
+    // waited for one chunk later: a memory latency per chunk (round 6: 5.6 k cycles per chunk whatever the matrix work, both forms).
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
   };
 
   Cursor comp{first, 0, 0, 0, 0, BM, 1.f};
   place(comp);
   Cursor wcur = comp, acur = comp;
+  int qi = 0;                        // chunks multiplied so far
   f16x8 wfa[2][2], wfb[2][2];        // the two steps' weight fragments of the current and of the next chunk
-  gload(areg0, sc0, lf0, acur);      // chunk 0
+  gload(arega, sca, lfa, acur);      // chunk 0
   advance(acur);
-  gload(areg1, sc1, lf1, acur);      // chunk 1
-  advance(acur);
-  gload(areg2, sc2, lf2, acur);      // chunk 2
-  advance(acur);
-  gload(areg3, sc3, lf3, acur);      // chunk 3
+  gload(aregb, scb, lfb, acur);      // chunk 1
   wload(wfa, wcur);
-  lstore(As0, areg0, sc0, lf0);
-  lzero(As0, lf0);
+  lstore(As0, arega, sca, lfa);
+  lzero(As0, lfa);
   advance(acur);
-  gload(areg0, sc0, lf0, acur);      // chunk 4
   __syncthreads();
-  // one chunk (gemm_x3.hip): the split of chunk q+1 issues beneath the MFMAs of chunk q, the weight fragments of chunk q+1 are
-  // requested a whole chunk ahead, the A rows of chunk q+5 as soon as the registers of chunk q+1 are free
+  // one chunk (gemm_x3.hip): the fragments of chunk q first, then its MFMAs with the split of chunk q+1 issuing beneath them; the
+  // weight fragments of chunk q+1 are requested a whole chunk ahead, the A rows of chunk q+3 as soon as the registers of chunk q+1 are free
   auto chunk = [&](const _Float16 (&Ar)[2][BM * RS], _Float16 (&Ad)[2][BM * RS], const f16x8 (&wcurf)[2][2], f16x8 (&wnext)[2][2],
                    f32x4 (&areg)[4], float& sc, int& lf) __attribute__((always_inline)) {
+    f16x8 af[2][RB][2];
+    frags(Ar, af);
     advance(wcur);
     wload(wnext, wcur);
+    __builtin_amdgcn_sched_barrier(0);       // (the reads stay in front: see frags)
     lstore(Ad, areg, sc, lf);                // chunk q+1
     const int lf_stored = lf;
     advance(acur);
-    gload(areg, sc, lf, acur);               // chunk q+5
-    step(Ar, 0, wcurf[0]);
-    step(Ar, 1, wcurf[1]);
+    gload(areg, sc, lf, acur);               // chunk q+3
+    step(af[0], wcurf[0]);
+    step(af[1], wcurf[1]);
 #pragma unroll
     for (int g = 0; g < 6 * RB; ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
@@ -263,16 +278,19 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
     }
     lzero(Ad, lf_stored);
     __syncthreads();
-    if (comp.c == nch - 1) {                 // block-uniform
+    if (comp.c == nch - 1 && qi < Q) {       // block-uniform (qi >= Q: the padding chunk of an odd stream, below)
       if (comp.r0 + BM <= p.M) epilogue(comp, BoolC<true>{}); else epilogue(comp, BoolC<false>{});
     }
     advance(comp);
+    ++qi;
   };
-  for (int q = 0; q < Q; q += 4) {           // (LDS buffers and weight fragments alternate with period two, the register sets with four)
-    chunk(As0, As1, wfa, wfb, areg1, sc1, lf1);
-    if (q + 1 < Q) chunk(As1, As0, wfb, wfa, areg2, sc2, lf2);       // block-uniform
-    if (q + 2 < Q) chunk(As0, As1, wfa, wfb, areg3, sc3, lf3);
-    if (q + 3 < Q) chunk(As1, As0, wfb, wfa, areg0, sc0, lf0);
+  // The two chunk bodies of an iteration are BOTH executed (an odd stream runs one padding chunk on re-fetched operands whose products
+  // are never stored): a branch around the second body is a second predecessor with other loads in flight -- the same merge.
+  __builtin_amdgcn_s_waitcnt(0x0f70);        // (and the loop is entered with nothing outstanding but what the prologue's last lines request)
+  gload(arega, sca, lfa, acur);              // chunk 2
+  for (int q = 0; q < Q; q += 2) {
+    chunk(As0, As1, wfa, wfb, aregb, scb, lfb);
+    chunk(As1, As0, wfb, wfa, arega, sca, lfa);
   }
 }
 

@@ -3,7 +3,7 @@
 # pass) over the bench's own 64-pair C3 step, summarised per kernel, and profiles/<tag>_pmc_limiter.json for bench.py.
 # usage: tools/gpu_pmc_limiter.sh <tag>      -> gpurun_out/<tag>_pmc_{sqa,sqb,ta,ta2,tcp,tcp2}.txt, gpurun_out/<tag>_pmc_limiter.json
 # (SKIP_SQ=1: only the TA / TCP passes; each pass is ~2-3 minutes of box time)
-tag=${1:-r05}
+tag=${1:-r06}
 R=$(pwd); export TMPDIR=/tmp
 out=$R/gpurun_out; mkdir -p $out
 pass() {  # name, counters...

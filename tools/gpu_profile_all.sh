@@ -2,7 +2,7 @@
 # Full measurement set for profiles/: bench JSON lines (c3 default, c2, c5), rocprofv3 kernel stats of the bench command,
 # and PMC passes (MFMA busy, FETCH_SIZE, WRITE_SIZE -- separate runs, kernel trace only) of the 64-pair step (the bench's own step).
 # usage: tools/gpu_profile_all.sh <tag>      -> gpurun_out/<tag>_*
-tag=${1:-r05}
+tag=${1:-r06}
 R=$(pwd); export TMPDIR=/tmp
 out=$R/gpurun_out; mkdir -p $out
 python bench.py > $out/${tag}_bench_c3.json 2> $out/${tag}_bench_c3.log
