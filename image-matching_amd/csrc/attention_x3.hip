@@ -399,6 +399,238 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnArgs p, float 
       }
   }
 }
+// attention_h2q2_kernel (round 6): attention_x3_kernel<32, FmtH2> with TWO 32-query blocks per wave -- a workgroup owns 256 queries, so
+// every staged K / V tile (its split into fp16 planes is a sixth of a wave-tile's VALU instructions) and every K / V^T fragment read
+// from LDS serves two query blocks.  The second block's O / T / m / l cost 34 registers and its Q fragments 16 more, which the
+// straight two-block form does not have (26 spilled registers, reloads inside the tile loop: measured in the compiler, not on the GPU);
+// here the Q fragments of both blocks live in LDS (32 KB per workgroup, wave-private: no barrier) and are read per tile, 16 registers
+// at a time.  Per query the instructions and their order are attention_x3_kernel's: bit-identical output (tools/ubench/attn_x3_bench
+// QB=1 / QB=2 dumps, tests/test_gpu_superglue.py).  Same box: 300 -> 281 us per launch, 5.83 -> 5.49 ms per C3 step.
+__global__ __launch_bounds__(256, 2) void attention_h2q2_kernel(AttnArgs p, float scale) {
+  typedef FmtH2 F;
+  typedef F::T E;
+  typedef F::x8 x8;
+  typedef F::x4 x4;
+  typedef F::x2 x2;
+  constexpr int HD = 32, NP = 2, TK = 32, KSB = HD + 8, NS = 2, V4 = HD / 4, QB = 2;
+  __shared__ __attribute__((aligned(16))) E Kt0[NP][TK * KSB];
+  __shared__ __attribute__((aligned(16))) E Kt1[NP][TK * KSB];
+  __shared__ __attribute__((aligned(16))) E Vt0[NP][TK * HD];
+  __shared__ __attribute__((aligned(16))) E Vt1[NP][TK * HD];
+  __shared__ __attribute__((aligned(16))) E Qs[4][QB][NS][NP][64 * 8];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const AttnBlock blk = attn_block();
+  const int head = blk.y;
+  const int side = blk.z / p.B, b = blk.z % p.B;
+  const int kside = p.cross ? 1 - side : side;
+  const int Nqp = side ? p.N1p : p.N0p, Nkp = kside ? p.N1p : p.N0p;
+  const int q0 = blk.x * 128 * QB;
+  if (q0 >= Nqp) return;
+  const int nq = side ? (p.n1 ? p.n1[b] : p.N1) : (p.n0 ? p.n0[b] : p.N0);
+  const int nk = kside ? (p.n1 ? p.n1[b] : p.N1) : (p.n0 ? p.n0[b] : p.N0);
+  const size_t qbase = (side ? (size_t)p.B * p.N0p : 0) + (size_t)b * Nqp;
+  const size_t kbase = (kside ? (size_t)p.B * p.N0p : 0) + (size_t)b * Nkp;
+  const int ld = 3 * p.d;
+  const int qrow0 = q0 + 32 * QB * wave + l31;            // query block jq of the wave: rows qrow0 + 32 jq
+
+  const float sq = pow2_scale(p.amax[(side * p.B + b) * 4]);
+  const float sk = pow2_scale(p.amax[(kside * p.B + b) * 4 + 1]);
+  const float sv = pow2_scale(p.amax[(kside * p.B + b) * 4 + 2]);
+  const float cinv = 1.0f / (sq * sk), svinv = 1.0f / sv;
+  // Q^T fragments (B operand) of both blocks, split as in attention_x3_kernel, into this wave's LDS region in fragment order
+#pragma unroll
+  for (int jq = 0; jq < QB; ++jq) {
+    const int qrow = qrow0 + 32 * jq;
+    const float* qp = p.qkv + (qbase + min(qrow, Nqp - 1)) * ld + head * HD + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * s), c = *reinterpret_cast<const f32x4*>(qp + 16 * s + 4);
+      float v[8] = {a[0] * scale, a[1] * scale, a[2] * scale, a[3] * scale, c[0] * scale, c[1] * scale, c[2] * scale, c[3] * scale};
+      if (qrow >= nq) {               // rows past the keypoint count are not covered by amax: anything there could overflow fp16
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      }
+      x8 qv[NP];
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        x2 pl[NP];
+        F::split(v[j] * sq, v[j + 1] * sq, pl);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { qv[q][j] = pl[q][0]; qv[q][j + 1] = pl[q][1]; }
+      }
+#pragma unroll
+      for (int q = 0; q < NP; ++q) *reinterpret_cast<x8*>(&Qs[wave][jq][s][q][lane * 8]) = qv[q];
+    }
+  }
+
+  f32x16 O[QB], T[QB];       // running output, and the current 64-key group's partial product (two-level accumulation)
+  float m[QB], l[QB];
+#pragma unroll
+  for (int jq = 0; jq < QB; ++jq) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { O[jq][r] = 0.f; T[jq][r] = 0.f; }
+    m[jq] = -INFINITY;
+    l[jq] = 0.f;
+  }
+
+  // K/V rows of this (pair, side) through a buffer descriptor (attention_x3_kernel)
+  const unsigned long long kaddr = (unsigned long long)(p.qkv + kbase * ld);
+  const unsigned long long kaddr_u = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(kaddr >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((unsigned)kaddr);
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)kaddr_u, 0, __builtin_amdgcn_readfirstlane(Nkp * ld * 4), 0x00020000);
+  const int skey = tid / V4, sv4 = tid % V4;            // this thread's float4 of a staged tile: key, four dims
+  const int kvo = (skey * ld + head * HD + 4 * sv4 + p.d) * 4;
+  const int nt = (nk + TK - 1) / TK;
+  f32x4 kreg0, vreg0, kreg1, vreg1;
+  auto gload = [&](f32x4& kr, f32x4& vr, int kt) __attribute__((always_inline)) {
+    const int so = __builtin_amdgcn_readfirstlane(kt * TK * ld * 4);
+    kr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, kvo, so, 0));
+    vr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, kvo + p.d * 4, so, 0));
+  };
+  auto lstore = [&](E (&Kd)[NP][TK * KSB], E (&Vd)[NP][TK * HD], const f32x4& kr, const f32x4& vr, int t) __attribute__((always_inline)) {
+    x4 kp[NP], vp[NP];
+    f32x4 kq = kr, vq = vr;
+    if (t * TK + TK > nk) {           // block-uniform: the tile that holds the end of the keys (amax does not cover what lies past them)
+      asm volatile("" ::: "memory");
+      if (t * TK + skey >= nk) { kq = (f32x4){0.f, 0.f, 0.f, 0.f}; vq = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    }
+    kq *= sk; vq *= sv;
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      x2 pl[NP];
+      F::split(kq[j], kq[j + 1], pl);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) { kp[q][j] = pl[q][0]; kp[q][j + 1] = pl[q][1]; }
+      F::split(vq[j], vq[j + 1], pl);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) { vp[q][j] = pl[q][0]; vp[q][j + 1] = pl[q][1]; }
+    }
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+      *reinterpret_cast<x4*>(&Kd[pl][skey * KSB + 4 * sv4]) = kp[pl];
+      *reinterpret_cast<x4*>(&Vd[pl][skey * HD + 4 * sv4]) = vp[pl];
+    }
+  };
+  const int tr_off = ((lane & 15) >> 2) * HD + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  auto tile = [&](int kt, const E (&Kr)[NP][TK * KSB], const E (&Vr)[NP][TK * HD], auto first, auto full) __attribute__((always_inline)) {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // K and V^T fragments: read once, they meet both query blocks
+    x8 kf[NS][NP], vf[2][NP];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) kf[s][pl] = *reinterpret_cast<const x8*>(&Kr[pl][l31 * KSB + 16 * s + 8 * hi]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+        const E* base = &Vr[pl][(16 * t + 4 * hi) * HD + tr_off];
+        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(base));
+        const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(base + 8 * HD));
+        const u32x2 aw = __builtin_bit_cast(u32x2, a), cw = __builtin_bit_cast(u32x2, c);
+        const u32x4 w = {aw[0], aw[1], cw[0], cw[1]};
+        vf[t][pl] = __builtin_bit_cast(x8, w);
+      }
+#pragma unroll
+    for (int jq = 0; jq < QB; ++jq) {
+      __builtin_amdgcn_sched_barrier(0);                      // (one query block at a time)
+      x8 qf[NS][NP];
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) qf[s][pl] = *reinterpret_cast<const x8*>(&Qs[wave][jq][s][pl][lane * 8]);
+      f32x16 S = zero16;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) S = mfma_terms<F>(kf[s], qf[s], S);
+      float mx = -INFINITY;
+      if constexpr (decltype(full)::value) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const float svv = key < nk ? S[r] : -INFINITY;
+          S[r] = svv;
+          mx = fmaxf(mx, svv);
+        }
+      }
+      mx = xhalf_max(mx);
+      mx = h2_reference(mx * cinv);
+      const float mn = fmaxf(m[jq], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m[jq] - mn);
+      float rs = 0.f;
+      x8 pf[2][NP];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(S[r], cinv, -mn));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(S[r + 1], cinv, -mn));
+        rs += p0 + p1;
+        x2 pl[NP];
+        F::split(p0, p1, pl);
+        const int t = r >> 3, j = r & 7;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { pf[t][q][j] = pl[q][0]; pf[t][q][j + 1] = pl[q][1]; }
+      }
+      rs = xhalf_sum(rs);
+      l[jq] = l[jq] * alpha + rs;
+      m[jq] = mn;
+      const bool rescale = __builtin_amdgcn_ballot_w64(alpha != 1.f) != 0;
+      if constexpr (decltype(first)::value) {
+        O[jq] += T[jq];
+        if (rescale) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[jq][r] *= alpha;
+        }
+        T[jq] = mfma_terms<F>(vf[1], pf[1], mfma_terms<F>(vf[0], pf[0], zero16));
+      } else {
+        if (rescale) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { O[jq][r] *= alpha; T[jq][r] *= alpha; }
+        }
+        T[jq] = mfma_terms<F>(vf[1], pf[1], mfma_terms<F>(vf[0], pf[0], T[jq]));
+      }
+    }
+  };
+
+  int th0 = 0, th1 = nt > 1 ? 1 : 0;
+  gload(kreg0, vreg0, th0);
+  gload(kreg1, vreg1, th1);
+  lstore(Kt0, Vt0, kreg0, vreg0, th0);
+  __syncthreads();
+  for (int kt = 0; kt < nt; kt += 2) {
+    th0 = kt + 2 < nt ? kt + 2 : kt;
+    gload(kreg0, vreg0, th0);
+    if (kt * 32 + 32 <= nk) tile(kt, Kt0, Vt0, BoolC<true>{}, BoolC<true>{});          // block-uniform
+    else tile(kt, Kt0, Vt0, BoolC<true>{}, BoolC<false>{});
+    lstore(Kt1, Vt1, kreg1, vreg1, th1);
+    __syncthreads();
+    if (kt + 1 < nt) {
+      th1 = kt + 3 < nt ? kt + 3 : kt;
+      gload(kreg1, vreg1, th1);
+      if (kt * 32 + 64 <= nk) tile(kt + 1, Kt1, Vt1, BoolC<false>{}, BoolC<true>{});
+      else tile(kt + 1, Kt1, Vt1, BoolC<false>{}, BoolC<false>{});
+      lstore(Kt0, Vt0, kreg0, vreg0, th0);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int jq = 0; jq < QB; ++jq) {
+    if (q0 + 32 * QB * wave + 32 * jq >= Nqp) break;                  // (wave-uniform: blocks past the padded rows store nothing)
+    const int qrow = qrow0 + 32 * jq;
+    O[jq] += T[jq];
+    const float inv = (l[jq] > 0.f && qrow < nq) ? (1.0f / l[jq]) * svinv : 0.f;
+    float* op = p.out + (qbase + qrow) * p.d + head * HD;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 v = make_float4(O[jq][4 * g] * inv, O[jq][4 * g + 1] * inv, O[jq][4 * g + 2] * inv, O[jq][4 * g + 3] * inv);
+      *reinterpret_cast<float4*>(op + 8 * g + 4 * hi) = v;
+    }
+  }
+}
+
 // The pipelined form (used for HD = 64: the straight form above needs 2 x the V / P / O registers there and spills).
 template <int HD, class F>
 __global__ __launch_bounds__(256, 2) void attention_x3p_kernel(AttnArgs p, float scale) {
@@ -730,7 +962,10 @@ hipError_t launch_attention_x3(const AttnArgs& a, hipStream_t s) {
   const float scale = (float)(1.4426950408889634 / sqrt((double)hd));   // log2(e)/sqrt(HD)
   if (a.amax) {                   // two fp16 planes, three term products per k-step; needs the launch's q / k / v maxima
     last_form = "attention_h2:f16x2";
-    if (hd == 32) hipLaunchKernelGGL((attention_x3_kernel<32, FmtH2>), grid, dim3(256), 0, s, a, scale);
+    if (hd == 32 && a.qblocks == 2 && nmax % 256 == 0) {            // two query blocks per wave: whole 256-query workgroups only
+      dim3 grid2((unsigned)(nmax / 256), (unsigned)a.heads, (unsigned)(2 * a.B));
+      hipLaunchKernelGGL(attention_h2q2_kernel, grid2, dim3(256), 0, s, a, scale);
+    } else if (hd == 32) hipLaunchKernelGGL((attention_x3_kernel<32, FmtH2>), grid, dim3(256), 0, s, a, scale);
     else hipLaunchKernelGGL((attention_x3p_kernel<64, FmtH2>), grid, dim3(256), 0, s, a, scale);
     return hipGetLastError();
   }

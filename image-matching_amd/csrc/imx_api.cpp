@@ -1026,7 +1026,7 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     AttnArgs a{};
     a.qkv = qkv; a.out = att; a.B = B; a.N0p = N0p; a.N1p = N1p; a.d = d; a.heads = HEADS;
     a.n0 = sd[0].n; a.n1 = sd[1].n; a.N0 = N0; a.N1 = N1; a.cross = c.gnn_layer_is_cross[l];
-    a.mfma_f32 = h->opt.mfma_f32; a.latency_forms = h->opt.latency_forms;
+    a.mfma_f32 = h->opt.mfma_f32; a.latency_forms = h->opt.latency_forms; a.qblocks = h->opt.attention_qblocks;
     const bool f16x2 = amax && attention_takes_x3(a) && (L.qkv_spread <= kAttnSpreadMax || h->opt.attention == 1);   // ("attention" = f16x2 forces it: the guard's A/B)
     if (f16x2) {
       if (!have_amax) RUN("qkv_amax", launch_qkv_amax(a, amax + 8 * B * l, s));
@@ -1151,6 +1151,8 @@ int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
     }
     else if (v == "direct") o.conv_direct = 1;
     else return -1;
+  } else if (key == "attention_qblocks") {
+    if (v == "1") o.attention_qblocks = 1; else if (v == "2") o.attention_qblocks = 2; else return -1;
   } else if (key == "linear") {
     if (v == "auto") o.linear = -1; else if (v == "f16x2" || v == "1") o.linear = 1; else if (v == "bf16x3" || v == "x3" || v == "0") o.linear = 0; else return -1;
   } else if (key == "conv_swizzle") {
@@ -1219,7 +1221,7 @@ int imx_create(int device_id, const imx_config_t* cfg, imx_handle_t* out) {
     h->device = device_id;
     h->cfg = *cfg;
     // the environment seeds the options once, here; afterwards only imx_set_option changes them
-    for (const char* key : {"mfma", "latency_forms", "conv", "gnn_tail", "attention", "linear"}) {
+    for (const char* key : {"mfma", "latency_forms", "conv", "gnn_tail", "attention", "attention_qblocks", "linear"}) {
       std::string env = std::string("IMX_") + key;
       for (char& ch : env) ch = (char)toupper((unsigned char)ch);
       if (const char* e = getenv(env.c_str()))
@@ -1652,7 +1654,7 @@ int imx_set_option(imx_handle_t h, const char* key, const char* value) {
   return guarded(h, "imx_set_option", [&]() -> int {
     if (!h) return -1;
     if (!key || !value) return fail(h, "imx_set_option: null argument");
-    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino_h|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3, linear = auto|f16x2|bf16x3, conv_swizzle = on|off, qkv_amax = epilogue|kernel, sinkhorn_group = auto|1|2|4, sinkhorn_prefetch = auto|off|on)", key, value);
+    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino_h|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3, linear = auto|f16x2|bf16x3, attention_qblocks = 1|2, conv_swizzle = on|off, qkv_amax = epilogue|kernel, sinkhorn_group = auto|1|2|4, sinkhorn_prefetch = auto|off|on)", key, value);
     return 0;
   });
 }
@@ -1667,6 +1669,7 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : o.conv_f16 == 2 ? "wino_h" : o.conv_f16 ? "wino" : "wino32";
     else if (k == "gnn_tail") h->opt_text = o.gnn_tail < 0 ? "auto" : o.gnn_tail == 2 ? "bf16x3" : o.gnn_tail ? "fused" : "unfused";
     else if (k == "attention") h->opt_text = o.attention < 0 ? "auto" : o.attention ? "f16x2" : "bf16x3";
+    else if (k == "attention_qblocks") h->opt_text = std::to_string(o.attention_qblocks);
     else if (k == "linear") h->opt_text = o.linear < 0 ? "auto" : o.linear ? "f16x2" : "bf16x3";
     else if (k == "conv_swizzle") h->opt_text = o.conv_swizzle ? "on" : "off";
     else if (k == "qkv_amax") h->opt_text = o.qkv_amax ? "kernel" : "epilogue";

@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
   hipMalloc(&dq, qkv.size() * 4); hipMalloc(&dout, rows * d * 4);
   hipMemcpy(dq, qkv.data(), qkv.size() * 4, hipMemcpyHostToDevice);
   AttnArgs a{dq, dout, B, N, N, d, heads, nullptr, nullptr, N - 5, N - 37, 1};
+  a.qblocks = getenv("QB") ? atoi(getenv("QB")) : 1;          // two 32-query blocks per wave (attention_h2q2_kernel, round 6)
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   unsigned* amax; hipMalloc(&amax, (size_t)2 * B * 16);
   {                                   // the maxima of the valid rows (three words), timed alone
