@@ -962,7 +962,10 @@ hipError_t launch_attention_x3(const AttnArgs& a, hipStream_t s) {
   const float scale = (float)(1.4426950408889634 / sqrt((double)hd));   // log2(e)/sqrt(HD)
   if (a.amax) {                   // two fp16 planes, three term products per k-step; needs the launch's q / k / v maxima
     last_form = "attention_h2:f16x2";
-    if (hd == 32 && a.qblocks == 2 && nmax % 256 == 0) {            // two query blocks per wave: whole 256-query workgroups only
+    // two query blocks per wave: whole 256-query workgroups only; "auto" where one block per wave would still leave two workgroups
+    // per slot of the chip (at one or two pairs the smaller workgroups fill more of it)
+    const bool q2 = a.qblocks == 2 || (a.qblocks <= 0 && (long)((nmax + 127) / 128) * a.heads * 2 * a.B >= 1024);
+    if (hd == 32 && q2 && nmax % 256 == 0) {
       dim3 grid2((unsigned)(nmax / 256), (unsigned)a.heads, (unsigned)(2 * a.B));
       hipLaunchKernelGGL(attention_h2q2_kernel, grid2, dim3(256), 0, s, a, scale);
     } else if (hd == 32) hipLaunchKernelGGL((attention_x3_kernel<32, FmtH2>), grid, dim3(256), 0, s, a, scale);

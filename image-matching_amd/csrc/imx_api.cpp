@@ -1152,7 +1152,7 @@ int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
     else if (v == "direct") o.conv_direct = 1;
     else return -1;
   } else if (key == "attention_qblocks") {
-    if (v == "1") o.attention_qblocks = 1; else if (v == "2") o.attention_qblocks = 2; else return -1;
+    if (v == "auto") o.attention_qblocks = -1; else if (v == "1") o.attention_qblocks = 1; else if (v == "2") o.attention_qblocks = 2; else return -1;
   } else if (key == "linear") {
     if (v == "auto") o.linear = -1; else if (v == "f16x2" || v == "1") o.linear = 1; else if (v == "bf16x3" || v == "x3" || v == "0") o.linear = 0; else return -1;
   } else if (key == "conv_swizzle") {
@@ -1654,7 +1654,7 @@ int imx_set_option(imx_handle_t h, const char* key, const char* value) {
   return guarded(h, "imx_set_option", [&]() -> int {
     if (!h) return -1;
     if (!key || !value) return fail(h, "imx_set_option: null argument");
-    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino_h|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3, linear = auto|f16x2|bf16x3, attention_qblocks = 1|2, conv_swizzle = on|off, qkv_amax = epilogue|kernel, sinkhorn_group = auto|1|2|4, sinkhorn_prefetch = auto|off|on)", key, value);
+    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino_h|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3, linear = auto|f16x2|bf16x3, attention_qblocks = auto|1|2, conv_swizzle = on|off, qkv_amax = epilogue|kernel, sinkhorn_group = auto|1|2|4, sinkhorn_prefetch = auto|off|on)", key, value);
     return 0;
   });
 }
@@ -1669,7 +1669,7 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     else if (k == "conv") h->opt_text = o.conv_direct ? "direct" : o.conv_f16 == 2 ? "wino_h" : o.conv_f16 ? "wino" : "wino32";
     else if (k == "gnn_tail") h->opt_text = o.gnn_tail < 0 ? "auto" : o.gnn_tail == 2 ? "bf16x3" : o.gnn_tail ? "fused" : "unfused";
     else if (k == "attention") h->opt_text = o.attention < 0 ? "auto" : o.attention ? "f16x2" : "bf16x3";
-    else if (k == "attention_qblocks") h->opt_text = std::to_string(o.attention_qblocks);
+    else if (k == "attention_qblocks") h->opt_text = o.attention_qblocks < 0 ? std::string("auto") : std::to_string(o.attention_qblocks);
     else if (k == "linear") h->opt_text = o.linear < 0 ? "auto" : o.linear ? "f16x2" : "bf16x3";
     else if (k == "conv_swizzle") h->opt_text = o.conv_swizzle ? "on" : "off";
     else if (k == "qkv_amax") h->opt_text = o.qkv_amax ? "kernel" : "epilogue";

@@ -28,7 +28,9 @@ struct Options {
   int qkv_amax = 0;        // "qkv_amax": 0 = "epilogue" (a plain q|k|v projection's epilogue writes the (side, pair) maxima), 1 = "kernel" (the separate pass)
   int sinkhorn_group = 0;  // "sinkhorn_group": 0 = "auto" (2 slabs per workgroup up to 1024 columns, 4 above, 1 below 64 slabs), 1 | 2 | 4
   int sinkhorn_prefetch = -1;  // "sinkhorn_prefetch": -1 = "auto" (on for the 16-wave form), 0 = "off", 1 = "on"
-  int attention_qblocks = 1;   // "attention_qblocks": 1 | 2 -- 32-query blocks per wave of the two-plane attention at head dim 32 (attention_x3.hip)
+  int attention_qblocks = -1;  // "attention_qblocks": -1 = "auto" (2 where the padded keypoint count is a multiple of 256 and one block per wave would
+                               //         still leave >= 1024 workgroups -- two per slot of the chip --, else 1) | 1 | 2: 32-query blocks per wave of the
+                               //         two-plane attention at head dim 32 (attention_h2q2_kernel; bit-identical results)
   int linear = -1;         // "linear": -1 = "auto" = 1 = "f16x2" (gemm_h2: the GNN's plain linear layers -- q|k|v, mlp.0', mlp.3, final_proj where the
                            //         layer tail is not fused -- as three fp16 plane products, scaled by the operands' actual (side, pair) maxima; needs
                            //         "attention" = f16x2 and weights inside the spread guard), 0 = "bf16x3" (gemm_x3: six bf16 plane products)
@@ -247,7 +249,7 @@ struct AttnArgs {
   const unsigned* amax;          // [2 B][4]: bit patterns of max |q|, |k|, |v| over the valid rows of (side, pair) = (s, b) at [s B + b] (launch_qkv_amax,
                                  // or the producing gnn_tail_x3); non-null selects the two-plane fp16 form of attention_x3.hip (three term
                                  // products instead of six), null the bf16 x 3 form
-  int qblocks;                   // Options::attention_qblocks: 2 = two 32-query blocks per wave in the two-plane head-dim-32 kernel (0 / 1: one)
+  int qblocks;                   // Options::attention_qblocks: 2 = two 32-query blocks per wave in the two-plane head-dim-32 kernel, 1 = one, -1 / 0 = auto
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 hipError_t launch_qkv_amax(const AttnArgs& a, unsigned* amax, hipStream_t s);

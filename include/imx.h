@@ -248,6 +248,9 @@ IMX_API const char* imx_timing_form(imx_handle_t h, int index);
  *                           them), which run three bf16 planes; "f16x2" forces the fp16 form everywhere (the guard's A/B); "bf16x3"
  *                           three bf16 planes and six term products everywhere (the A/B reference; no range limit; both are closer to
  *                           a float64 evaluation than the fp32 MFMA form).
+ *   "attention_qblocks" "auto" (default) | "1" | "2": 32-query blocks per wave of the two-plane attention at head dim 32.  Two (a workgroup of
+ *                           256 queries: every staged key / value tile and every fragment read serves two blocks; bit-identical results)
+ *                           where the padded keypoint count is a multiple of 256 and one block per wave would still leave 1024 workgroups;
  *   "linear"         "auto" (default) = "f16x2": the plain linear layers of the GNN in the throughput path (every layer's q|k|v, mlp.0',
  *                           mlp.3 and final_proj where the layer tail is not fused -- descriptor_dim 256 --, layer 0's q|k|v otherwise) as
  *                           three fp16 plane products (gemm_h2): both operands as two fp16 planes, the weights scaled by one power of

@@ -436,3 +436,32 @@ def test_sinkhorn_next_slab_prefetch_is_bit_identical(name, monkeypatch):
         for i in range(3):
             assert np.array_equal(res["0"][0][i], res["1"][0][i]), (G, i)
         assert np.array_equal(res["0"][1], res["1"][1]) and np.array_equal(res["0"][2], res["1"][2]), G
+
+
+@pytest.mark.parametrize("name", ["c3_pair_s59.npz"])
+def test_two_query_blocks_per_wave_are_bit_identical(name):
+    """Round 6: attention_h2q2_kernel (two 32-query blocks per wave, the Q fragments of both in wave-private LDS) runs the one-block
+    kernel's instructions per query in the same order: GNN output, scores and matches bit for bit, on a full-size pair ("2" forces it
+    at one pair; "auto" takes it from 16 pairs up) and on a batch of three with ragged counts (keys and queries past a count)."""
+    g = util.golden(name)
+    H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
+    one = {k: v.cuda() for k, v in _oracle_pair_inputs(seed, H, W, d, K).items()}
+    three = {k: torch.cat([v, v.flip(-1 if k.startswith("desc") else 1), v], 0).contiguous() for k, v in one.items()}
+    n0 = torch.tensor([K, 700, 3], dtype=torch.int32, device="cuda")
+    n1 = torch.tensor([900, K, 1], dtype=torch.int32, device="cuda")
+    eng, L = _engine(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(d))
+    eng.set_option("latency_forms", "off")
+    eng.set_debug(True)
+    res = {}
+    for qb in ("1", "2"):
+        eng.set_option("attention_qblocks", qb)
+        assert eng.get_option("attention_qblocks") == qb
+        a = _run(eng, one, (1, 1, H, W))
+        xa, sa = eng.fetch("x").copy(), eng.fetch("scores_in").copy()
+        b = _run(eng, three, (1, 1, H, W), n0, n1)
+        res[qb] = (a, xa, sa, b, eng.fetch("x").copy())
+    for i in range(4):
+        assert np.array_equal(res["1"][0][i], res["2"][0][i]) and np.array_equal(res["1"][3][i], res["2"][3][i]), i
+    assert np.array_equal(res["1"][1], res["2"][1]) and np.array_equal(res["1"][2], res["2"][2]) and np.array_equal(res["1"][4], res["2"][4])
+    assert np.array_equal(res["2"][0][0], g["matches0"])
