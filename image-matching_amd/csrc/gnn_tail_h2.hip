@@ -71,7 +71,8 @@ __device__ __forceinline__ void image_barrier(int n) {
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// NW = 4 waves per workgroup, two workgroups of 128 rows per CU, 16-KB weight images of two k-steps (gnn_tail_x3.hip measured the grouping)
+// NW = 4 waves per workgroup, two workgroups of 128 rows per CU, 16-KB weight images of two k-steps (gnn_tail_x3.hip measured the grouping;
+// round 6, this kernel: NW = 8 -- one 256-row workgroup per CU, half the weight stream per row -- 2.86 against 2.70 ms per C3 step, same box)
 template <int NPASS, int NW>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void gnn_tail_h2_kernel(GnnTailArgs p) {
   constexpr int D = 128;
