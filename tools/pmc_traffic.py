@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # bench.py kernel name -> pattern on the rocprofv3 kernel name (tools/rocpd_pmc.py: short()).  The gemm_x3 instantiations are told
 # apart by their template arguments <BN, RES, RELU>: mlp.0 is the only one with ReLU, mlp.3 the only 128-column one with a residual;
 # <128, false, false> averages q|k|v (18 launches) with final_proj and convDb (1 each)
-NAMES = {"conv1ab_pool": r"conv1ab_wino24", "attention": r"attention_x3_kernel|attention_kernel", "sinkhorn": r"sinkhorn_slab",
+NAMES = {"conv1ab_pool": r"conv1ab_wino24", "attention": r"attention_h2q2_kernel|attention_x3_kernel|attention_kernel", "sinkhorn": r"sinkhorn_slab",
          "gnn_tail": r"gnn_tail_x3_kernel<3"}      # (round 4: the three gemm_x3 instantiations of a layer tail became gnn_tail_x3; the remaining
                                                    # gemm_x3 launches -- heads, keypoint encoder, layer 0's q|k|v -- share instantiations and are not split)
 
