@@ -1111,6 +1111,13 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     part = pt;
   }
   SinkhornArgs sk{S, u, v, B, N0p, N1p, sd[0].n, sd[1].n, N0, N1, h->bin_score, c.sinkhorn_iterations, part, h->opt.sinkhorn_group, h->opt.sinkhorn_prefetch};
+  if (h->debug && part) {        // developer instrumentation: the slab kernel's workgroup lives (all zeros unless sg_misc.hip was built with -DSK_TRACE)
+    const int Rs = sinkhorn_slab_rows(N1p), ng = N0p / Rs + 1;
+    WS(trc, unsigned long long, "sg.sk_trace", (size_t)B * ng * 8 * sizeof(unsigned long long));
+    HIP_OK(h, hipMemsetAsync(trc, 0, (size_t)B * ng * 8 * sizeof(unsigned long long), s));
+    sk.trace = trc;
+    tap(h, "sk_trace", trc, {(int64_t)B * ng, 16});
+  }
   RUN("sinkhorn", launch_sinkhorn(sk, s));
   MatchArgs ma{S, u, v, B, N0p, N1p, sd[0].n, sd[1].n, N0, N1, h->bin_score, c.match_threshold,
                max0, idx0, max1, idx1, m0, m1, ms0, ms1};

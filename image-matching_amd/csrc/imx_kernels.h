@@ -301,6 +301,8 @@ struct SinkhornArgs {
   float* part;               // scratch (B, N0p/R + 1, N1p + 1, 2) for the slab form, R = sinkhorn_slab_rows(N1p); may be null
   int group = 0;             // Options::sinkhorn_group (0 = auto)
   int prefetch = -1;         // Options::sinkhorn_prefetch (-1 = auto)
+  unsigned long long* trace = nullptr;   // developer instrumentation (a -DSK_TRACE build of sg_misc.hip only; tools/sinkhorn_trace.py): eight 64-bit words per
+                                         // slab-kernel workgroup of the LAST iteration -- s_memrealtime at entry / after each slab / at exit, HW_ID, XCC_ID
 };
 int sinkhorn_slab_rows(int N1p);
 hipError_t launch_sinkhorn(const SinkhornArgs& a, hipStream_t s);

@@ -176,8 +176,13 @@ __global__ __launch_bounds__(1024) void sinkhorn_cols(SinkhornArgs a) {
 // the NEXT slab's row (one dword per line and lane: 32 lines of a 1024-column segment in one instruction, one register, result
 // unused), so the next row pass's float4 loads find their lines on the way or in L2 instead of starting an HBM latency after the
 // barrier.  Same loads, same arithmetic: bit-identical.
+#ifdef SK_SGPRS      // (experiments: cap the slab kernel's scalar registers)
+#define SK_SGPR_ATTR __attribute__((amdgpu_num_sgpr(SK_SGPRS)))
+#else
+#define SK_SGPR_ATTR
+#endif
 template <int R, int NW, int G, bool PF>
-__global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* __restrict__ part, int ngroup_max) {   // (eight waves per SIMD: <= 64 registers)
+__global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornArgs a, float* __restrict__ part, int ngroup_max) {   // (eight waves per SIMD: <= 64 registers)
   extern __shared__ float sm[];
   float* tile = sm;                       // [R][N1p]
   float* vs = tile + R * a.N1p;           // [N1p + 1]
@@ -187,6 +192,14 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
   int m, n;
   counts(a, b, m, n);
   if (m == 0 || n == 0 || grp * G * R > m) return;
+#ifdef SK_TRACE
+  // workgroup lives: the 100-MHz constant clock at entry, after each slab and at exit, and where the workgroup ran
+  unsigned long long* const trw = a.trace ? a.trace + ((size_t)b * ngroup_max + grp) * 8 : nullptr;
+  if (trw && tid == 0) {
+    trw[0] = __builtin_amdgcn_s_memrealtime();
+    trw[6] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);   // XCC_ID | HW_ID
+  }
+#endif
   const float* v = a.v + (size_t)b * (a.N1p + 1);
   for (int j = tid; j <= n; j += 64 * NW) vs[j] = v[j];
   __syncthreads();
@@ -380,6 +393,9 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
     const LSE t = generic_col(n);
     cdust = lse_merge(cdust, t);
   }
+#ifdef SK_TRACE
+  if (trw && tid == 0 && g < 4) trw[1 + g] = __builtin_amdgcn_s_memrealtime();
+#endif
   }  // slabs of the group
   float2* pb = reinterpret_cast<float2*>(part + ((size_t)b * ngroup_max + grp) * (a.N1p + 1) * 2);
 #pragma unroll
@@ -388,6 +404,9 @@ __global__ __launch_bounds__(64 * NW) void sinkhorn_slab(SinkhornArgs a, float* 
     if (j < n) pb[j] = make_float2(cacc[c].m, cacc[c].s);
   }
   if (tid == 0) pb[n] = make_float2(cdust.m, cdust.s);
+#ifdef SK_TRACE
+  if (trw && tid == 0) trw[5] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // v[j] = log_nu[j] - logsumexp over the slabs' partial (max, sum) pairs.  64 columns x 16 slab groups per
