@@ -176,14 +176,20 @@ __global__ __launch_bounds__(1024) void sinkhorn_cols(SinkhornArgs a) {
 // the NEXT slab's row (one dword per line and lane: 32 lines of a 1024-column segment in one instruction, one register, result
 // unused), so the next row pass's float4 loads find their lines on the way or in L2 instead of starting an HBM latency after the
 // barrier.  Same loads, same arithmetic: bit-identical.
-#ifdef SK_SGPRS      // (experiments: cap the slab kernel's scalar registers)
-#define SK_SGPR_ATTR __attribute__((amdgpu_num_sgpr(SK_SGPRS)))
-#else
-#define SK_SGPR_ATTR
+// Scalar registers capped at 80 (round 6): a CU holds eight waves per SIMD only while a wave's scalar allocation is <= 80 -- measured with
+// the workgroup-life stamps below (tools/sinkhorn_trace.py, profiles/r06_sinkhorn_trace.txt): at 82-87 scalar registers the compiler still
+// reports occupancy 8, but the chip ran 3 of the 8-wave workgroups per CU at C3 instead of 4 and ONE of the 16-wave workgroups at C5
+// instead of two (the C5 launch was two rounds of 256 workgroups).  With the cap the few spilled scalars cost one vector register
+// (hence `cdust` in LDS: 64 -> 62 registers before the cap) and the C5 iteration went from 34 to 29 us (8 pairs), the C3 one from 60 to 54.
+#ifndef SK_SGPRS
+#define SK_SGPRS 80
 #endif
+#define SK_SGPR_ATTR __attribute__((amdgpu_num_sgpr(SK_SGPRS)))
 template <int R, int NW, int G, bool PF>
 __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornArgs a, float* __restrict__ part, int ngroup_max) {   // (eight waves per SIMD: <= 64 registers)
-  extern __shared__ float sm[];
+  // (16-byte aligned: the dynamic array starts behind the static ones, and at an 8-byte offset the b128 accesses of `tile` run at half
+  // rate -- measured: two more static floats took the C5 iteration from 3.98 to 6.26 ms)
+  extern __shared__ __align__(16) float sm[];
   float* tile = sm;                       // [R][N1p]
   float* vs = tile + R * a.N1p;           // [N1p + 1]
   __shared__ float uu[R];
@@ -205,7 +211,9 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
   __syncthreads();
   const float norm = -logf((float)(m + n));
   constexpr int MAXC = R == 4 ? 4 : 2;    // real columns per thread: N1p / (64 NW) -- N1p <= 1024 with 8 waves, <= 2048 with 16 (R >= 8), <= 4096 with 16 (R = 4)
-  LSE cacc[MAXC], cdust{-INFINITY, 0.f};  // (the dustbin column j = n: thread 0's)
+  LSE cacc[MAXC];
+  __shared__ float cdust[2];               // the dustbin column j = n: thread 0's running (max, sum), in LDS -- two registers of every lane otherwise
+  if (tid == 0) { cdust[0] = -INFINITY; cdust[1] = 0.f; }
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) cacc[c] = LSE{-INFINITY, 0.f};
   [[maybe_unused]] float pf_line = 0.f;   // (PF: the touched word of the next slab's row segment)
@@ -391,7 +399,8 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
   __builtin_amdgcn_sched_barrier(0);
   if (tid == 0) {
     const LSE t = generic_col(n);
-    cdust = lse_merge(cdust, t);
+    const LSE c2 = lse_merge(LSE{cdust[0], cdust[1]}, t);
+    cdust[0] = c2.m; cdust[1] = c2.s;
   }
 #ifdef SK_TRACE
   if (trw && tid == 0 && g < 4) trw[1 + g] = __builtin_amdgcn_s_memrealtime();
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
     const int j = tid + c * 64 * NW;
     if (j < n) pb[j] = make_float2(cacc[c].m, cacc[c].s);
   }
-  if (tid == 0) pb[n] = make_float2(cdust.m, cdust.s);
+  if (tid == 0) pb[n] = make_float2(cdust[0], cdust[1]);
 #ifdef SK_TRACE
   if (trw && tid == 0) trw[5] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -614,7 +623,9 @@ static void launch_slab_k(const SinkhornArgs& a, int nslab_max, int G, hipStream
   // 1.98 -> 2.01 with it).  Measured and dropped beside it: dispatching every pair's short last group (the dustbin row's slab) after
   // all full groups, so that the leftovers of 520 workgroups on 512 slots are the short ones -- 4.19 -> 4.29 ms at C5, nothing at C3
   // (tools/sinkhorn_time.py --prefetch 0 1; the handle option "sinkhorn_prefetch" = auto | off | on overrides)
-  const bool p = a.prefetch < 0 ? NW == 16 : a.prefetch != 0;
+  // Round 6: with the scalar-register cap two 16-wave workgroups ARE resident per CU and cover each other: C5 3.58 -> 3.49 ms without it,
+  // C3 1.92 -> 1.85.  Off unless asked for.
+  const bool p = a.prefetch > 0;
   if (G == 4) { if (p) launch_slab_g<R, NW, 4, true>(a, nslab_max, s); else launch_slab_g<R, NW, 4, false>(a, nslab_max, s); }
   else if (G == 2) { if (p) launch_slab_g<R, NW, 2, true>(a, nslab_max, s); else launch_slab_g<R, NW, 2, false>(a, nslab_max, s); }
   else launch_slab_g<R, NW, 1, false>(a, nslab_max, s);
@@ -650,7 +661,13 @@ hipError_t launch_sinkhorn(const SinkhornArgs& a, hipStream_t s) {
     // chip anyway (the handle option "sinkhorn_group" overrides: the A/B switch of the parity tests; 1 = a partial per slab, as before round 5)
     // (measured, tools/sinkhorn_time.py: C3, 129 slabs of 1024 columns x 64 pairs: 2.28 / 2.02 / 2.03 ms per 30 iterations with 1 / 2 / 4
     // slabs per workgroup; C5, 257 slabs of 2048 columns x 8 pairs: 4.49 / 4.63 / 4.18 per 100)
-    int G = a.N0p / R + 1 < 64 ? 1 : a.N1p <= 1024 ? 2 : 4;
+    // (round 6, eight waves per SIMD resident: C3 x 64 pairs 1.99 / 1.82 ms per 30 iterations with 2 / 4 slabs per workgroup -- four where
+    // the groups of four still fill the 1024 workgroup slots of the 8-wave form)
+    // the most slabs per workgroup (4, 2, 1) whose groups still fill the resident workgroup slots (1024 of the 8-wave form, 512 of the
+    // 16-wave one): C3 x 1 pair 0.276 / 0.320 / 0.445 ms with 1 / 2 / 4, x 16 pairs 0.755 / 0.686 / 0.743, x 64 pairs - / 2.01 / 1.85
+    const int nsl = a.N0p / R + 1;
+    const long slots = a.N1p <= 1024 ? 1024 : 512;
+    int G = (long)((nsl + 3) / 4) * a.B >= slots ? 4 : (long)((nsl + 1) / 2) * a.B >= slots ? 2 : 1;
     if (a.group == 1 || a.group == 2 || a.group == 4) G = a.group;
     const int nslab_max = (a.N0p / R + 1 + G - 1) / G;           // groups per pair = the partial buffer's rows per pair (<= N0p / R + 1: a.part's size)
     // (Round 5: walking the batch in groups whose score matrices fit the 256-MB Infinity Cache -- all iterations of a group back to

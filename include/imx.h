@@ -263,8 +263,9 @@ IMX_API const char* imx_timing_form(imx_handle_t h, int index);
  * equal matches); none of them is read from the environment:
  *   "conv_swizzle"      "on" (default) the tensor between two pair-form 3x3 layers without a pool is tile-swizzled; "off": blocked;
  *   "qkv_amax"          "epilogue" (default) a plain q|k|v projection writes the (side, pair) maxima in its epilogue; "kernel": a separate pass;
- *   "sinkhorn_group"    "auto" (default: 2 slabs per workgroup up to 1024 columns, 4 above, 1 below 64 slabs) | "1" | "2" | "4";
- *   "sinkhorn_prefetch" "auto" (default: on for the 16-wave form, i.e. above 1024 columns) | "off" | "on".
+ *   "sinkhorn_group"    "auto" (default: the most slabs per workgroup -- 4, 2 or 1 -- whose groups still fill the chip's resident
+ *                       workgroup slots: 1024 up to 1024 columns, 512 above) | "1" | "2" | "4";
+ *   "sinkhorn_prefetch" "auto" (default: off since round 6 -- two 16-wave workgroups per CU cover each other) | "off" | "on".
  * Read-only (imx_get_option only): "arith_guard" -- what the weights-derived guards decided at imx_finalize_weights: the largest spread
  * of a layer's transformed convolution weights and the pipe the 3x3 chain runs on, the GNN layers whose tail runs bf16x3, the largest
  * bound looseness, the layers whose attention runs bf16x3 with the largest q|k|v channel spread, the largest spread of the plain
