@@ -172,10 +172,11 @@ __global__ __launch_bounds__(1024) void sinkhorn_cols(SinkhornArgs a) {
 // as many workgroups resident per CU to cover each other's load latency and barriers.
 // Round 5: a workgroup walks G consecutive slabs and merges their column partials in registers before writing them: the partials
 // were 2 x 68 MB of an iteration's traffic at C3 (written here, read by sinkhorn_vmerge) beside the 268 MB of S.
-// PF (round 5, IMX_SINKHORN_PREFETCH): before a slab's barriers and column pass, each wave touches the 128-byte lines of ITS segment of
-// the NEXT slab's row (one dword per line and lane: 32 lines of a 1024-column segment in one instruction, one register, result
-// unused), so the next row pass's float4 loads find their lines on the way or in L2 instead of starting an HBM latency after the
-// barrier.  Same loads, same arithmetic: bit-identical.
+// PF ("sinkhorn_prefetch" = on; off by default): once a slab's row segment has been written to LDS, the wave loads ITS segment of the NEXT
+// slab's row into the same registers, where it stays in flight through the reductions, both barriers and the column pass.  Same loads, same
+// arithmetic: bit-identical.  Round 5's form only touched the lines (4.20 -> 4.03 ms at C5 with ONE workgroup resident per CU); with two
+// resident (below) neither form pays: C5 3.43 ms without, 3.95 with (G = 2, equal occupancy), C3 1.98 / 1.99 -- the other workgroups of
+// the CU already cover the latency, and the 16 registers cost the G = 4 form its eighth wave (profiles/r06_sinkhorn_trace.txt, sk22).
 // Scalar registers capped at 80 (round 6): a CU holds eight waves per SIMD only while a wave's scalar allocation is <= 80 -- measured with
 // the workgroup-life stamps below (tools/sinkhorn_trace.py, profiles/r06_sinkhorn_trace.txt): at 82-87 scalar registers the compiler still
 // reports occupancy 8, but the chip ran 3 of the 8-wave workgroups per CU at C3 instead of 4 and ONE of the 16-wave workgroups at C5
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
   float* tile = sm;                       // [R][N1p]
   float* vs = tile + R * a.N1p;           // [N1p + 1]
   __shared__ float uu[R];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: row pointers in scalar registers)
   const int b = blockIdx.y, grp = blockIdx.x;
   int m, n;
   counts(a, b, m, n);
@@ -216,7 +217,9 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
   if (tid == 0) { cdust[0] = -INFINITY; cdust[1] = 0.f; }
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) cacc[c] = LSE{-INFINITY, 0.f};
-  [[maybe_unused]] float pf_line = 0.f;   // (PF: the touched word of the next slab's row segment)
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  [[maybe_unused]] f32x4 xr[4];           // the fast row path's batch of S; with PF it may already hold the NEXT slab's segment
+  [[maybe_unused]] bool have = false;     // (PF) xr was loaded for this slab by the previous one (wave-uniform)
   // (G is a template parameter and the loop fully unrolled: as a run-time loop hipcc keeps 40 more vector and 50 more scalar registers
   // across the slabs -- 81 / 105 against 43 / 58 -- and the kernel falls off its eight waves per SIMD)
 #pragma unroll
@@ -244,17 +247,28 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
         // no bounds or count masks, and the adds / fmas / partial sums as packed f32x4 operations -- on this SIMD every VALU
         // instruction costs matrix-pipe-free but real issue time, and the masked form spends a third of its instructions on
         // compares and selects.
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        f32x4 x[4], t4[4];
+        f32x4 t4[4];
+        if (!(PF && have)) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = *reinterpret_cast<const f32x4*>(Srow + jlo + k * 256 + lane * 4);
+          for (int k = 0; k < 4; ++k) xr[k] = *reinterpret_cast<const f32x4*>(Srow + jlo + k * 256 + lane * 4);
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int j = jlo + k * 256 + lane * 4;
-          *reinterpret_cast<f32x4*>(trow + j) = x[k];
-          t4[k] = x[k] + *reinterpret_cast<const f32x4*>(vs + j);
+          *reinterpret_cast<f32x4*>(trow + j) = xr[k];
+          t4[k] = xr[k] + *reinterpret_cast<const f32x4*>(vs + j);
           mx = fmaxf(fmaxf(mx, fmaxf(t4[k][0], t4[k][1])), fmaxf(t4[k][2], t4[k][3]));
+        }
+        if constexpr (PF && G > 1) {
+          // xr is dead: the NEXT slab's segment of this wave goes into it now and stays in flight through the reductions, both barriers
+          // and the column pass (round 6; the round-5 form only touched the lines, which left the L2 -> register latency after the barrier)
+          have = g + 1 < G && i + R < m;
+          __builtin_amdgcn_sched_barrier(0);         // (not before xr's last use: hoisted, the loads take a second set of registers)
+          if (have) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xr[k] = *reinterpret_cast<const f32x4*>(Srow + (size_t)R * a.N1p + jlo + k * 256 + lane * 4);
+          }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -271,6 +285,7 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
         acc = LSE{mx, lse_unbias(sum, mx, ml)};
       } else if (jlo < n) {
+        have = false;
         float4 x[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -314,7 +329,6 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
     if (i <= m && seg == W - 1 && lane == 0) lse_add(acc, a.alpha + vs[n]);      // the dustbin column, once per row
     if (lane == 0) { pm[wave] = acc.m; ps[wave] = acc.s; }
   }
-  if constexpr (PF && G > 1) { if (g > 0) asm volatile("" :: "v"(pf_line)); }
   __syncthreads();
   if (tid < R && i0 + tid <= m) {
     LSE t{pm[tid * W], ps[tid * W]};
@@ -327,13 +341,6 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
     a.u[(size_t)b * (a.N0p + 1) + i] = ui;
   }
   __syncthreads();
-  if constexpr (PF && G > 1) {
-    // (a plain load whose value is only "used" by an empty asm after the NEXT slab's row pass, where every load of the wave has been
-    // consumed: the compiler's own vmcnt tracking keeps the register until then and the wait it inserts there is free.  A volatile
-    // load becomes flat_load sc0 sc1 + vmcnt(0) on the spot -- a stall, not a prefetch.)
-    const int i = i0 + R + wave / W, seglen = a.N1p / W;
-    if (g + 1 < G && i < m && lane * 32 < seglen) pf_line = a.S[((size_t)b * a.N0p + i) * a.N1p + (wave % W) * seglen + lane * 32];
-  }
   const int rows = min(R, m + 1 - i0);      // rows of this slab, the last may be the dustbin row
   // all R rows REAL (i0 + R <= m): `rows == R` alone also admits a slab whose last row is the dustbin row i == m
   // (m % R == R-1), and that row of `tile` is never written by the row pass
@@ -623,8 +630,8 @@ static void launch_slab_k(const SinkhornArgs& a, int nslab_max, int G, hipStream
   // 1.98 -> 2.01 with it).  Measured and dropped beside it: dispatching every pair's short last group (the dustbin row's slab) after
   // all full groups, so that the leftovers of 520 workgroups on 512 slots are the short ones -- 4.19 -> 4.29 ms at C5, nothing at C3
   // (tools/sinkhorn_time.py --prefetch 0 1; the handle option "sinkhorn_prefetch" = auto | off | on overrides)
-  // Round 6: with the scalar-register cap two 16-wave workgroups ARE resident per CU and cover each other: C5 3.58 -> 3.49 ms without it,
-  // C3 1.92 -> 1.85.  Off unless asked for.
+  // Round 6: with the scalar-register cap two 16-wave workgroups ARE resident per CU and cover each other: off unless asked for
+  // (measurements at the kernel's head comment).
   const bool p = a.prefetch > 0;
   if (G == 4) { if (p) launch_slab_g<R, NW, 4, true>(a, nslab_max, s); else launch_slab_g<R, NW, 4, false>(a, nslab_max, s); }
   else if (G == 2) { if (p) launch_slab_g<R, NW, 2, true>(a, nslab_max, s); else launch_slab_g<R, NW, 2, false>(a, nslab_max, s); }
