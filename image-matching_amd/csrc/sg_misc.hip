@@ -175,7 +175,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_cols(SinkhornArgs a) {
 // PF ("sinkhorn_prefetch" = on; off by default): once a slab's row segment has been written to LDS, the wave loads ITS segment of the NEXT
 // slab's row into the same registers, where it stays in flight through the reductions, both barriers and the column pass.  Same loads, same
 // arithmetic: bit-identical.  Round 5's form only touched the lines (4.20 -> 4.03 ms at C5 with ONE workgroup resident per CU); with two
-// resident (below) neither form pays: C5 3.43 ms without, 3.95 with (G = 2, equal occupancy), C3 1.98 / 1.99 -- the other workgroups of
+// resident (below) neither form pays: C5 3.78 ms without, 3.95 with (G = 2, equal occupancy), C3 1.98 / 1.99 -- the other workgroups of
 // the CU already cover the latency, and the 16 registers cost the G = 4 form its eighth wave (profiles/r06_sinkhorn_trace.txt, sk22).
 // Scalar registers capped at 80 (round 6): a CU holds eight waves per SIMD only while a wave's scalar allocation is <= 80 -- measured with
 // the workgroup-life stamps below (tools/sinkhorn_trace.py, profiles/r06_sinkhorn_trace.txt): at 82-87 scalar registers the compiler still
