@@ -41,6 +41,36 @@ __device__ __forceinline__ LSE wave_lse(LSE a) {
   return a;
 }
 __device__ __forceinline__ float lse_value(const LSE& a) { return a.m + logf(a.s); }
+// Wave-wide max / sum of the slab kernel's row pass as DPP operations (round 6): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+// leave every lane of a 16-lane row with the row's result, row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3) carry it to the last row,
+// v_readlane 63 hands it back as a scalar: 6 VALU instructions and no LDS round trip, where __shfl_xor was 6 x (ds_bpermute + its
+// address arithmetic + a wait on the LDS queue).  All 64 lanes must be active (the row pass branches on the wave index only).
+// (inline assembly: through __builtin_amdgcn_update_dpp every step became v_mov + v_mov_dpp + a canonicalising v_max + the operation;
+// s_nop 1 = the two wait states between a VALU write and a DPP read of the same register)
+#define IMX_WAVE_REDUCE_DPP(OP)                                                   \
+  asm volatile("s_nop 1\n\t"                                                      \
+               OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+               "s_nop 1\n\t"                                                      \
+               OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+               "s_nop 1\n\t"                                                      \
+               OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
+               "s_nop 1\n\t"                                                      \
+               OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"          \
+               "s_nop 1\n\t"                                                      \
+               OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"        \
+               "s_nop 1\n\t"                                                      \
+               OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"        \
+               "s_nop 1"                                                          \
+               : "+v"(v))
+__device__ __forceinline__ float wave_max_u(float v) {
+  IMX_WAVE_REDUCE_DPP("v_max_f32_dpp");
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_sum_u(float v) {
+  IMX_WAVE_REDUCE_DPP("v_add_f32_dpp");
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float uniform_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 // The two-pass forms below evaluate exp(t - mx) as exp2(fma(t, LOG2E, ml)) with ml = -(mx * LOG2E) ROUNDED: every term of a sum
 // then carries the common factor 2^d, d = fma(mx, LOG2E, ml) = the product's rounding error (exact; up to 1.5e-5 at |mx| ~ 250,
 // i.e. a 1e-5 bias of that log-sum-exp -- round 3: on a 7 x 64 transport problem with |Z| ~ 230 it put Z 3.3x further from float64
@@ -210,7 +240,9 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
   const float* v = a.v + (size_t)b * (a.N1p + 1);
   for (int j = tid; j <= n; j += 64 * NW) vs[j] = v[j];
   __syncthreads();
-  const float norm = -logf((float)(m + n));
+  // (scalars: left to the compiler, both logarithms were re-evaluated by every wave in every slab -- 35 instructions of a slab's 270)
+  const float norm = uniform_f(-logf((float)(m + n)));
+  const float log_mu_dust = uniform_f(logf((float)n) + norm);
   constexpr int MAXC = R == 4 ? 4 : 2;    // real columns per thread: N1p / (64 NW) -- N1p <= 1024 with 8 waves, <= 2048 with 16 (R >= 8), <= 4096 with 16 (R = 4)
   LSE cacc[MAXC];
   __shared__ float cdust[2];               // the dustbin column j = n: thread 0's running (max, sum), in LDS -- two registers of every lane otherwise
@@ -270,8 +302,7 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
             for (int k = 0; k < 4; ++k) xr[k] = *reinterpret_cast<const f32x4*>(Srow + (size_t)R * a.N1p + jlo + k * 256 + lane * 4);
           }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        mx = wave_max_u(mx);
         const float ml = -mx * LOG2E;                 // mx is finite: real scores
         const f32x4 l2e = {LOG2E, LOG2E, LOG2E, LOG2E}, ml4 = {ml, ml, ml, ml};
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
@@ -281,8 +312,7 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
           s4 += (f32x4){__builtin_amdgcn_exp2f(a4[0]), __builtin_amdgcn_exp2f(a4[1]), __builtin_amdgcn_exp2f(a4[2]), __builtin_amdgcn_exp2f(a4[3])};
         }
         float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        sum = wave_sum_u(sum);
         acc = LSE{mx, lse_unbias(sum, mx, ml)};
       } else if (jlo < n) {
         have = false;
@@ -309,8 +339,7 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
 #pragma unroll
           for (int c = 0; c < 4; ++c) mx = fmaxf(mx, t[4 * k + c]);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        mx = wave_max_u(mx);
         float sum = 0.f;
         if (mx > -INFINITY) {
           const float ml = -mx * LOG2E;
@@ -318,8 +347,7 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
           for (int e = 0; e < 16; ++e) sum += __builtin_amdgcn_exp2f((t[e] - mx) * LOG2E);      // exp(t - mx); -inf -> 0
           (void)ml;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        sum = wave_sum_u(sum);
         acc = LSE{mx, sum};
       }
     } else if (i == m) {
@@ -335,7 +363,7 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
 #pragma unroll
     for (int k = 1; k < W; ++k) t = lse_merge(t, LSE{pm[tid * W + k], ps[tid * W + k]});
     const int i = i0 + tid;
-    const float log_mu = i < m ? norm : logf((float)n) + norm;
+    const float log_mu = i < m ? norm : log_mu_dust;
     const float ui = log_mu - lse_value(t);
     uu[tid] = ui;
     a.u[(size_t)b * (a.N0p + 1) + i] = ui;
