@@ -32,6 +32,13 @@ __device__ __forceinline__ LSE lse_merge(const LSE& a, const LSE& b) {
   const float eb = (b.m == -INFINITY) ? 0.f : exp_neg(nm - b.m);
   return LSE{nm, a.s * ea + b.s * eb};
 }
+// b.m finite (a slab's column always holds a row): ONE exponential -- of the two factors of lse_merge one is exp(0) = 1.  An empty
+// accumulator (a.m = -inf, a.s = 0): d = -inf, e = 0, the sum is b's.
+__device__ __forceinline__ LSE lse_merge1(const LSE& a, const LSE& b) {
+  const float d = a.m - b.m;
+  const float e = exp_neg(fabsf(d));
+  return LSE{fmaxf(a.m, b.m), d >= 0.f ? fmaf(b.s, e, a.s) : fmaf(a.s, e, b.s)};
+}
 __device__ __forceinline__ LSE wave_lse(LSE a) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -244,9 +251,7 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
   const float norm = uniform_f(-logf((float)(m + n)));
   const float log_mu_dust = uniform_f(logf((float)n) + norm);
   constexpr int MAXC = R == 4 ? 4 : 2;    // real columns per thread: N1p / (64 NW) -- N1p <= 1024 with 8 waves, <= 2048 with 16 (R >= 8), <= 4096 with 16 (R = 4)
-  LSE cacc[MAXC];
-  __shared__ float cdust[2];               // the dustbin column j = n: thread 0's running (max, sum), in LDS -- two registers of every lane otherwise
-  if (tid == 0) { cdust[0] = -INFINITY; cdust[1] = 0.f; }
+  LSE cacc[MAXC];                         // (the dustbin column j = n needs no S: sinkhorn_vmerge takes it from u, round 6)
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) cacc[c] = LSE{-INFINITY, 0.f};
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
           s4 += (f32x4){__builtin_amdgcn_exp2f(a4[0]), __builtin_amdgcn_exp2f(a4[1]), __builtin_amdgcn_exp2f(a4[2]), __builtin_amdgcn_exp2f(a4[3])};
         }
         const LSE t{mx, lse_unbias((s4[0] + s4[1]) + (s4[2] + s4[3]), mx, ml)};
-        cacc[c] = lse_merge(cacc[c], t);                              // (the first slab: exp(0) = 1 and an empty accumulator's 0 -- the pair as computed)
+        cacc[c] = lse_merge1(cacc[c], t);
       }
     }
   } else {
@@ -427,15 +432,9 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
       const int j = tid + c * 64 * NW;
       if (j < n) {
         const LSE t = generic_col(j);
-        cacc[c] = lse_merge(cacc[c], t);
+        cacc[c] = lse_merge1(cacc[c], t);
       }
     }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  if (tid == 0) {
-    const LSE t = generic_col(n);
-    const LSE c2 = lse_merge(LSE{cdust[0], cdust[1]}, t);
-    cdust[0] = c2.m; cdust[1] = c2.s;
   }
 #ifdef SK_TRACE
   if (trw && tid == 0 && g < 4) trw[1 + g] = __builtin_amdgcn_s_memrealtime();
@@ -447,7 +446,6 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
     const int j = tid + c * 64 * NW;
     if (j < n) pb[j] = make_float2(cacc[c].m, cacc[c].s);
   }
-  if (tid == 0) pb[n] = make_float2(cdust[0], cdust[1]);
 #ifdef SK_TRACE
   if (trw && tid == 0) trw[5] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -466,7 +464,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_vmerge(SinkhornArgs a, const fl
   // two-pass merges: the maximum of the (max, sum) pairs first, then ONE exp per pair -- a chain of pairwise lse_merge()
   // spends two exps (quarter-rate instructions) and two selects per pair
   LSE t{-INFINITY, 0.f};
-  if (j <= n) {
+  if (j < n) {
     const float2* pb = reinterpret_cast<const float2*>(part + (size_t)b * nslab_max * (a.N1p + 1) * 2) + j;
     for (int s0 = g; s0 < nslab; s0 += 64) {
       float2 q[4];
@@ -486,6 +484,25 @@ __global__ __launch_bounds__(1024) void sinkhorn_vmerge(SinkhornArgs a, const fl
       }
     }
   }
+  // The dustbin column j = n holds alpha in every row i <= m: its log-sum-exp over (alpha + u[i]) needs no S and no slab partial (round 6:
+  // thread 0 of every slab workgroup used to walk it, 8 LDS reads and ~80 instructions per slab on the wave the others wait for).  The
+  // block that owns column n reduces it here, 1024 rows at a time: wave maximum and sum (two-pass), waves merged through LDS below.
+  __shared__ float dm[16], ds[16];
+  const bool dust_block = (int)blockIdx.x == n / 64;       // (block-uniform)
+  if (dust_block) {
+    const float* u = a.u + (size_t)b * (a.N0p + 1);
+    LSE d{-INFINITY, 0.f};
+    for (int i0 = 0; i0 <= m; i0 += 1024) {
+      const int i = i0 + (int)threadIdx.x;
+      const float x = i <= m ? a.alpha + u[i] : -INFINITY;
+      const float mx = wave_max_u(x);
+      if (mx > -INFINITY) {                                // (wave-uniform)
+        const float sum = wave_sum_u(__builtin_amdgcn_exp2f((x - mx) * LOG2E));
+        d = lse_merge(d, LSE{mx, sum});
+      }
+    }
+    if (c == 0) { dm[g] = d.m; ds[g] = d.s; }            // (c = lane, g = wave)
+  }
   pm[g][c] = t.m;
   ps[g][c] = t.s;
   __syncthreads();
@@ -499,6 +516,11 @@ __global__ __launch_bounds__(1024) void sinkhorn_vmerge(SinkhornArgs a, const fl
     for (int k = 0; k < 16; ++k) sum = fmaf(ps[k][c], __builtin_amdgcn_exp2f((pm[k][c] - nm) * LOG2E), sum);
     (void)ml;
     t = LSE{nm, sum};
+    if (j == n) {
+      t = LSE{dm[0], ds[0]};
+#pragma unroll
+      for (int k = 1; k < 16; ++k) t = lse_merge(t, LSE{dm[k], ds[k]});
+    }
     const float norm = -logf((float)(m + n));
     const float log_nu = j < n ? norm : logf((float)m) + norm;
     a.v[(size_t)b * (a.N1p + 1) + j] = log_nu - lse_value(t);
