@@ -103,7 +103,7 @@ struct imx_handle_s {
   int upload_net = 0;                    // net whose finalize is running (upload() files allocations under it)
   // SuperPoint
   float *w1 = nullptr, *b1 = nullptr;
-  float c1a_l1 = 0.f, c1a_bmax = 0.f;
+  float c1a_l1 = 0.f, c1a_bmax = 0.f, c1a_spread = 1.f;   // (c1a_spread: max over median of conv1a's output-channel maxima, the fp16-plane guard)
   ConvW conv[8];   // conv1b, 2a, 2b, 3a, 3b, 4a, 4b, heads (convPa | convDa)
   GemmW pb, db;
   // SuperGlue
@@ -473,6 +473,18 @@ int finalize_superpoint(imx_handle_t h) {
       h->c1a_bmax = std::max(h->c1a_bmax, std::fabs(b[c]));
     }
     h->c1a_l1 = std::max(h->c1a_l1, 1e-30f);
+    // conv1a's weights meet no fp16 scale (fp32 pipe), but an output channel far above the others is what conv1b's input transform then
+    // sees -- one channel owning the tile's power of two, the typical channel 2^k below it.  wino24h_pack's statistic on the plain
+    // weights (the rescale conv1a x 2^k / conv1b's column x 2^-k showed in no transformed-weight table)
+    std::vector<double> comax(64, 0.0);
+    double wmax = 0.0;
+    for (int t = 0; t < 9; ++t)
+      for (int c = 0; c < 64; ++c) {
+        comax[c] = std::max(comax[c], (double)std::fabs(w[t * 64 + c]));
+        wmax = std::max(wmax, comax[c]);
+      }
+    std::nth_element(comax.begin(), comax.begin() + 32, comax.end());
+    h->c1a_spread = comax[32] > 0 ? (float)std::min(3.0e38, wmax / comax[32]) : (wmax > 0 ? 3.0e38f : 1.f);
   }
   const int cin[8] = {1, 64, 64, 64, 64, 128, 128, 128}, cout[8] = {64, 64, 64, 64, 128, 128, 128, 128};
   for (int i = 1; i < 8; ++i)
@@ -751,6 +763,7 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   // 2^14 below the largest |U| (a checkpoint with one runaway channel) would push that channel's weights under 2^-3 x 2^13 / 2^14 and
   // lose the low plane -- the whole chain then runs the fp32-MFMA Winograd kernels ("conv" reports it through imx_timing_form)
   for (int i = 1; i < 8; ++i) all_h = all_h && h->conv[i].wuh != nullptr && h->conv[i].u_spread <= kConvSpreadMax;
+  all_h = all_h && h->conv[0].wuh != nullptr && h->conv[0].u_spread <= kConvSpreadMax && h->c1a_spread <= kConvSpreadMax;   // (conv1b; conv1a's plain output channels)
   // The maxima live in 256 slots per layer (the kernels' LDS tables): a batch of more than 256 images runs its 3x3 layers in slices of
   // 256 images, each with its own tables, so that an image's scales -- and with them its low-order bits -- never depend on which other
   // images share the call (tests/test_gpu_superpoint.py: image b of a 260-image batch equals the same image alone).
@@ -1684,8 +1697,8 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     else if (k == "sinkhorn_prefetch") h->opt_text = o.sinkhorn_prefetch < 0 ? "auto" : o.sinkhorn_prefetch ? "on" : "off";
     else if (k == "arith_guard") {      // read-only: what the weights-derived guards decided (after imx_finalize_weights)
       char buf[96];
-      float sp = 0.f;
-      for (int i = 1; i < 8; ++i) sp = std::max(sp, h->conv[i].u_spread);
+      float sp = h->c1a_spread;
+      for (int i = 0; i < 8; ++i) sp = std::max(sp, h->conv[i].u_spread);
       snprintf(buf, sizeof buf, "conv: max spread 2^%.1f -> %s; gnn_tail bf16x3 layers:", std::log2(std::max(sp, 1.f)), sp <= kConvSpreadMax ? "f16x2" : "f32");
       h->opt_text = buf;
       for (size_t l = 0; l < h->layers.size(); ++l)

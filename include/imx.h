@@ -269,7 +269,7 @@ IMX_API const char* imx_timing_form(imx_handle_t h, int index);
  * Read-only (imx_get_option only): "arith_guard" -- what the weights-derived guards decided at imx_finalize_weights: the largest spread
  * of a layer's transformed convolution weights and the pipe the 3x3 chain runs on, the GNN layers whose tail runs bf16x3, the largest
  * bound looseness, the layers whose attention runs bf16x3 with the largest q|k|v channel spread, the largest spread of the plain
- * linear layers' weights and the form they run.  The guards cover the convolution weights' per-output-channel spread, the layer
+ * linear layers' weights and the form they run.  The guards cover the convolution weights' per-output-channel spread (all eight 3x3 layers, conv1a by its plain weights), the layer
  * tails' bounds, the q / k / v projections' channel spread (round 6) and the linear layers' weight spread; they are estimates from
  * the WEIGHTS -- an input-dependent outlier (one activation 2^16 above the rest of its (side, pair)) is not seen by them.
  * "conv" also accepts "wx3" (round 3's removed bf16-plane convolution: runs "wino32" and says so on stderr).

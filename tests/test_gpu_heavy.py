@@ -111,16 +111,20 @@ def test_heavy_superpoint_weights_vs_reference_golden(conv):
             assert {tuple(p) for p in kp.astype(int)} == {tuple(p) for p in g[f"keypoints{side}"].astype(int)}, f"{name}: keypoint set, image {side}"
 
 
-def test_convolution_guard_moves_the_chain_to_the_fp32_kernels():
+@pytest.mark.parametrize("where", ["conv2a", "conv1a"])
+def test_convolution_guard_moves_the_chain_to_the_fp32_kernels(where):
     """One BatchNorm scale at 2^20: conv2a's transformed weights spread over more than 2^14, the typical channel would lose its low fp16
     plane under the layer's one scale -- the guard must put the chain on the fp32-MFMA Winograd kernels (and say so), and the outputs
-    still sit inside the tolerance of the SAME golden vectors (the re-parameterisation is exact for the reference)."""
+    still sit inside the tolerance of the SAME golden vectors (the re-parameterisation is exact for the reference).
+    "conv1a" (round 6): the same rescale between conv1a and conv1b -- conv1a's weights are in no transformed-weight table
+    (it runs on the fp32 pipe), so the guard reads the spread of its plain output channels."""
     from image_matching_amd import _lib as L
     sd = synth.make_superpoint_state_dict(128)
     f = np.float32(2.0 ** 20)
-    sd["down1.mpconv.1.conv.1.weight"][5] *= f
-    sd["down1.mpconv.1.conv.1.bias"][5] *= f
-    sd["down1.mpconv.1.conv.3.weight"][:, 5] *= np.float32(2.0 ** -20)
+    bn, nxt = ("down1.mpconv.1.conv.1", "down1.mpconv.1.conv.3") if where == "conv2a" else ("inc.conv.conv.1", "inc.conv.conv.3")
+    sd[bn + ".weight"][5] *= f
+    sd[bn + ".bias"][5] *= f
+    sd[nxt + ".weight"][:, 5] *= np.float32(2.0 ** -20)
     g = util.golden("sp_small.npz")
     H, W, seed, K = int(g["H"]), int(g["W"]), int(g["seed"]), int(g["max_keypoints"])
     eng = _engine(128, K)
