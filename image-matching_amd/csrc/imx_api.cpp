@@ -103,6 +103,8 @@ struct imx_handle_s {
   int upload_net = 0;                    // net whose finalize is running (upload() files allocations under it)
   // SuperPoint
   float *w1 = nullptr, *b1 = nullptr;
+  // the dense NMS map behind the "nms" tap when the detector ran the candidate-bit form: computed on demand by imx_debug_fetch
+  struct { const float* smap = nullptr; float* nms = nullptr; void* scratch = nullptr; int B = 0, H = 0, W = 0, radius = 0; bool pending = false; } nms_lazy;
   float c1a_l1 = 0.f, c1a_bmax = 0.f, c1a_spread = 1.f;   // (c1a_spread: max over median of conv1a's output-channel maxima, the fp16-plane guard)
   ConvW conv[8];   // conv1b, 2a, 2b, 3a, 3b, 4a, 4b, heads (convPa | convDa)
   GemmW pb, db;
@@ -847,14 +849,20 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   if (gemm(h, s, "convPb", h->pb, hd, 512, 256, nullptr, 0, 0, nullptr, 0, semi, 65, rows, false)) return -1;
   if (gemm(h, s, "convDb", h->db, hd + 256, 512, 256, nullptr, 0, 0, nullptr, 0, dense, d, rows, false)) return -1;
   h->det_Hc = Hc; h->det_Wc = Wc;
-  if (dense_only) { h->det_B = 0; return 0; }     // network only (imx_superpoint_dense)
+  if (dense_only) { h->det_B = 0; h->nms_lazy.pending = false; return 0; }     // network only (imx_superpoint_dense)
   RUN("softmax_shuffle", launch_softmax_shuffle(semi, 65, smap, B, Hc, Wc, s));
   WS(nms_scratch, unsigned, "sp.nms_scratch", nms_scratch_bytes(B, H8, W8, c.nms_radius));
-  RUN("nms", launch_nms(smap, nms, B, H8, W8, c.nms_radius, s, nms_scratch));
+  // Round 6: NMS + threshold + remove_borders leave the detector as candidate BIT rows (20 words per 640-pixel row) and the keypoint kernels
+  // count / scatter from those -- the dense where(max_mask, scores, 0) map (a 157-MB write and two reads at C3) is only materialised for
+  // the debug tap, for "keypoints" = dense, and where the bit form does not apply (radius > 4 or 0, a negative threshold: there the
+  // suppressed zeros pass `> threshold`)
+  const bool kp_bits = nms_candidate_bits_supported(c.nms_radius, c.keypoint_threshold) && h->opt.keypoints != 0;
+  if (kp_bits) RUN("nms", launch_nms_candidate_bits(smap, B, H8, W8, c.nms_radius, c.keypoint_threshold, c.remove_borders, s, nms_scratch));
+  else RUN("nms", launch_nms(smap, nms, B, H8, W8, c.nms_radius, s, nms_scratch));
 
   const int Ksel = c.max_keypoints >= 0 ? (c.max_keypoints > 0 ? c.max_keypoints : 1) : H8 * W8;
   KeypointArgs k{};
-  k.nms = nms; k.B = B; k.H = H8; k.W = W8; k.threshold = c.keypoint_threshold; k.border = c.remove_borders;
+  k.nms = kp_bits ? nullptr : nms; k.cand_bits = kp_bits ? nms_scratch : nullptr; k.scores = smap; k.B = B; k.H = H8; k.W = W8; k.threshold = c.keypoint_threshold; k.border = c.remove_borders;
   k.max_keypoints = c.max_keypoints; k.Ksel = Ksel;
   WS(row_count, int, "kp.row_count", (size_t)B * H8 * 4);
   WS(row_off, int, "kp.row_off", (size_t)B * H8 * 4);
@@ -883,6 +891,9 @@ int sp_detect(imx_handle_t h, const float* img0, const float* img1, int split, i
   tap(h, "semi", semi, {B, Hc, Wc, 65});
   tap(h, "desc_raw", dense, {B, Hc, Wc, d});
   tap(h, "score_map", smap, {B, H8, W8});
+  // the "nms" tap: the dense map is materialised only if somebody fetches it (after the keypoints: the pass overwrites the bit rows)
+  h->nms_lazy.smap = smap; h->nms_lazy.nms = nms; h->nms_lazy.scratch = nms_scratch; h->nms_lazy.B = B; h->nms_lazy.H = H8; h->nms_lazy.W = W8;
+  h->nms_lazy.radius = c.nms_radius; h->nms_lazy.pending = kp_bits;
   tap(h, "nms", nms, {B, H8, W8});
   return 0;
 }
@@ -1181,6 +1192,8 @@ int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
     if (v == "epilogue") o.qkv_amax = 0; else if (v == "kernel") o.qkv_amax = 1; else return -1;
   } else if (key == "sinkhorn_group") {
     if (v == "auto" || v == "0") o.sinkhorn_group = 0; else if (v == "1" || v == "2" || v == "4") o.sinkhorn_group = v[0] - '0'; else return -1;
+  } else if (key == "keypoints") {
+    if (v == "auto") o.keypoints = -1; else if (v == "dense") o.keypoints = 0; else if (v == "bits") o.keypoints = 1; else return -1;
   } else if (key == "sinkhorn_prefetch") {
     if (v == "auto") o.sinkhorn_prefetch = -1; else if (v == "off" || v == "0") o.sinkhorn_prefetch = 0; else if (v == "on" || v == "1") o.sinkhorn_prefetch = 1; else return -1;
   } else {
@@ -1600,6 +1613,12 @@ int imx_debug_fetch(imx_handle_t h, const char* name, float* host_out, int64_t c
     if (capacity < n) return fail(h, "imx_debug_fetch: capacity %lld < %lld elements", (long long)capacity, (long long)n);
     HIP_OK(h, hipSetDevice(h->device));
     HIP_OK(h, hipDeviceSynchronize());
+    if (h->nms_lazy.pending && name && std::string(name) == "nms") {
+      auto& z = h->nms_lazy;
+      HIP_OK(h, launch_nms(z.smap, z.nms, z.B, z.H, z.W, z.radius, nullptr, z.scratch));
+      HIP_OK(h, hipDeviceSynchronize());
+      z.pending = false;
+    }
     if (!it->second.blocked) {
       HIP_OK(h, hipMemcpy(host_out, it->second.p, (size_t)n * 4, hipMemcpyDeviceToHost));
       return 0;
@@ -1674,7 +1693,7 @@ int imx_set_option(imx_handle_t h, const char* key, const char* value) {
   return guarded(h, "imx_set_option", [&]() -> int {
     if (!h) return -1;
     if (!key || !value) return fail(h, "imx_set_option: null argument");
-    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino_h|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3, linear = auto|f16x2|bf16x3, attention_qblocks = auto|1|2, conv_swizzle = on|off, qkv_amax = epilogue|kernel, sinkhorn_group = auto|1|2|4, sinkhorn_prefetch = auto|off|on)", key, value);
+    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino_h|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3, linear = auto|f16x2|bf16x3, attention_qblocks = auto|1|2, conv_swizzle = on|off, qkv_amax = epilogue|kernel, sinkhorn_group = auto|1|2|4, sinkhorn_prefetch = auto|off|on, keypoints = auto|dense|bits)", key, value);
     return 0;
   });
 }
@@ -1695,6 +1714,7 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     else if (k == "qkv_amax") h->opt_text = o.qkv_amax ? "kernel" : "epilogue";
     else if (k == "sinkhorn_group") h->opt_text = o.sinkhorn_group ? std::to_string(o.sinkhorn_group) : std::string("auto");
     else if (k == "sinkhorn_prefetch") h->opt_text = o.sinkhorn_prefetch < 0 ? "auto" : o.sinkhorn_prefetch ? "on" : "off";
+    else if (k == "keypoints") h->opt_text = o.keypoints < 0 ? "auto" : o.keypoints ? "bits" : "dense";
     else if (k == "arith_guard") {      // read-only: what the weights-derived guards decided (after imx_finalize_weights)
       char buf[96];
       float sp = h->c1a_spread;

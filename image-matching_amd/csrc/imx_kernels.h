@@ -27,7 +27,8 @@ struct Options {
   int conv_swizzle = 1;    // "conv_swizzle": 1 = "on" (the tensor between two pair-form layers without a pool is tile-swizzled), 0 = "off" (blocked)
   int qkv_amax = 0;        // "qkv_amax": 0 = "epilogue" (a plain q|k|v projection's epilogue writes the (side, pair) maxima), 1 = "kernel" (the separate pass)
   int sinkhorn_group = 0;  // "sinkhorn_group": 0 = "auto" (2 slabs per workgroup up to 1024 columns, 4 above, 1 below 64 slabs), 1 | 2 | 4
-  int sinkhorn_prefetch = -1;  // "sinkhorn_prefetch": -1 = "auto" (on for the 16-wave form), 0 = "off", 1 = "on"
+  int sinkhorn_prefetch = -1;  // "sinkhorn_prefetch": -1 = "auto" (= off since round 6), 0 = "off", 1 = "on"
+  int keypoints = -1;          // "keypoints": -1 = "auto" (candidate bit rows where the NMS is the staged form and the threshold >= 0), 0 = "dense" (the NMS score map, three passes), 1 = "bits"
   int attention_qblocks = -1;  // "attention_qblocks": -1 = "auto" (2 where the padded keypoint count is a multiple of 256 and one block per wave would
                                //         still leave >= 1024 workgroups -- two per slot of the chip --, else 1) | 1 | 2: 32-query blocks per wave of the
                                //         two-plane attention at head dim 32 (attention_h2q2_kernel; bit-identical results)
@@ -180,9 +181,14 @@ hipError_t launch_dense_export(const float* semi, int ld, const float* dense, in
 // (radius 1..4: two bit-row masks for the staged three-kernel form; otherwise three float maps for the generic passes)
 size_t nms_scratch_bytes(int B, int H, int W, int radius);
 hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int radius, hipStream_t s, void* scratch);
+// the detector's form (radius 1..4, threshold >= 0): NMS + threshold + remove_borders as bit rows at the head of `scratch` (KeypointArgs::cand_bits)
+bool nms_candidate_bits_supported(int radius, float threshold);
+hipError_t launch_nms_candidate_bits(const float* scores, int B, int H, int W, int radius, float threshold, int border, hipStream_t s, void* scratch);
 // threshold + border removal + row-major compaction, then top-k (score desc, index asc on ties).
 struct KeypointArgs {
-  const float* nms;          // (B,H,W)
+  const float* nms;          // (B,H,W) where(max_mask, scores, 0); or null with:
+  const unsigned* cand_bits; // (B,H,ceil(W/32)) candidate bit rows of launch_nms_candidate_bits (NMS + threshold + border), and
+  const float* scores;       // (B,H,W) the score map they index (round 6)
   int B, H, W;
   float threshold; int border; int max_keypoints;   // -1 = keep all
   int* row_count;            // (B,H) scratch

@@ -117,9 +117,13 @@ __global__ __launch_bounds__(256) void nms_pool_cols(const float* __restrict__ r
 //   stage 1/2 supp = dilate(max_mask) (bit rows: shifts + an OR over 2R+1 rows), supp_scores = supp ? -1 : scores,
 //             max_mask |= ~supp & (supp_scores == max_pool(supp_scores))                halo 2R for the bits, R for the scores
 // stage 2 writes where(max_mask, scores, 0) instead of the bits.  Same compare-only arithmetic: bit-exact.
+// stage 3 (round 6) = stage 2 for the detector's own use: it writes the KEYPOINT CANDIDATE bits -- max_mask & score > threshold & inside
+// the border (superpoint_test.py:135-141) -- as bit rows again, and the keypoint kernels count / scatter from those 20 words per row
+// instead of three passes over the dense map (its 157-MB write here and two reads there, at C3).
 template <int R, int STAGE>
 __global__ __launch_bounds__(256) void nms_stage_kernel(const float* __restrict__ scores, const unsigned* __restrict__ min_,
-                                                         unsigned* __restrict__ mout, float* __restrict__ out, int H, int W, int WW) {
+                                                         unsigned* __restrict__ mout, float* __restrict__ out, int H, int W, int WW,
+                                                         float thr, int border) {
   constexpr int TY = 32, TX = 64, SY = TY + 2 * R, SX = TX + 2 * R, PITCH = SX | 1, NV = 8 + 2 * R;
   constexpr int MR = SY + 2 * R;                     // bit rows of the previous mask (halo 2R)
   __shared__ float P[SY * PITCH];                    // scores / supp_scores on the region
@@ -203,7 +207,11 @@ __global__ __launch_bounds__(256) void nms_stage_kernel(const float* __restrict_
         const bool was = (Mb[(ty + 2 * R) * 4 + (bit >> 5)] >> (bit & 31)) & 1u;
         mx = in && (was || (x >= 0.f && x == m));                                         // (:19-21)
       }
-      if constexpr (STAGE < 2) {
+      if constexpr (STAGE == 3) {
+        mx = mx && gy >= border && gy < H - border && gx >= border && gx < W - border;
+        if (mx) mx = img[(size_t)gy * W + gx] > thr;         // (the ORIGINAL score: P holds -1 where the pixel was suppressed)
+      }
+      if constexpr (STAGE != 2) {
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(mx);
         if (tx == 0 && gy < H) {
           unsigned* mo = mout + ((size_t)b * H + gy) * WW + (x0 >> 5);
@@ -218,14 +226,15 @@ __global__ __launch_bounds__(256) void nms_stage_kernel(const float* __restrict_
 }
 
 template <int R>
-hipError_t launch_nms_staged(const float* scores, float* out, unsigned* scratch, int B, int H, int W, hipStream_t s) {
+hipError_t launch_nms_staged(const float* scores, float* out, unsigned* scratch, int B, int H, int W, hipStream_t s, float thr = 0.f, int border = 0) {
   const int WW = (W + 31) / 32;
   unsigned* m0 = scratch;
   unsigned* m1 = scratch + (size_t)B * H * WW;
   dim3 grid((W + 63) / 64, (H + 31) / 32, B);
-  hipLaunchKernelGGL((nms_stage_kernel<R, 0>), grid, dim3(256), 0, s, scores, (const unsigned*)nullptr, m0, (float*)nullptr, H, W, WW);
-  hipLaunchKernelGGL((nms_stage_kernel<R, 1>), grid, dim3(256), 0, s, scores, (const unsigned*)m0, m1, (float*)nullptr, H, W, WW);
-  hipLaunchKernelGGL((nms_stage_kernel<R, 2>), grid, dim3(256), 0, s, scores, (const unsigned*)m1, (unsigned*)nullptr, out, H, W, WW);
+  hipLaunchKernelGGL((nms_stage_kernel<R, 0>), grid, dim3(256), 0, s, scores, (const unsigned*)nullptr, m0, (float*)nullptr, H, W, WW, 0.f, 0);
+  hipLaunchKernelGGL((nms_stage_kernel<R, 1>), grid, dim3(256), 0, s, scores, (const unsigned*)m0, m1, (float*)nullptr, H, W, WW, 0.f, 0);
+  if (out) hipLaunchKernelGGL((nms_stage_kernel<R, 2>), grid, dim3(256), 0, s, scores, (const unsigned*)m1, (unsigned*)nullptr, out, H, W, WW, 0.f, 0);
+  else hipLaunchKernelGGL((nms_stage_kernel<R, 3>), grid, dim3(256), 0, s, scores, (const unsigned*)m1, m0, (float*)nullptr, H, W, WW, thr, border);   // candidate bits over mask 0
   return hipGetLastError();
 }
 
@@ -295,6 +304,70 @@ __global__ __launch_bounds__(256) void kp_scatter_rows(KeypointArgs a) {
       cs[pos] = nms[(size_t)y * a.W + x];
     }
     off += __popcll(m);
+  }
+}
+
+// ---- the same three steps from the CANDIDATE BIT rows of nms_stage_kernel<R, 3> (round 6: a.cand_bits, a.scores = the un-suppressed score
+// map): a row is ceil(W/32) words, so counting is a popcount per word inside the per-image scan and the scatter touches the score map only
+// at the candidates.  Row-major order as before (words ascending, bits ascending).
+__global__ __launch_bounds__(256) void kp_scan_rows_bits(KeypointArgs a) {
+  __shared__ int part[256];
+  __shared__ int carry;
+  const int b = blockIdx.x, tid = threadIdx.x, WW = (a.W + 31) / 32;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int y0 = 0; y0 < a.H; y0 += 256) {
+    const int y = y0 + tid;
+    int v = 0;
+    if (y < a.H) {
+      const unsigned* wr = a.cand_bits + ((size_t)b * a.H + y) * WW;
+      for (int w = 0; w < WW; ++w) v += __popc(wr[w]);
+    }
+    part[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      int t = tid >= o ? part[tid - o] : 0;
+      __syncthreads();
+      part[tid] += t;
+      __syncthreads();
+    }
+    if (y < a.H) a.row_off[(size_t)b * a.H + y] = carry + part[tid] - v;
+    __syncthreads();
+    if (tid == 255) carry += part[255];
+    __syncthreads();
+  }
+  if (tid == 0) a.cand_count[b] = carry;
+}
+
+// one wave per image row: lane l owns word l (+ 64 k) of the row
+__global__ __launch_bounds__(256) void kp_scatter_rows_bits(KeypointArgs a) {
+  const int lane = threadIdx.x & 63, WW = (a.W + 31) / 32;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)a.B * a.H) return;
+  const int b = (int)(row / a.H), y = (int)(row % a.H);
+  const unsigned* wr = a.cand_bits + (size_t)row * WW;
+  const float* sc = a.scores + ((size_t)b * a.H + y) * a.W;
+  int off = a.row_off[row];
+  int* ci = a.cand_idx + (size_t)b * a.H * a.W;
+  float* cs = a.cand_score + (size_t)b * a.H * a.W;
+  for (int w0 = 0; w0 < WW; w0 += 64) {
+    unsigned bits = w0 + lane < WW ? wr[w0 + lane] : 0u;
+    const int n = __popc(bits);
+    int inc = n;                                      // inclusive prefix of the lanes' counts
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    int pos = off + inc - n;
+    while (bits) {
+      const int x = (w0 + lane) * 32 + __ffs(bits) - 1;
+      bits &= bits - 1;
+      ci[pos] = y * a.W + x;
+      cs[pos] = sc[x];
+      ++pos;
+    }
+    off += __shfl(inc, 63);
   }
 }
 
@@ -588,7 +661,23 @@ size_t nms_scratch_bytes(int B, int H, int W, int radius) {
   return (size_t)3 * B * H * W * sizeof(float);                                                    // row maxima, mask, supp_scores
 }
 
+bool nms_candidate_bits_supported(int radius, float threshold) { return radius >= 1 && radius <= 4 && threshold >= 0.f; }
+
+// simple_nms + threshold + remove_borders as candidate bit rows (B, H, ceil(W/32) words at the head of `scratch`): kp_*_bits' input
+hipError_t launch_nms_candidate_bits(const float* scores, int B, int H, int W, int radius, float threshold, int border, hipStream_t s, void* scratch) {
+  if (!nms_candidate_bits_supported(radius, threshold) || !scratch) return hipErrorInvalidValue;
+  last_form = "nms_staged_bits:hbm";
+  unsigned* bits = static_cast<unsigned*>(scratch);
+  switch (radius) {
+    case 1: return launch_nms_staged<1>(scores, nullptr, bits, B, H, W, s, threshold, border);
+    case 2: return launch_nms_staged<2>(scores, nullptr, bits, B, H, W, s, threshold, border);
+    case 3: return launch_nms_staged<3>(scores, nullptr, bits, B, H, W, s, threshold, border);
+    default: return launch_nms_staged<4>(scores, nullptr, bits, B, H, W, s, threshold, border);
+  }
+}
+
 hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int radius, hipStream_t s, void* scratch) {
+  if (!out) return hipErrorInvalidValue;
   if (radius < 0 || !scratch) return hipErrorInvalidValue;
   if (radius == 0) return hipMemcpyAsync(out, scores, (size_t)B * H * W * sizeof(float), hipMemcpyDeviceToDevice, s);
   if (radius <= 4) {
@@ -621,9 +710,15 @@ hipError_t launch_nms(const float* scores, float* out, int B, int H, int W, int 
 
 hipError_t launch_keypoints(const KeypointArgs& a, hipStream_t s) {
   long rows = (long)a.B * a.H;
-  hipLaunchKernelGGL(kp_count_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(kp_scan_rows, dim3(a.B), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(kp_scatter_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
+  if (a.cand_bits) {
+    if (!a.scores) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kp_scan_rows_bits, dim3(a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(kp_scatter_rows_bits, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(kp_count_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(kp_scan_rows, dim3(a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(kp_scatter_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
+  }
   int P = 1;
   if (a.max_keypoints > 0) { while (P < a.max_keypoints) P <<= 1; }
   if (P > 16384 && !a.sort_scratch) return hipErrorInvalidValue;

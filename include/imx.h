@@ -265,7 +265,10 @@ IMX_API const char* imx_timing_form(imx_handle_t h, int index);
  *   "qkv_amax"          "epilogue" (default) a plain q|k|v projection writes the (side, pair) maxima in its epilogue; "kernel": a separate pass;
  *   "sinkhorn_group"    "auto" (default: the most slabs per workgroup -- 4, 2 or 1 -- whose groups still fill the chip's resident
  *                       workgroup slots: 1024 up to 1024 columns, 512 above) | "1" | "2" | "4";
- *   "sinkhorn_prefetch" "auto" (default: off since round 6 -- two 16-wave workgroups per CU cover each other) | "off" | "on".
+ *   "sinkhorn_prefetch" "auto" (default: off since round 6 -- two 16-wave workgroups per CU cover each other) | "off" | "on";
+ *   "keypoints"         "auto" (default: "bits" where nms_radius is 1..4 and keypoint_threshold >= 0, else "dense") | "dense" (the
+ *                       keypoint kernels read the NMS'd score map, three passes) | "bits" (they read the candidate bit rows the last
+ *                       NMS stage writes; the "nms" debug tap is then computed when it is fetched).
  * Read-only (imx_get_option only): "arith_guard" -- what the weights-derived guards decided at imx_finalize_weights: the largest spread
  * of a layer's transformed convolution weights and the pipe the 3x3 chain runs on, the GNN layers whose tail runs bf16x3, the largest
  * bound looseness, the layers whose attention runs bf16x3 with the largest q|k|v channel spread, the largest spread of the plain

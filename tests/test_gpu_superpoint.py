@@ -483,3 +483,37 @@ def test_odd_sizes_whose_pooled_sizes_are_whole_tiles(H, W):
     ref = superpoint_ref.superpoint_forward(x, sd, util.sp_config(128, 100), return_dense=True)
     util.assert_close(_nchw(eng.fetch("x4")), ref["x4"].numpy(), f"{H}x{W} x4")
     util.assert_close(_nchw(eng.fetch("semi")), ref["semi"].numpy(), f"{H}x{W} semi")
+
+
+@pytest.mark.parametrize("H,W,radius,border,thr,K", [(480, 640, 4, 4, 0.005, 1024), (123, 165, 2, 0, 0.0005, -1), (40, 2216, 4, 8, 0.002, 300),
+                                                     (64, 72, 1, 16, 0.015, 30), (96, 128, 3, 4, 0.0, 5000)])
+def test_keypoints_from_candidate_bit_rows_equal_the_dense_form(H, W, radius, border, thr, K):
+    """Round 6: NMS + threshold + remove_borders leave the detector as candidate BIT rows and the keypoint kernels count
+    and scatter from those ("keypoints" = bits, the default where the staged NMS applies) instead of three passes over the dense
+    where(max_mask, scores, 0) map ("keypoints" = dense).  Compare-only work either way: keypoints, scores, descriptors and counts must
+    agree bit for bit -- on a row of more than 64 mask words (W = 2216), a zero threshold, a border wider than the NMS radius and an
+    image smaller than one NMS tile."""
+    from image_matching_amd import _lib as L
+    from image_matching_amd.engine import Engine
+    d = 128
+    cfg = util.sp_config(d, K, nms_radius=radius, remove_borders=border, keypoint_threshold=thr)
+    eng = Engine(cfg, util.sg_config(d), "cuda")
+    eng.load_state_dict(L.NET_SUPERPOINT, util.sp_sd(d))
+    x = torch.cat([util.pair(900 + i, H, W)[i & 1] for i in range(3)]).cuda()
+    got = {}
+    for mode in ("dense", "bits", "auto"):
+        eng.set_option("keypoints", mode)
+        assert eng.get_option("keypoints") == mode
+        eng.timing_reset()
+        eng.set_timing(True)
+        kpts, scores, desc, n = eng.superpoint(x)
+        torch.cuda.synchronize()
+        forms = {r[0]: r[3] for r in eng.timing_report(forms=True)}
+        eng.set_timing(False)
+        assert forms["nms"] == ("nms_staged:hbm" if mode == "dense" else "nms_staged_bits:hbm"), forms
+        got[mode] = (kpts.clone(), scores.clone(), desc.clone(), list(n))
+    assert sum(got["dense"][3]) > 0, "the case must produce keypoints"
+    for mode in ("bits", "auto"):
+        assert got[mode][3] == got["dense"][3], (mode, got[mode][3], got["dense"][3])
+        for a, b, name in zip(got[mode][:3], got["dense"][:3], ("keypoints", "scores", "descriptors")):
+            assert torch.equal(a, b), f"{name} differ between keypoints = {mode} and dense"
