@@ -1135,6 +1135,11 @@ int sg_forward(imx_handle_t h, int B, const SgSide sd[2], int64_t* m0, int64_t* 
     part = pt;
   }
   SinkhornArgs sk{S, u, v, B, N0p, N1p, sd[0].n, sd[1].n, N0, N1, h->bin_score, c.sinkhorn_iterations, part, h->opt.sinkhorn_group, h->opt.sinkhorn_prefetch};
+  if (part && h->opt.sinkhorn_merge > 0) {       // "sinkhorn_merge" = fused: the slab kernel merges its own column partials (auto = kernel: measured, sg_misc.hip)
+    WS(mc, unsigned, "sg.sk_merge_cnt", ((size_t)B + 1) * sizeof(unsigned));
+    sk.merge_cnt = mc;
+    tap(h, "sk_merge_cnt", mc, {(int64_t)B + 1});          // (word [B] != 0: a merging workgroup gave up waiting -- never seen; the tests read it)
+  }
   if (h->debug && part) {        // developer instrumentation: the slab kernel's workgroup lives (all zeros unless sg_misc.hip was built with -DSK_TRACE)
     const int Rs = sinkhorn_slab_rows(N1p), ng = N0p / Rs + 1;
     WS(trc, unsigned long long, "sg.sk_trace", (size_t)B * ng * 8 * sizeof(unsigned long long));
@@ -1192,6 +1197,8 @@ int apply_option(imx_handle_t h, const std::string& key, const std::string& v) {
     if (v == "epilogue") o.qkv_amax = 0; else if (v == "kernel") o.qkv_amax = 1; else return -1;
   } else if (key == "sinkhorn_group") {
     if (v == "auto" || v == "0") o.sinkhorn_group = 0; else if (v == "1" || v == "2" || v == "4") o.sinkhorn_group = v[0] - '0'; else return -1;
+  } else if (key == "sinkhorn_merge") {
+    if (v == "auto") o.sinkhorn_merge = -1; else if (v == "kernel") o.sinkhorn_merge = 0; else if (v == "fused") o.sinkhorn_merge = 1; else return -1;
   } else if (key == "keypoints") {
     if (v == "auto") o.keypoints = -1; else if (v == "dense") o.keypoints = 0; else if (v == "bits") o.keypoints = 1; else return -1;
   } else if (key == "sinkhorn_prefetch") {
@@ -1693,7 +1700,7 @@ int imx_set_option(imx_handle_t h, const char* key, const char* value) {
   return guarded(h, "imx_set_option", [&]() -> int {
     if (!h) return -1;
     if (!key || !value) return fail(h, "imx_set_option: null argument");
-    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino_h|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3, linear = auto|f16x2|bf16x3, attention_qblocks = auto|1|2, conv_swizzle = on|off, qkv_amax = epilogue|kernel, sinkhorn_group = auto|1|2|4, sinkhorn_prefetch = auto|off|on, keypoints = auto|dense|bits)", key, value);
+    if (apply_option(h, key, value)) return fail(h, "imx_set_option: unknown option or value '%s' = '%s' (mfma = x3|f32, latency_forms = auto|off|on|unfused, conv = wino|wino_h|wino32|direct, gnn_tail = auto|fused|bf16x3|unfused, attention = auto|f16x2|bf16x3, linear = auto|f16x2|bf16x3, attention_qblocks = auto|1|2, conv_swizzle = on|off, qkv_amax = epilogue|kernel, sinkhorn_group = auto|1|2|4, sinkhorn_prefetch = auto|off|on, sinkhorn_merge = auto|kernel|fused, keypoints = auto|dense|bits)", key, value);
     return 0;
   });
 }
@@ -1714,6 +1721,7 @@ const char* imx_get_option(imx_handle_t h, const char* key) {
     else if (k == "qkv_amax") h->opt_text = o.qkv_amax ? "kernel" : "epilogue";
     else if (k == "sinkhorn_group") h->opt_text = o.sinkhorn_group ? std::to_string(o.sinkhorn_group) : std::string("auto");
     else if (k == "sinkhorn_prefetch") h->opt_text = o.sinkhorn_prefetch < 0 ? "auto" : o.sinkhorn_prefetch ? "on" : "off";
+    else if (k == "sinkhorn_merge") h->opt_text = o.sinkhorn_merge < 0 ? "auto" : o.sinkhorn_merge ? "fused" : "kernel";
     else if (k == "keypoints") h->opt_text = o.keypoints < 0 ? "auto" : o.keypoints ? "bits" : "dense";
     else if (k == "arith_guard") {      // read-only: what the weights-derived guards decided (after imx_finalize_weights)
       char buf[96];

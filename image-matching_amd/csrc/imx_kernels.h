@@ -28,6 +28,7 @@ struct Options {
   int qkv_amax = 0;        // "qkv_amax": 0 = "epilogue" (a plain q|k|v projection's epilogue writes the (side, pair) maxima), 1 = "kernel" (the separate pass)
   int sinkhorn_group = 0;  // "sinkhorn_group": 0 = "auto" (2 slabs per workgroup up to 1024 columns, 4 above, 1 below 64 slabs), 1 | 2 | 4
   int sinkhorn_prefetch = -1;  // "sinkhorn_prefetch": -1 = "auto" (= off since round 6), 0 = "off", 1 = "on"
+  int sinkhorn_merge = -1;     // "sinkhorn_merge": -1 = "auto" (= kernel), 0 = "kernel" (sinkhorn_vmerge, a second launch per iteration), 1 = "fused" (the last-arriving slab workgroups of a pair merge its column partials)
   int keypoints = -1;          // "keypoints": -1 = "auto" (candidate bit rows where the NMS is the staged form and the threshold >= 0), 0 = "dense" (the NMS score map, three passes), 1 = "bits"
   int attention_qblocks = -1;  // "attention_qblocks": -1 = "auto" (2 where the padded keypoint count is a multiple of 256 and one block per wave would
                                //         still leave >= 1024 workgroups -- two per slot of the chip --, else 1) | 1 | 2: 32-query blocks per wave of the
@@ -307,6 +308,9 @@ struct SinkhornArgs {
   float* part;               // scratch (B, N0p/R + 1, N1p + 1, 2) for the slab form, R = sinkhorn_slab_rows(N1p); may be null
   int group = 0;             // Options::sinkhorn_group (0 = auto)
   int prefetch = -1;         // Options::sinkhorn_prefetch (-1 = auto)
+  unsigned* merge_cnt = nullptr;   // (B + 1) words, or null: with it the slab kernel merges its own partials ("sinkhorn_merge" = fused, round 6) --
+                                   // per-pair arrival counters over the iterations of one launch_sinkhorn (zeroed by it), word [B] = a spin that gave up
+  int it = 0;                      // (set by launch_sinkhorn: the iteration a launch belongs to)
   unsigned long long* trace = nullptr;   // developer instrumentation (a -DSK_TRACE build of sg_misc.hip only; tools/sinkhorn_trace.py): eight 64-bit words per
                                          // slab-kernel workgroup of the LAST iteration -- s_memrealtime at entry / after each slab / at exit, HW_ID, XCC_ID
 };

@@ -30,7 +30,7 @@ __device__ __forceinline__ LSE lse_merge(const LSE& a, const LSE& b) {
   const float nm = fmaxf(a.m, b.m);
   const float ea = (a.m == -INFINITY) ? 0.f : exp_neg(nm - a.m);
   const float eb = (b.m == -INFINITY) ? 0.f : exp_neg(nm - b.m);
-  return LSE{nm, a.s * ea + b.s * eb};
+  return LSE{nm, fmaf(b.s, eb, a.s * ea)};          // (explicit: left to contraction, two instantiations of one kernel fused different products)
 }
 // b.m finite (a slab's column always holds a row): ONE exponential -- of the two factors of lse_merge one is exp(0) = 1.  An empty
 // accumulator (a.m = -inf, a.s = 0): d = -inf, e = 0, the sum is b's.
@@ -200,6 +200,96 @@ __global__ __launch_bounds__(1024) void sinkhorn_cols(SinkhornArgs a) {
   }
 }
 
+// ---- v[j] = log_nu[j] - logsumexp over the slab groups' partial (max, sum) pairs, for one block of 64 columns of one pair: the body of
+// sinkhorn_vmerge, shared with the slab kernel's fused tail (round 6).  NT threads = 64 columns x GG chains; the arithmetic is that of 16
+// chains per column whatever GG is (a thread walks chains g, g + GG, ...), so both callers produce the same bits.
+// COH: the partials and u were written by OTHER workgroups of the same launch -- agent-scope (sc1) loads, which do not hit a stale line
+// of this XCD's L2.
+template <bool COH>
+__device__ __forceinline__ float2 ld_part(const float2* p) {
+  if constexpr (COH) {
+    const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__builtin_bit_cast(float, (unsigned)w), __builtin_bit_cast(float, (unsigned)(w >> 32)));
+  } else {
+    return *p;
+  }
+}
+template <bool COH>
+__device__ __forceinline__ float ld_f(const float* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+// pm / ps: [16][64] floats each, dm / ds: [16] each (LDS).  All NT threads of the workgroup call it (barriers inside).
+template <int GG, bool COH>
+__device__ __forceinline__ void vmerge_block(const SinkhornArgs& a, const float* __restrict__ part, int ngroup_max, int b, int m, int n, int ngroups,
+                                             int cb, float* pm, float* ps, float* dm, float* ds) {
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6, j = cb * 64 + c;
+  // two-pass merges: the maximum of the (max, sum) pairs first, then ONE exp per pair -- a chain of pairwise lse_merge()
+  // spends two exps (quarter-rate instructions) and two selects per pair
+  for (int vg = g; vg < 16; vg += GG) {
+    LSE t{-INFINITY, 0.f};
+    if (j < n) {
+      const float2* pb = reinterpret_cast<const float2*>(part + (size_t)b * ngroup_max * (a.N1p + 1) * 2) + j;
+      for (int s0 = vg; s0 < ngroups; s0 += 64) {
+        float2 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int sl = s0 + 16 * k;
+          q[k] = sl < ngroups ? ld_part<COH>(pb + (size_t)sl * (a.N1p + 1)) : make_float2(-INFINITY, 0.f);
+        }
+        const float nm = fmaxf(fmaxf(t.m, fmaxf(q[0].x, q[1].x)), fmaxf(q[2].x, q[3].x));
+        if (nm > -INFINITY) {
+          float sum = t.s * __builtin_amdgcn_exp2f((t.m - nm) * LOG2E);          // exp2(-inf) = 0 for an empty accumulator
+#pragma unroll
+          for (int k = 0; k < 4; ++k) sum = fmaf(q[k].y, __builtin_amdgcn_exp2f((q[k].x - nm) * LOG2E), sum);
+          t = LSE{nm, sum};
+        }
+      }
+    }
+    pm[vg * 64 + c] = t.m;
+    ps[vg * 64 + c] = t.s;
+  }
+  // The dustbin column j = n holds alpha in every row i <= m: its log-sum-exp over (alpha + u[i]) needs no S and no slab partial (round 6:
+  // thread 0 of every slab workgroup used to walk it, 8 LDS reads and ~80 instructions per slab on the wave the others wait for).  The
+  // block that owns column n reduces it here: 64-row chunks, chunk ch to chain ch % 16 (wave maximum and sum, two-pass), chains merged below.
+  const bool dust_block = cb == n / 64;                    // (workgroup-uniform)
+  if (dust_block) {
+    const float* u = a.u + (size_t)b * (a.N0p + 1);
+    for (int vw = g; vw < 16; vw += GG) {
+      LSE d{-INFINITY, 0.f};
+      for (int i0 = vw * 64; i0 <= m; i0 += 1024) {
+        const int i = i0 + c;
+        const float x = i <= m ? a.alpha + ld_f<COH>(u + i) : -INFINITY;
+        const float mx = wave_max_u(x);
+        if (mx > -INFINITY) {                              // (wave-uniform)
+          const float sum = wave_sum_u(__builtin_amdgcn_exp2f((x - mx) * LOG2E));
+          d = lse_merge(d, LSE{mx, sum});
+        }
+      }
+      if (c == 0) { dm[vw] = d.m; ds[vw] = d.s; }
+    }
+  }
+  __syncthreads();
+  if (g == 0 && j <= n) {
+    float nm = pm[c];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) nm = fmaxf(nm, pm[k * 64 + c]);
+    float sum = 0.f;                                                               // (nm finite for j < n: group 0 always contributes)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum = fmaf(ps[k * 64 + c], __builtin_amdgcn_exp2f((pm[k * 64 + c] - nm) * LOG2E), sum);
+    LSE t{nm, sum};
+    if (j == n) {
+      t = LSE{dm[0], ds[0]};
+#pragma unroll
+      for (int k = 1; k < 16; ++k) t = lse_merge(t, LSE{dm[k], ds[k]});
+    }
+    const float norm = -logf((float)(m + n));
+    const float log_nu = j < n ? norm : logf((float)m) + norm;
+    a.v[(size_t)b * (a.N1p + 1) + j] = log_nu - lse_value(t);
+  }
+  __syncthreads();                                         // (pm / ps / dm / ds are reused by the caller's next block)
+}
+
 // Slab form of one Sinkhorn iteration: a workgroup (16 waves) keeps R rows of S in LDS, computes their
 // u (row pass, :145) and immediately the partial column log-sum-exps of (Z + u) over those rows
 // (:146), so S is read from HBM/L2 once per iteration instead of twice.  Both passes hold their operands in
@@ -223,7 +313,7 @@ __global__ __launch_bounds__(1024) void sinkhorn_cols(SinkhornArgs a) {
 #define SK_SGPRS 80
 #endif
 #define SK_SGPR_ATTR __attribute__((amdgpu_num_sgpr(SK_SGPRS)))
-template <int R, int NW, int G, bool PF>
+template <int R, int NW, int G, bool PF, bool FM>
 __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornArgs a, float* __restrict__ part, int ngroup_max) {   // (eight waves per SIMD: <= 64 registers)
   // (16-byte aligned: the dynamic array starts behind the static ones, and at an 8-byte offset the b128 accesses of `tile` run at half
   // rate -- measured: two more static floats took the C5 iteration from 3.98 to 6.26 ms)
@@ -371,7 +461,8 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
     const float log_mu = i < m ? norm : log_mu_dust;
     const float ui = log_mu - lse_value(t);
     uu[tid] = ui;
-    a.u[(size_t)b * (a.N0p + 1) + i] = ui;
+    if constexpr (FM) __hip_atomic_store(a.u + (size_t)b * (a.N0p + 1) + i, ui, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by the pair's merging workgroup in this launch)
+    else a.u[(size_t)b * (a.N0p + 1) + i] = ui;
   }
   __syncthreads();
   const int rows = min(R, m + 1 - i0);      // rows of this slab, the last may be the dustbin row
@@ -441,10 +532,55 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
 #endif
   }  // slabs of the group
   float2* pb = reinterpret_cast<float2*>(part + ((size_t)b * ngroup_max + grp) * (a.N1p + 1) * 2);
+  if constexpr (!FM) {
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    const int j = tid + c * 64 * NW;
-    if (j < n) pb[j] = make_float2(cacc[c].m, cacc[c].s);
+    for (int c = 0; c < MAXC; ++c) {
+      const int j = tid + c * 64 * NW;
+      if (j < n) pb[j] = make_float2(cacc[c].m, cacc[c].s);
+    }
+  } else {
+    // Fused merge ("sinkhorn_merge" = fused; round 6, VERDICT r5 next 5: one launch per iteration) -- built, bit-identical to the merge
+    // kernel, and SLOWER: C3 x 64 pairs 1.70 -> 4.24 ms per 30 iterations, C5 x 8 pairs 3.22 -> 4.70 per 100 (profiles/r06_sinkhorn_trace.txt,
+    // sk27); not the default.  The pair's workgroups take a ticket as they finish; the last min(groups, column blocks) arrivals stay, wait
+    // until every group of the pair has arrived and merge one block of 64 columns each (more when there are fewer groups than blocks).
+    // Data written by one workgroup and read by another in the same launch moves through agent-scope (sc1) stores and loads -- the
+    // partials here, u in the row pass -- and the ticket is taken after this workgroup's stores have been acknowledged (s_waitcnt
+    // vmcnt(0) + barrier): no L2 write-back fence.  Why it loses: half of a pair's workgroups now end their lives as mergers -- eight or
+    // sixteen waves holding a slab slot while 64 x 16 chains wait on sc1 loads that are served past the L2 -- and every workgroup pays the
+    // ticket's round trip; sinkhorn_vmerge does the same work in 8 us with the whole chip, from L2.
+    // No deadlock: workgroups are dispatched in block order (x fastest: pair by pair) per XCD, so whatever a waiting workgroup waits
+    // for is either running or at the head of a queue whose slots are held by workgroups that do finish -- the first
+    // groups - min(groups, blocks) arrivals of every pair never wait.  The spin is bounded all the same (word [B] of the counters).
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int j = tid + c * 64 * NW;
+      if (j < n) {
+        const unsigned long long w = (unsigned long long)__builtin_bit_cast(unsigned, cacc[c].m) | ((unsigned long long)__builtin_bit_cast(unsigned, cacc[c].s) << 32);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(pb + j), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ unsigned ticket;
+    const int ng = m / (G * R) + 1;                         // the pair's groups that run (grp * G * R <= m)
+    const unsigned base = (unsigned)a.it * (unsigned)ng;
+    if (tid == 0) ticket = __hip_atomic_fetch_add(a.merge_cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int my = (int)(ticket - base);                    // arrival index 0 .. ng - 1
+    const int ncb = n / 64 + 1, nmrg = min(ng, ncb);        // blocks of 64 columns over 0 .. n; mergers
+    if (my >= ng - nmrg) {
+      if (tid == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(a.merge_cnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base < (unsigned)ng) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 24)) { __hip_atomic_store(a.merge_cnt + a.B, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+      }
+      __syncthreads();
+      float* pmm = sm;                                      // (the tile is free: 2 x 4 KB + 128 bytes, launch_slab_g sizes the dynamic LDS for it)
+      for (int cb = my - (ng - nmrg); cb < ncb; cb += nmrg)
+        vmerge_block<NW, true>(a, part, ngroup_max, b, m, n, ng, cb, pmm, pmm + 1024, pmm + 2048, pmm + 2064);
+    }
   }
 #ifdef SK_TRACE
   if (trw && tid == 0) trw[5] = __builtin_amdgcn_s_memrealtime();
@@ -454,77 +590,14 @@ __global__ __launch_bounds__(64 * NW) SK_SGPR_ATTR void sinkhorn_slab(SinkhornAr
 // v[j] = log_nu[j] - logsumexp over the slabs' partial (max, sum) pairs.  64 columns x 16 slab groups per
 // workgroup; each thread loads its (up to 4 at a time) partials before merging them, so the loads overlap.
 __global__ __launch_bounds__(1024) void sinkhorn_vmerge(SinkhornArgs a, const float* __restrict__ part, int nslab_max, int R, int G) {
-  __shared__ float pm[16][64], ps[16][64];
-  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int b = blockIdx.y, j = blockIdx.x * 64 + c;
+  __shared__ float pm[16 * 64], ps[16 * 64], dm[16], ds[16];
+  const int b = blockIdx.y;
   int m, n;
   counts(a, b, m, n);
   if (m == 0 || n == 0) return;
   const int nslab = (m / R + 1 + G - 1) / G;        // groups of G slabs, merged by sinkhorn_slab (nslab_max = groups per pair)
-  // two-pass merges: the maximum of the (max, sum) pairs first, then ONE exp per pair -- a chain of pairwise lse_merge()
-  // spends two exps (quarter-rate instructions) and two selects per pair
-  LSE t{-INFINITY, 0.f};
-  if (j < n) {
-    const float2* pb = reinterpret_cast<const float2*>(part + (size_t)b * nslab_max * (a.N1p + 1) * 2) + j;
-    for (int s0 = g; s0 < nslab; s0 += 64) {
-      float2 q[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int sl = s0 + 16 * k;
-        q[k] = sl < nslab ? pb[(size_t)sl * (a.N1p + 1)] : make_float2(-INFINITY, 0.f);
-      }
-      const float nm = fmaxf(fmaxf(t.m, fmaxf(q[0].x, q[1].x)), fmaxf(q[2].x, q[3].x));
-      if (nm > -INFINITY) {
-        const float ml = -nm * LOG2E;
-        float sum = t.s * __builtin_amdgcn_exp2f((t.m - nm) * LOG2E);          // exp2(-inf) = 0 for an empty accumulator
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sum = fmaf(q[k].y, __builtin_amdgcn_exp2f((q[k].x - nm) * LOG2E), sum);
-        (void)ml;
-        t = LSE{nm, sum};
-      }
-    }
-  }
-  // The dustbin column j = n holds alpha in every row i <= m: its log-sum-exp over (alpha + u[i]) needs no S and no slab partial (round 6:
-  // thread 0 of every slab workgroup used to walk it, 8 LDS reads and ~80 instructions per slab on the wave the others wait for).  The
-  // block that owns column n reduces it here, 1024 rows at a time: wave maximum and sum (two-pass), waves merged through LDS below.
-  __shared__ float dm[16], ds[16];
-  const bool dust_block = (int)blockIdx.x == n / 64;       // (block-uniform)
-  if (dust_block) {
-    const float* u = a.u + (size_t)b * (a.N0p + 1);
-    LSE d{-INFINITY, 0.f};
-    for (int i0 = 0; i0 <= m; i0 += 1024) {
-      const int i = i0 + (int)threadIdx.x;
-      const float x = i <= m ? a.alpha + u[i] : -INFINITY;
-      const float mx = wave_max_u(x);
-      if (mx > -INFINITY) {                                // (wave-uniform)
-        const float sum = wave_sum_u(__builtin_amdgcn_exp2f((x - mx) * LOG2E));
-        d = lse_merge(d, LSE{mx, sum});
-      }
-    }
-    if (c == 0) { dm[g] = d.m; ds[g] = d.s; }            // (c = lane, g = wave)
-  }
-  pm[g][c] = t.m;
-  ps[g][c] = t.s;
-  __syncthreads();
-  if (g == 0 && j <= n) {
-    float nm = pm[0][c];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) nm = fmaxf(nm, pm[k][c]);
-    const float ml = -nm * LOG2E;                                                  // finite: slab 0 always contributes
-    float sum = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) sum = fmaf(ps[k][c], __builtin_amdgcn_exp2f((pm[k][c] - nm) * LOG2E), sum);
-    (void)ml;
-    t = LSE{nm, sum};
-    if (j == n) {
-      t = LSE{dm[0], ds[0]};
-#pragma unroll
-      for (int k = 1; k < 16; ++k) t = lse_merge(t, LSE{dm[k], ds[k]});
-    }
-    const float norm = -logf((float)(m + n));
-    const float log_nu = j < n ? norm : logf((float)m) + norm;
-    a.v[(size_t)b * (a.N1p + 1) + j] = log_nu - lse_value(t);
-  }
+  if ((int)blockIdx.x * 64 > n) return;             // (columns 0 .. n)
+  vmerge_block<16, false>(a, part, nslab_max, b, m, n, nslab, (int)blockIdx.x, pm, ps, dm, ds);
 }
 
 // ------------------------------------------------------------------ matches
@@ -666,23 +739,26 @@ hipError_t launch_gather_desc(const float* src, int64_t sb, int64_t sc, int64_t 
   return hipGetLastError();
 }
 
-template <int R, int NW, int G, bool PF>
+template <int R, int NW, int G, bool PF, bool FM = false>
 static void launch_slab_g(const SinkhornArgs& a, int nslab_max, hipStream_t s) {
-  const size_t lds = ((size_t)R * a.N1p + a.N1p + 1) * sizeof(float);
+  size_t lds = ((size_t)R * a.N1p + a.N1p + 1) * sizeof(float);
+  if (FM && lds < 2080 * sizeof(float)) lds = 2080 * sizeof(float);      // the fused merge's chains live in the tile's LDS
   static unsigned long long attr = 0;
-  raise_lds_limit(reinterpret_cast<const void*>(sinkhorn_slab<R, NW, G, PF>), 96 * 1024, attr);
-  hipLaunchKernelGGL((sinkhorn_slab<R, NW, G, PF>), dim3((unsigned)nslab_max, (unsigned)a.B), dim3(64 * NW), lds, s, a, a.part, nslab_max);
+  raise_lds_limit(reinterpret_cast<const void*>(sinkhorn_slab<R, NW, G, PF, FM>), 96 * 1024, attr);
+  hipLaunchKernelGGL((sinkhorn_slab<R, NW, G, PF, FM>), dim3((unsigned)nslab_max, (unsigned)a.B), dim3(64 * NW), lds, s, a, a.part, nslab_max);
 }
 template <int R, int NW>
 static void launch_slab_k(const SinkhornArgs& a, int nslab_max, int G, hipStream_t s) {
-  // PF on where a row is split over two waves of a 16-wave workgroup (N1p = 2048: two workgroups per CU, each slab's loads an exposed
-  // latency): C5, 8 pairs x 100 iterations 4.20 -> 4.03 ms; off for the 8-wave form (four workgroups per CU cover each other: C3
-  // 1.98 -> 2.01 with it).  Measured and dropped beside it: dispatching every pair's short last group (the dustbin row's slab) after
-  // all full groups, so that the leftovers of 520 workgroups on 512 slots are the short ones -- 4.19 -> 4.29 ms at C5, nothing at C3
-  // (tools/sinkhorn_time.py --prefetch 0 1; the handle option "sinkhorn_prefetch" = auto | off | on overrides)
-  // Round 6: with the scalar-register cap two 16-wave workgroups ARE resident per CU and cover each other: off unless asked for
-  // (measurements at the kernel's head comment).
+  // Round 6: with the scalar-register cap two 16-wave workgroups ARE resident per CU and cover each other: the next-slab prefetch is off
+  // unless asked for (measurements at the kernel's head comment).  The fused merge ("sinkhorn_merge" = fused) is its own instantiation:
+  // as a run-time branch its code cost the default kernel 9 registers and 3 % of its time
   const bool p = a.prefetch > 0;
+  if (a.merge_cnt) {
+    if (G == 4) launch_slab_g<R, NW, 4, false, true>(a, nslab_max, s);
+    else if (G == 2) launch_slab_g<R, NW, 2, false, true>(a, nslab_max, s);
+    else launch_slab_g<R, NW, 1, false, true>(a, nslab_max, s);
+    return;
+  }
   if (G == 4) { if (p) launch_slab_g<R, NW, 4, true>(a, nslab_max, s); else launch_slab_g<R, NW, 4, false>(a, nslab_max, s); }
   else if (G == 2) { if (p) launch_slab_g<R, NW, 2, true>(a, nslab_max, s); else launch_slab_g<R, NW, 2, false>(a, nslab_max, s); }
   else launch_slab_g<R, NW, 1, false>(a, nslab_max, s);
@@ -696,7 +772,7 @@ static void launch_slab_iter(const SinkhornArgs& a, int nslab_max, int G, hipStr
   } else {
     launch_slab_k<R, 16>(a, nslab_max, G, s);
   }
-  hipLaunchKernelGGL(sinkhorn_vmerge, dim3((unsigned)((a.N1p + 1 + 63) / 64), (unsigned)a.B), dim3(1024), 0, s, a, a.part, nslab_max, R, G);
+  if (!a.merge_cnt) hipLaunchKernelGGL(sinkhorn_vmerge, dim3((unsigned)((a.N1p + 1 + 63) / 64), (unsigned)a.B), dim3(1024), 0, s, a, a.part, nslab_max, R, G);
 }
 
 hipError_t launch_sinkhorn(const SinkhornArgs& a, hipStream_t s) {
@@ -731,10 +807,16 @@ hipError_t launch_sinkhorn(const SinkhornArgs& a, hipStream_t s) {
     // back -- was measured and is SLOWER: 2.22 ms for the 64 C3 pairs in one group, 2.58 / 2.88 / 3.16 / 4.25 ms with groups of 150 /
     // 112 / 72 / 40 MB.  An iteration of 64 pairs is 73 us over two launches: the loop is paced by launches and their tails, not by
     // the 268 MB an iteration reads, and smaller groups only multiply the launches.)
+    SinkhornArgs ai = a;
+    if (ai.merge_cnt) {
+      e = hipMemsetAsync(ai.merge_cnt, 0, ((size_t)a.B + 1) * sizeof(unsigned), s);
+      if (e != hipSuccess) return e;
+    }
     for (int it = 0; it < a.iters; ++it) {
-      if (R == 16) launch_slab_iter<16>(a, nslab_max, G, s);
-      else if (R == 8) launch_slab_iter<8>(a, nslab_max, G, s);
-      else launch_slab_iter<4>(a, nslab_max, G, s);
+      ai.it = it;
+      if (R == 16) launch_slab_iter<16>(ai, nslab_max, G, s);
+      else if (R == 8) launch_slab_iter<8>(ai, nslab_max, G, s);
+      else launch_slab_iter<4>(ai, nslab_max, G, s);
     }
     return hipGetLastError();
   }

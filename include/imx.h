@@ -266,6 +266,8 @@ IMX_API const char* imx_timing_form(imx_handle_t h, int index);
  *   "sinkhorn_group"    "auto" (default: the most slabs per workgroup -- 4, 2 or 1 -- whose groups still fill the chip's resident
  *                       workgroup slots: 1024 up to 1024 columns, 512 above) | "1" | "2" | "4";
  *   "sinkhorn_prefetch" "auto" (default: off since round 6 -- two 16-wave workgroups per CU cover each other) | "off" | "on";
+ *   "sinkhorn_merge"    "auto" (default: = "kernel") | "kernel" (sinkhorn_vmerge: a second launch per iteration) | "fused" (the last
+ *                       slab workgroups of a pair merge its column partials: one launch per iteration, bit-identical, measured slower);
  *   "keypoints"         "auto" (default: "bits" where nms_radius is 1..4 and keypoint_threshold >= 0, else "dense") | "dense" (the
  *                       keypoint kernels read the NMS'd score map, three passes) | "bits" (they read the candidate bit rows the last
  *                       NMS stage writes; the "nms" debug tap is then computed when it is fetched).

@@ -465,3 +465,42 @@ def test_two_query_blocks_per_wave_are_bit_identical(name):
         assert np.array_equal(res["1"][0][i], res["2"][0][i]) and np.array_equal(res["1"][3][i], res["2"][3][i]), i
     assert np.array_equal(res["1"][1], res["2"][1]) and np.array_equal(res["1"][2], res["2"][2]) and np.array_equal(res["1"][4], res["2"][4])
     assert np.array_equal(res["2"][0][0], g["matches0"])
+
+
+@pytest.mark.parametrize("name", ["c3_pair_s59.npz", "c5_pair_s19.npz"])
+def test_sinkhorn_fused_merge_equals_the_merge_kernel(name):
+    """Round 6 (one launch per Sinkhorn iteration): the last-arriving slab workgroups of a pair merge its column
+    partials themselves ("sinkhorn_merge" = fused, the default) instead of a second launch (sinkhorn_vmerge, "kernel").  Both run the
+    same merge routine on the same 16 chains per column: potentials and matches must agree bit for bit -- on a full pair, for every
+    group size (1 = more groups than column blocks: most of a pair's workgroups leave without merging; 4 at one pair = fewer groups
+    than blocks: a merger takes several), on a batch of three with ragged counts (a pair with one column: a single block; three rows:
+    a single group), and the word that records a merger giving up its wait must stay zero."""
+    g = util.golden(name)
+    H, W, d, K, seed = (int(g[k]) for k in ("H", "W", "d", "K", "seed"))
+    one = {k: v.cuda() for k, v in _oracle_pair_inputs(seed, H, W, d, K).items()}
+    three = {k: torch.cat([v, v.flip(-1 if k.startswith("desc") else 1), v], 0).contiguous() for k, v in one.items()}
+    n0 = torch.tensor([K, 700, 3], dtype=torch.int32, device="cuda")
+    n1 = torch.tensor([900, K, 1], dtype=torch.int32, device="cuda")
+    eng, L = _engine(d)
+    eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(d))
+    eng.set_option("latency_forms", "off")
+    eng.set_debug(True)
+    for G in ("auto", "1", "2", "4"):
+        eng.set_option("sinkhorn_group", G)
+        res = {}
+        for how in ("kernel", "fused"):
+            eng.set_option("sinkhorn_merge", how)
+            assert eng.get_option("sinkhorn_merge") == how
+            a = _run(eng, one, (1, 1, H, W))
+            ua, va = eng.fetch("u").copy(), eng.fetch("v").copy()
+            if how == "fused":
+                assert int(eng.fetch("sk_merge_cnt").view(np.uint32)[-1]) == 0, "a merging workgroup gave up waiting"
+            b = _run(eng, three, (1, 1, H, W), n0, n1)
+            res[how] = (a, ua, va, b, eng.fetch("u").copy(), eng.fetch("v").copy())
+            if how == "fused":
+                assert int(eng.fetch("sk_merge_cnt").view(np.uint32)[-1]) == 0, "a merging workgroup gave up waiting (batch of three)"
+        for i in range(4):
+            assert np.array_equal(res["kernel"][0][i], res["fused"][0][i]) and np.array_equal(res["kernel"][3][i], res["fused"][3][i]), (G, i)
+        for i in (1, 2, 4, 5):
+            assert np.array_equal(res["kernel"][i], res["fused"][i]), (G, i, np.abs(res["kernel"][i] - res["fused"][i]).max())
+    assert np.array_equal(res["fused"][0][0], g["matches0"])
