@@ -17,7 +17,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 NAMES = {"conv1ab_pool": r"conv1ab_wino24", "conv3x3_pair": r"conv3x3_wino24p", "conv3x3_tile": r"conv3x3_wino24h", "attention": r"attention_h2q2_kernel|attention_x3p?_kernel|attention_kernel",
-         "sinkhorn": r"sinkhorn_slab", "gnn_tail": r"gnn_tail_h2|gnn_tail_x3", "gemm_x3": r"gemm_x3<", "gemm_h2": r"gemm_h2<"}
+         "sinkhorn": r"sinkhorn_slab", "gnn_tail": r"gnn_tail_h2|gnn_tail_x3", "gemm_x3": r"gemm_x3<", "gemm_h2": r"gemm_h2(<|IL)"}
 NSIMD, NCU, NXCD = 4, 256, 8
 
 
