@@ -504,3 +504,26 @@ def test_sinkhorn_fused_merge_equals_the_merge_kernel(name):
         for i in (1, 2, 4, 5):
             assert np.array_equal(res["kernel"][i], res["fused"][i]), (G, i, np.abs(res["kernel"][i] - res["fused"][i]).max())
     assert np.array_equal(res["fused"][0][0], g["matches0"])
+
+
+def test_sinkhorn_fused_merge_on_a_small_pair():
+    """The fused merge where the slab tile is smaller than the merge's 8 KB of chains (the launcher raises the dynamic LDS) and a pair
+    has fewer groups than workgroup slots by far: sg_small's pair (a few hundred keypoints), throughput forms, every group size."""
+    g = util.golden("sg_small.npz")
+    eng, L = _engine()
+    eng.load_state_dict(L.NET_SUPERGLUE, util.sg_sd(128))
+    eng.set_option("latency_forms", "off")
+    eng.set_debug(True)
+    t = {k: torch.from_numpy(g[k]).cuda() for k in KEYS}
+    for G in ("auto", "1", "2", "4"):
+        eng.set_option("sinkhorn_group", G)
+        res = {}
+        for how in ("kernel", "fused"):
+            eng.set_option("sinkhorn_merge", how)
+            out = _run(eng, t, (1, 1, 120, 160))
+            res[how] = (out, eng.fetch("u").copy(), eng.fetch("v").copy())
+        assert int(eng.fetch("sk_merge_cnt").view(np.uint32)[-1]) == 0
+        for i in range(4):
+            assert np.array_equal(res["kernel"][0][i], res["fused"][0][i]), (G, i)
+        assert np.array_equal(res["kernel"][1], res["fused"][1]) and np.array_equal(res["kernel"][2], res["fused"][2]), G
+    assert np.array_equal(res["fused"][0][0], g["matches0"])
