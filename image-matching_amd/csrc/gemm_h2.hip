@@ -71,6 +71,12 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
   const int first = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
   if (first >= ntiles) return;
   const int nmine = (ntiles - first + G - 1) / G, Q = nmine * nch;
+#ifdef GH2_STAGGER
+  // (experiment: the second workgroup of every CU starts late, so that its tile boundaries -- the store bursts -- fall into the other's chunks)
+  if ((int)blockIdx.x >= (G >> 1)) {
+    for (int k = 0; k < GH2_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
 
   auto place = [&](Cursor& cu) {
     cu.r0 = (cu.t / nct) * BM;
@@ -183,6 +189,19 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
       for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rb][PA[t]], wf[PB[t]], acc[rb], 0, 0, 0);
   };
 
+  // Developer instrumentation (-DGH2_TRACE; tools/gemm_h2_trace.py, profiles/r06_gemm_h2_trace.txt): s_memtime of the first 64 workgroups at
+  // every chunk's entry / before its barrier / after it, and at four points of every tile's epilogue (-DGH2_TRACE=2: also when a chunk's
+  // fragments have arrived -- that stamp keeps the split from interleaving with the MFMAs)
+#ifdef GH2_TRACE
+#define GH2_STAMP(k) do { if (trw && qi < 24) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (tid == 0) trw[qi * 4 + (k)] = t_; } } while (0)
+#define GH2_ESTAMP(k) do { if (trw && ntile_done < 4) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (tid == 0) trw[96 + ntile_done * 8 + (k)] = t_; } } while (0)
+  unsigned long long* const trw = (p.trace && blockIdx.x < 64) ? p.trace + (size_t)blockIdx.x * 128 : nullptr;
+  int ntile_done = 0;
+#else
+#define GH2_STAMP(k) do {} while (0)
+#define GH2_ESTAMP(k) do {} while (0)
+#endif
+  int qi = 0;                        // chunks multiplied so far
   // epilogue from registers (gemm_x3.hip): lane (col = i, kb) holds rows (r & 3) + 8 (r >> 2) + 4 kb of its column; the accumulators
   // carry sA sW: one fma un-scales and adds the bias
   auto epilogue = [&](const Cursor& cu, auto full) __attribute__((always_inline)) {
@@ -194,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
     const bool track = p.amax || p.amax_row;
     const int left = track ? cu.left - (wr * WROWS + 4 * kb) : -0x40000000;
     unsigned mx = 0;
+    GH2_ESTAMP(0);
     if (col < p.N) {
       const float bias = p.bias ? p.bias[col] : 0.f;
       float* o = p.out + (size_t)rbase * p.ldo + col;
@@ -222,6 +242,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
         }
       }
     }
+    GH2_ESTAMP(1);
     if (track) {
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
@@ -239,13 +260,17 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
     // vector-memory state of all predecessors of a block, and with this path's stores and bias load in the mix it gave up counting and
     // put s_waitcnt vmcnt(0) at the head of EVERY chunk -- the A rows and weight fragments requested one and two chunks ahead were
     // waited for one chunk later: a memory latency per chunk (round 6: 5.6 k cycles per chunk whatever the matrix work, both forms).
+    GH2_ESTAMP(2);
     __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
+    GH2_ESTAMP(3);
+#ifdef GH2_TRACE
+    ++ntile_done;
+#endif
   };
 
   Cursor comp{first, 0, 0, 0, 0, BM, 1.f};
   place(comp);
   Cursor wcur = comp, acur = comp;
-  int qi = 0;                        // chunks multiplied so far
   f16x8 wfa[2][2], wfb[2][2];        // the two steps' weight fragments of the current and of the next chunk
   gload(arega, sca, lfa, acur);      // chunk 0
   advance(acur);
@@ -259,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
   // weight fragments of chunk q+1 are requested a whole chunk ahead, the A rows of chunk q+3 as soon as the registers of chunk q+1 are free
   auto chunk = [&](const _Float16 (&Ar)[2][BM * RS], _Float16 (&Ad)[2][BM * RS], const f16x8 (&wcurf)[2][2], f16x8 (&wnext)[2][2],
                    f32x4 (&areg)[4], float& sc, int& lf) __attribute__((always_inline)) {
+    GH2_STAMP(0);
     f16x8 af[2][RB][2];
     frags(Ar, af);
     advance(wcur);
@@ -268,6 +294,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
     const int lf_stored = lf;
     advance(acur);
     gload(areg, sc, lf, acur);               // chunk q+3
+#if defined(GH2_TRACE) && GH2_TRACE > 1
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the fragments have arrived: what the first MFMA waits for)
+    GH2_STAMP(1);
+#endif
     step(af[0], wcurf[0]);
     step(af[1], wcurf[1]);
 #pragma unroll
@@ -277,7 +307,9 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
       __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // and at most one LDS store
     }
     lzero(Ad, lf_stored);
+    GH2_STAMP(2);
     __syncthreads();
+    GH2_STAMP(3);
     if (comp.c == nch - 1 && qi < Q) {       // block-uniform (qi >= Q: the padding chunk of an odd stream, below)
       if (comp.r0 + BM <= p.M) epilogue(comp, BoolC<true>{}); else epilogue(comp, BoolC<false>{});
     }

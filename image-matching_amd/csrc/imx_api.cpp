@@ -704,6 +704,12 @@ int gemm(imx_handle_t h, hipStream_t s, const char* name, const GemmW& W, const 
       return fail(h, "internal: gemm '%s' was planned on fp16 planes but cannot run there", name);
     am->done = am->amax != nullptr;
     am->h2 = true;
+    if (h->debug) {        // developer instrumentation: chunk stamps of the first 64 workgroups (all zeros unless gemm_h2.hip was built with -DGH2_TRACE); the LAST launch's stay
+      WS(trc, unsigned long long, (std::string("sg.gh2_trace_") + name).c_str(), (size_t)64 * 128 * sizeof(unsigned long long));
+      HIP_OK(h, hipMemsetAsync(trc, 0, (size_t)64 * 128 * sizeof(unsigned long long), s));
+      gh.trace = trc;
+      tap(h, (std::string("gh2_trace_") + name).c_str(), trc, {64, 256});
+    }
     RUN(name, launch_gemm_h2(gh, W.wh2, s));
     return 0;
   }

@@ -132,6 +132,7 @@ struct GemmArgs {
   const unsigned* sa1; int sa1_stride, sa1_off, sa1_cross;
   unsigned* amax_row; int amax_row_stride, amax_row_off;
   float w_inv;
+  unsigned long long* trace = nullptr;   // developer instrumentation (a -DGH2_TRACE build of gemm_h2.hip only): s_memtime stamps of the first workgroups' chunks
 };
 bool gemm_x3_amax_supported(const GemmArgs& a);
 // wh2 = the weights as two fp16 planes of w s in B-fragment order [Npad/32][K/16][2][64][8] (imx_api.cpp: split_f16x2)
