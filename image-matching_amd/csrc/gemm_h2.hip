@@ -58,7 +58,7 @@ __device__ __forceinline__ void split_h2(float x0, float x1, f16x2& h, f16x2& m)
 struct Cursor { int t, c, r0, n0, sp, left; float sA; };
 
 template <int BN, bool RES, bool RELU>
-__global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __restrict__ wx, int nct, int ntiles) {
+__global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __restrict__ wx, int nct, int ntiles, int stagger) {
   constexpr int WC = BN / 32, WR = 4 / WC, WROWS = BM / WR, RB = WROWS / 32;   // BN = 128: 1 x 4 waves of 128 x 32; BN = 64: 2 x 2 of 64 x 32
   // two separate objects (not one [2] array): the compiler must see that the stores of chunk q+1 never alias the loads of chunk q
   __shared__ __attribute__((aligned(16))) _Float16 As0[2][BM * RS];
@@ -71,12 +71,12 @@ __global__ __launch_bounds__(256, 2) void gemm_h2(GemmArgs p, const _Float16* __
   const int first = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
   if (first >= ntiles) return;
   const int nmine = (ntiles - first + G - 1) / G, Q = nmine * nch;
-#ifdef GH2_STAGGER
-  // (experiment: the second workgroup of every CU starts late, so that its tile boundaries -- the store bursts -- fall into the other's chunks)
-  if ((int)blockIdx.x >= (G >> 1)) {
-    for (int k = 0; k < GH2_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
+  // Staggered start (round 6): the workgroups run in lockstep -- same K, same start -- so every tile boundary was a chip-wide burst of
+  // stores followed by a chip-wide wait for it (stamps, profiles/r06_gemm_h2_trace.txt: 18.7 k cycles of s_waitcnt vmcnt(0) after the first
+  // tile of q|k|v at C5 against 1.2 - 4.5 k after the later, already spread ones).  Eight groups of workgroups start 64 x 31 cycles apart:
+  // C5's three launches per layer 3.80 -> 3.59 ms per step (2 x 127, 4 x 63, 4 x 127, 2 x 254: 3.66 / 3.65 / 3.61 / 3.64).  Timing only.
+  if (stagger)
+    for (int k = 0; k < ((int)blockIdx.x * 8) / G; ++k) __builtin_amdgcn_s_sleep(31);
 
   auto place = [&](Cursor& cu) {
     cu.r0 = (cu.t / nct) * BM;
@@ -378,13 +378,14 @@ hipError_t launch_gemm_h2(const GemmArgs& a, const void* wh2, hipStream_t s) {
   const int nct = a.Npad / (wide ? 128 : 64), ntiles = ((a.M + BM - 1) / BM) * nct;
   last_form = "gemm_h2:f16x2";
   const dim3 grid((unsigned)(ntiles < want ? ntiles : want));
+  const int stagger = ntiles >= want ? 1 : 0;             // (a full chip: see the kernel)
 #define IMX_H2(BN_)                                                                                      \
   if (a.res) {                                                                                           \
-    if (a.relu) hipLaunchKernelGGL((gemm_h2<BN_, true, true>), grid, dim3(256), 0, s, a, wx, nct, ntiles);  \
-    else hipLaunchKernelGGL((gemm_h2<BN_, true, false>), grid, dim3(256), 0, s, a, wx, nct, ntiles);        \
+    if (a.relu) hipLaunchKernelGGL((gemm_h2<BN_, true, true>), grid, dim3(256), 0, s, a, wx, nct, ntiles, stagger);  \
+    else hipLaunchKernelGGL((gemm_h2<BN_, true, false>), grid, dim3(256), 0, s, a, wx, nct, ntiles, stagger);        \
   } else {                                                                                               \
-    if (a.relu) hipLaunchKernelGGL((gemm_h2<BN_, false, true>), grid, dim3(256), 0, s, a, wx, nct, ntiles); \
-    else hipLaunchKernelGGL((gemm_h2<BN_, false, false>), grid, dim3(256), 0, s, a, wx, nct, ntiles);       \
+    if (a.relu) hipLaunchKernelGGL((gemm_h2<BN_, false, true>), grid, dim3(256), 0, s, a, wx, nct, ntiles, stagger); \
+    else hipLaunchKernelGGL((gemm_h2<BN_, false, false>), grid, dim3(256), 0, s, a, wx, nct, ntiles, stagger);       \
   }
   if (wide) { IMX_H2(128) } else { IMX_H2(64) }
 #undef IMX_H2
