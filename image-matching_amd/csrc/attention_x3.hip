@@ -407,9 +407,6 @@ __global__ __launch_bounds__(256, 2) void attention_x3_kernel(AttnArgs p, float 
 // at a time.  Per query the instructions and their order are attention_x3_kernel's: bit-identical output (tools/ubench/attn_x3_bench
 // QB=1 / QB=2 dumps, tests/test_gpu_superglue.py).  Same box: 300 -> 281 us per launch, 5.83 -> 5.49 ms per C3 step.
 __global__ __launch_bounds__(256, 2) void attention_h2q2_kernel(AttnArgs p, float scale) {
-#ifdef STG_ATT
-  IMX_STAGGER_START(STG_ATT);
-#endif
   typedef FmtH2 F;
   typedef F::T E;
   typedef F::x8 x8;

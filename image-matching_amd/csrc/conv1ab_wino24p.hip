@@ -69,9 +69,6 @@ __device__ __forceinline__ float v_scale_of_bound(float bound) {
 }
 
 __global__ __launch_bounds__(512) void conv1ab_wino24p(ConvArgs p, int tiles_x, int tiles_y, int ntiles) {
-#ifdef STG_CONV1
-  IMX_STAGGER_START(STG_CONV1);
-#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_1p[];
   float* raw = reinterpret_cast<float*>(smem_1p + NG * VGRP * 2);               // [NG][192][RSH]: 32 channels of each conv1a patch
   float* img = raw + NG * RAWSZ;                                                // [NG][12][20]

@@ -107,9 +107,6 @@ __device__ __forceinline__ float v_scale_inv(unsigned amax_bits) {
 
 template <bool POOL, bool RELU, bool FASTW, bool INZ>
 __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, int tiles_y, int ntiles, int nitems) {
-#ifdef STG_CONV3
-  IMX_STAGGER_START(STG_CONV3);
-#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
   float* raw = reinterpret_cast<float*>(smem_p + NG * VGRP * 2);               // [NG][NSUB][RAWC]   (V [NG][2][VPLANE] halves sits at 0)
   unsigned* amax_tab = reinterpret_cast<unsigned*>(raw + NG * NSUB * RAWC);    // [AMAX_SLOTS]: this workgroup's output maxima per image slot

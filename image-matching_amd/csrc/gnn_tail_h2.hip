@@ -75,9 +75,6 @@ __device__ __forceinline__ void image_barrier(int n) {
 // round 6, this kernel: NW = 8 -- one 256-row workgroup per CU, half the weight stream per row -- 2.86 against 2.70 ms per C3 step, same box)
 template <int NPASS, int NW>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void gnn_tail_h2_kernel(GnnTailArgs p) {
-#ifdef STG_TAIL
-  IMX_STAGGER_START(STG_TAIL);
-#endif
   constexpr int D = 128;
   constexpr int SPI = NW / 2;                              // k-steps per weight image (8 KB each: 4 blocks x 2 planes x 1 KB)
   constexpr int SLOT = SPI * 512;                          // 16-byte elements per image

@@ -5,18 +5,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Experiment switch (round 6): a kernel whose workgroups all start at once runs in lockstep -- its loads and stores come as chip-wide bursts.
-// IMX_STAGGER_START(unit) delays a workgroup by phase x 64 x unit cycles, phase = its XCD (linear block id & 7; STG_MODE 1: the next three bits).
-#ifndef STG_MODE
-#define STG_MODE 0
-#endif
-#define IMX_STAGGER_START(unit)                                                                                              \
-  do {                                                                                                                       \
-    const unsigned lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                                     \
-    const unsigned ph_ = STG_MODE ? (lin_ >> 3) & 7u : lin_ & 7u;                                                            \
-    for (unsigned k_ = 0; k_ < ph_; ++k_) __builtin_amdgcn_s_sleep(unit);                                                    \
-  } while (0)
-
 namespace imx {
 
 // Kernel-form options of a handle (imx_set_option; environment variables only seed the defaults at imx_create).  Launchers take
