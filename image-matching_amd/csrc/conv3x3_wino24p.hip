@@ -520,15 +520,14 @@ __global__ __launch_bounds__(512) void conv3x3_wino24p(ConvArgs p, int tiles_x, 
     // 3 ph .. 3 ph + 2 are this wave's, the other three the partner's
     f32x4 y[2][4];
     {
-      f32x4 s0[6], s1[6];
-      if (ph == 0) {
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj) { s0[jj] = sK0[jj]; s1[jj] = sK1[jj]; s0[3 + jj] = gs0[jj]; s1[3 + jj] = gs1[jj]; }
-      } else {
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj) { s0[jj] = gs0[jj]; s1[jj] = gs1[jj]; s0[3 + jj] = sK0[jj]; s1[3 + jj] = sK1[jj]; }
-      }
-      w24_out_cols(s0, s1, k8, y);
+      // (the column stage is instantiated in both branches of the wave-uniform order test: assembling one s0 / s1 in the branches and
+      // transforming after the join cost ~60 register copies per pair and wave, round 6)
+      auto cols = [&](const f32x4 (&a0)[3], const f32x4 (&a1)[3], const f32x4 (&b0)[3], const f32x4 (&b1)[3]) __attribute__((always_inline)) {
+        const f32x4 s0[6] = {a0[0], a0[1], a0[2], b0[0], b0[1], b0[2]}, s1[6] = {a1[0], a1[1], a1[2], b1[0], b1[1], b1[2]};
+        w24_out_cols(s0, s1, k8, y);
+      };
+      if (ph == 0) { cols(sK0, sK1, gs0, gs1); asm volatile("" ::: "memory"); }
+      else { cols(gs0, gs1, sK0, sK1); asm volatile("; order 1" ::: "memory"); }
     }
     P_STAMP(7)
     {
