@@ -30,6 +30,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int GT_STAGE_RS = 36;
+#ifndef GT_RING
+#define GT_RING 3      // weight images resident per workgroup: the stream runs two images ahead (round 6: with two, one ahead, 2.69 -> 2.63 ms
+                       // per C3 step on one box; 70 KB of LDS per workgroup, two workgroups per CU)
+#endif
 constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};      // the three plane products, smallest first: planes (A, B)
 
 // eight fp32 values (already scaled) -> the two fp16 planes of one B operand (attention_x3.hip: FmtH2::split)
@@ -81,8 +85,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gnn_tail_h2_kernel(GnnTailArg
   constexpr int NT = 64 * NW;
   constexpr int NSTEP = 2 * (16 + 8) + 8 * NPASS;          // k-steps of the whole tail
   constexpr int NIMG = NSTEP / SPI;
-  extern __shared__ __attribute__((aligned(16))) u32x4 ring[];       // [2][SLOT] weight images, the biases (2 D + D + NPASS D floats), the transpose tiles
-  float* lbias = reinterpret_cast<float*>(ring + 2 * SLOT);
+  extern __shared__ __attribute__((aligned(16))) u32x4 ring[];       // [GT_RING][SLOT] weight images, the biases (2 D + D + NPASS D floats), the transpose tiles
+  float* lbias = reinterpret_cast<float*>(ring + GT_RING * SLOT);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
   const int row0 = blockIdx.x * (32 * NW) + 32 * wave;
   float* stage = lbias + (3 + NPASS) * D + wave * (32 * GT_STAGE_RS);      // this wave's 32 x 32 transpose tile (row stride 36 floats: conflict-free 16-byte accesses)
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gnn_tail_h2_kernel(GnnTailArg
   const float c1 = s_h / k1, c2inv = 1.0f / k2, c3inv = 1.0f / k3;
   const float sin_lane = row_valid ? s_in : 0.f;                                  // rows past the count: inputs zeroed (the maxima do not cover them)
 
-  // ---- the weight stream: image i -> ring slot i & 1 by LDS-DMA, one image ahead (six pieces per thread: 16-byte elements j * NT + tid)
+  // ---- the weight stream: image i -> ring slot i % GT_RING by LDS-DMA, GT_RING - 1 images ahead (four pieces per thread: 16-byte elements j * NT + tid)
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
   int pend = 0;      // VMEM operations issued after the newest image's DMA pieces that may still be in flight at the next barrier
@@ -121,17 +125,20 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gnn_tail_h2_kernel(GnnTailArg
 #pragma unroll
     for (int j = 0; j < SLOT / NT; ++j)
       __builtin_amdgcn_global_load_lds((glb_void*)(stream + (size_t)i * SLOT + j * NT + tid),
-                                       (lds_void*)(ring + (i & 1) * SLOT + j * NT + 64 * wave), 16, 0, 0);
+                                       (lds_void*)(ring + (i % GT_RING) * SLOT + j * NT + 64 * wave), 16, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     pend = 0;
   };
-  // global k-step gs: at the first step of an image the workgroup meets (image gs / SPI is in its slot: its DMA was issued an image ago;
-  // the other slot is free) and the next image is requested
+  // global k-step gs: at the first step of an image the workgroup meets (image gs / SPI is in its slot: its DMA was issued GT_RING - 1
+  // images ago; the slot of the image just finished is free) and the image GT_RING - 1 ahead is requested
   auto enter_step = [&](int gs) __attribute__((always_inline)) {
     if (gs % SPI) return;
     const int img = gs / SPI;
-    if (img > 0) image_barrier(active ? pend : 0);
-    if (img + 1 < NIMG) fetch(img + 1);
+    // (GT_RING = 3: image img was requested TWO boundaries ago -- the four DMA pieces of image img + 1 were issued after it and may
+    // still be in flight)
+    constexpr int AHEAD = GT_RING - 1, YOUNGER = 4 * (AHEAD - 1);
+    if (img > 0) image_barrier((active ? pend : 0) + (img + 1 < NIMG ? YOUNGER : 0));
+    if (img + AHEAD < NIMG) fetch(img + AHEAD);
   };
   // one k-step: 12 MFMAs.  The A operands (four output blocks x two planes from the image) are read two blocks at a time and the two
   // blocks' MFMAs alternate, so consecutive MFMAs never share an accumulator.
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gnn_tail_h2_kernel(GnnTailArg
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) a[e][q] = __builtin_bit_cast(f16x8, ring[(i & 1) * SLOT + ((t * 4 + 2 * pr + e) * 2 + q) * 64 + lane]);
+        for (int q = 0; q < 2; ++q) a[e][q] = __builtin_bit_cast(f16x8, ring[(i % GT_RING) * SLOT + ((t * 4 + 2 * pr + e) * 2 + q) * 64 + lane]);
 #pragma unroll
       for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -191,6 +198,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gnn_tail_h2_kernel(GnnTailArg
   };
 
   fetch(0);
+  if constexpr (GT_RING > 2) { if (NIMG > 1) fetch(1); }
   for (int e = tid; e < (3 + NPASS) * D; e += NT) lbias[e] = e < 2 * D ? p.b1[e] : e < 3 * D ? p.b2[e - 2 * D] : p.b3[e - 3 * D];
   __syncthreads();                     // (a full fence: the biases, and image 0)
   f32x16 acc2[4];                      // x' (mlp.3's output, transposed)
@@ -323,7 +331,7 @@ hipError_t launch_gnn_tail_h2(const GnnTailArgs& a, hipStream_t s) {
   last_form = "gnn_tail_h2:f16x2";
   static unsigned long long attr[2] = {0, 0};
   auto go = [&](auto kern, int nw, int which) {
-    const size_t lds = 2 * (size_t)(nw / 2) * 8192 + (size_t)(3 * a.d + a.n3 + nw * 32 * GT_STAGE_RS) * sizeof(float);
+    const size_t lds = GT_RING * (size_t)(nw / 2) * 8192 + (size_t)(3 * a.d + a.n3 + nw * 32 * GT_STAGE_RS) * sizeof(float);
     raise_lds_limit(reinterpret_cast<const void*>(kern), (int)lds, attr[which]);
     hipLaunchKernelGGL(kern, dim3((unsigned)((a.M + 32 * nw - 1) / (32 * nw))), dim3(64 * nw), lds, s, a);
   };
