@@ -336,3 +336,21 @@ def test_heavy_weight_sets_are_function_preserving():
     # ... while the weights an implementation folds ARE heavy-tailed: a BatchNorm scale 2^10 above its neighbours
     w = synth.make_superglue_state_dict(d, variant="t", heavy=True)["gnn.layers.3.mlp.1.weight"]
     assert abs(w[9]) > 200 * np.median(np.abs(w))
+
+
+def test_every_handle_option_is_documented():
+    """Every key imx_set_option accepts (the chain of `key == "..."` in imx_api.cpp's apply_option) and the read-only ones appear in
+    include/imx.h's option documentation and in INTEGRATION.md -- a switch that changes which kernels run must not be findable only in
+    the source (undocumented behaviour changes)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "image-matching_amd", "csrc", "imx_api.cpp")).read()
+    body = src[src.index("int apply_option("):]
+    body = body[:body.index("\n}\n")]
+    keys = sorted(set(re.findall(r'key == "([a-z_0-9]+)"', body)))
+    assert len(keys) >= 12, keys
+    header = open(os.path.join(root, "include", "imx.h")).read()
+    integ = open(os.path.join(root, "INTEGRATION.md")).read()
+    for k in keys + ["arith_guard"]:
+        assert f'"{k}"' in header, f"option '{k}' is not documented in include/imx.h"
+        assert f"`{k}`" in integ, f"option '{k}' is not mentioned in INTEGRATION.md"
